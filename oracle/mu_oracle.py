@@ -1,0 +1,283 @@
+"""CPU oracle for the beta-divergence multiplicative-update (MU) hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package may import this
+module: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` are allowed to.  It is the checker, never the thing that is
+shipped or measured as the product.
+
+What it restates (file:line under /root/reference):
+
+* ``torchnmf/constants.py:3``        eps = float32 machine epsilon (2**-23)
+* ``torchnmf/metrics.py:6-96``       kl_div / euclidean / is_div / beta_div
+* ``torchnmf/nmf.py:52-92``          _double_backward_update (the MU step)
+* ``torchnmf/nmf.py:122-131``        beta == 1 closed-form denominators
+* ``torchnmf/nmf.py:297-409``        BaseComponent.fit (dense branch only)
+* ``torchnmf/nmf.py:691-693``        NMF.reconstruct   (V ~ H W^T)
+* ``torchnmf/nmf.py:776-779``        NMFD.reconstruct  (1-D convolutive)
+
+The reference obtains the MU numerator/denominator through two autograd
+``backward`` calls on the reconstruction; for a single linear (or conv1d)
+layer those gradients are plain contractions, which is what is written out
+here ("closed form").  Parity pinning: the reference has no golden vectors
+for this path, so this oracle is pinned against the
+reference itself, imported in the build container by
+``tools/make_golden.py``; the resulting fixtures live in ``tests/golden/``
+and ``tests/test_oracle_golden.py`` re-checks the oracle against them.
+
+Everything is float32 torch on CPU, like the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+EPS = float(torch.finfo(torch.float32).eps)  # constants.py:3
+
+
+# --------------------------------------------------------------------------
+# metrics.py:6-96
+# --------------------------------------------------------------------------
+def beta_div(x: torch.Tensor, y: torch.Tensor, beta: float) -> torch.Tensor:
+    """beta-divergence of reconstruction ``x`` from target ``y`` (metrics.py:60-96)."""
+    if beta == 2:  # metrics.py:39
+        d = x - y
+        return (d * d).sum() * 0.5
+    if beta == 1:  # metrics.py:22
+        yf = y.reshape(-1)
+        return yf @ ((y + EPS).log() - (x + EPS).log()).reshape(-1) - y.sum() + x.sum()
+    if beta == 0:  # metrics.py:56-57
+        ye, xe = y + EPS, x + EPS
+        return (ye / xe).sum() - ye.log().sum() + xe.log().sum() - y.numel()
+    xe = x.reshape(-1) + EPS  # metrics.py:85
+    yf = y.reshape(-1)
+    if beta < 0:  # metrics.py:87-88
+        yf = yf + EPS
+    bm = beta - 1
+    t1 = yf.pow(beta).sum()
+    t2 = xe.pow(beta).sum()
+    t3 = yf @ xe.pow(bm)
+    return (t1 + bm * t2 - beta * t3) / (beta * bm)
+
+
+def fit_loss(x: torch.Tensor, y: torch.Tensor, beta: float) -> float:
+    """The scalar ``fit`` tracks: sqrt(2 * beta_div) (nmf.py:362, 402)."""
+    return float((beta_div(x, y, beta) * 2).sqrt())
+
+
+def gamma_of(beta: float) -> float:
+    """MU exponent (nmf.py:341-346)."""
+    if beta < 1:
+        return 1.0 / (2.0 - beta)
+    if beta > 2:
+        return 1.0 / (beta - 1.0)
+    return 1.0
+
+
+def mu_terms(V: torch.Tensor, S: torch.Tensor, beta: float):
+    """(output_neg, output_pos) of nmf.py:61-74.  ``output_pos`` is None for beta == 1."""
+    if beta == 2:
+        return V, S  # no eps (nmf.py:62-63)
+    if beta == 1:
+        return V / (S + EPS), None
+    if beta == 0:
+        gp = (S + EPS).reciprocal()
+        return gp.square() * V, gp
+    Se = S + EPS
+    return Se.pow(beta - 2) * V, Se.pow(beta - 1)
+
+
+def _apply(theta: torch.Tensor, neg: torch.Tensor, pos: torch.Tensor, pos_is_closed_form: bool,
+           gamma: float, l1: float, l2: float) -> torch.Tensor:
+    """nmf.py:78-92: relu/eps, regularisers, multiplier, in-place multiply."""
+    neg = neg.relu() + EPS  # nmf.py:78
+    if not pos_is_closed_form:
+        pos = pos.relu() + EPS  # nmf.py:83 (skipped for the beta == 1 closed form)
+    if l1 > 0:
+        pos = pos + l1  # nmf.py:85-86
+    if l2 > 0:
+        pos = pos + l2 * theta  # nmf.py:87-88
+    mult = neg / pos
+    if gamma != 1:
+        mult = mult.pow(gamma)
+    return theta * mult
+
+
+# --------------------------------------------------------------------------
+# dense NMF:  V (N,C) ~ H (N,R) @ W (C,R)^T      (nmf.py:659-662, 691-693)
+# --------------------------------------------------------------------------
+def nmf_reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    return H @ W.t()
+
+
+def nmf_w_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    """W half-step (nmf.py:367-378).  grad_W of <S, G> is G^T H."""
+    S = nmf_reconstruct(H, W)
+    gn, gp = mu_terms(V, S, beta)
+    neg = gn.t() @ H
+    if gp is None:
+        pos = H.sum(0, keepdim=True)  # nmf.py:122-125
+        return _apply(W, neg, pos, True, gamma, l1, l2)
+    return _apply(W, neg, gp.t() @ H, False, gamma, l1, l2)
+
+
+def nmf_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    """H half-step with the already updated W (nmf.py:380-391).  grad_H is G W."""
+    S = nmf_reconstruct(H, W)
+    gn, gp = mu_terms(V, S, beta)
+    neg = gn @ W
+    if gp is None:
+        pos = W.sum(0)  # nmf.py:128-131 -> (R,)
+        return _apply(H, neg, pos, True, gamma, l1, l2)
+    return _apply(H, neg, gp @ W, False, gamma, l1, l2)
+
+
+# --------------------------------------------------------------------------
+# NMFD:  V (B,C,L) ~ sum_t W[:,:,t] H[:,:,l-t]    (nmf.py:706-713, 776-779)
+#        W (C,R,T), H (B,R,L-T+1)
+# --------------------------------------------------------------------------
+def nmfd_reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    B, R, Lh = H.shape
+    C, _, T = W.shape
+    out = torch.zeros(B, C, Lh + T - 1, dtype=H.dtype)
+    for t in range(T):
+        # out[b, c, j + t] += sum_r W[c, r, t] H[b, r, j]
+        out[:, :, t:t + Lh] += torch.einsum('cr,brj->bcj', W[:, :, t], H)
+    return out
+
+
+def _nmfd_grad_w(G: torch.Tensor, H: torch.Tensor, T: int) -> torch.Tensor:
+    # W.grad[c,r,t] = sum_b sum_j G[b,c,j+t] H[b,r,j]            
+    Lh = H.shape[2]
+    cols = [torch.einsum('bcj,brj->cr', G[:, :, t:t + Lh], H) for t in range(T)]
+    return torch.stack(cols, dim=2)
+
+
+def _nmfd_grad_h(G: torch.Tensor, W: torch.Tensor, Lh: int) -> torch.Tensor:
+    # H.grad[b,r,j] = sum_c sum_t W[c,r,t] G[b,c,j+t]
+    T = W.shape[2]
+    out = torch.zeros(G.shape[0], W.shape[1], Lh, dtype=G.dtype)
+    for t in range(T):
+        out += torch.einsum('cr,bcj->brj', W[:, :, t], G[:, :, t:t + Lh])
+    return out
+
+
+def nmfd_w_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    S = nmfd_reconstruct(H, W)
+    gn, gp = mu_terms(V, S, beta)
+    T = W.shape[2]
+    neg = _nmfd_grad_w(gn, H, T)
+    if gp is None:
+        pos = H.sum((0, 2), keepdim=True)  # (1,R,1)  nmf.py:122-125
+        return _apply(W, neg, pos, True, gamma, l1, l2)
+    return _apply(W, neg, _nmfd_grad_w(gp, H, T), False, gamma, l1, l2)
+
+
+def nmfd_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    S = nmfd_reconstruct(H, W)
+    gn, gp = mu_terms(V, S, beta)
+    Lh = H.shape[2]
+    neg = _nmfd_grad_h(gn, W, Lh)
+    if gp is None:
+        pos = W.sum((0, 2), keepdim=True).squeeze(0)  # (R,1)  nmf.py:128-131
+        return _apply(H, neg, pos, True, gamma, l1, l2)
+    return _apply(H, neg, _nmfd_grad_h(gp, W, Lh), False, gamma, l1, l2)
+
+
+# --------------------------------------------------------------------------
+# fit driver (nmf.py:297-409, dense branch)
+# --------------------------------------------------------------------------
+_STEPS = {
+    'nmf': (nmf_reconstruct, nmf_w_step, nmf_h_step),
+    'nmfd': (nmfd_reconstruct, nmfd_w_step, nmfd_h_step),
+}
+
+
+def validate_target(V: torch.Tensor, beta: float) -> None:
+    """nmf.py:329-336."""
+    assert bool(torch.all(V >= 0.)), "Target should be non-negative."
+    if float(V.min()) == 0 and beta <= 0:
+        raise ValueError("When beta <= 0 and V contains zeros, the training process may diverge. "
+                         "Please add small values to V, or use a positive beta value.")
+
+
+def fit(V: torch.Tensor, W0: torch.Tensor, H0: torch.Tensor, beta: float = 1, tol: float = 1e-4,
+        max_iter: int = 200, alpha: float = 0, l1_ratio: float = 0, trainable_W: bool = True,
+        trainable_H: bool = True, kind: str = 'nmf',
+        snapshots: Optional[List[int]] = None) -> Tuple[torch.Tensor, torch.Tensor, int, List[float], dict]:
+    """Returns (W, H, n_iter, losses, snaps).
+
+    ``losses[0]`` is loss_init, then one entry per 10th iteration (nmf.py:393-407).
+    ``snaps[k]`` = (W, H) after k iterations for k in ``snapshots``.
+    """
+    recon, w_step, h_step = _STEPS[kind]
+    V = V.float()
+    W, H = W0.clone().float(), H0.clone().float()
+    validate_target(V, beta)
+    gamma = gamma_of(beta)
+    l1 = alpha * l1_ratio
+    l2 = alpha * (1 - l1_ratio)
+    loss_init = fit_loss(recon(H, W), V, beta)
+    losses = [loss_init]
+    prev = loss_init
+    snaps = {}
+    n_iter = -1
+    for n_iter in range(max_iter):
+        if trainable_W:
+            W = w_step(V, W, H, beta, gamma, l1, l2)
+        if trainable_H:
+            H = h_step(V, W, H, beta, gamma, l1, l2)
+        if snapshots and (n_iter + 1) in snapshots:
+            snaps[n_iter + 1] = (W.clone(), H.clone())
+        if n_iter % 10 == 9:
+            loss = fit_loss(recon(H, W), V, beta)
+            losses.append(loss)
+            if (prev - loss) / loss_init < tol:
+                break
+            prev = loss
+    return W, H, n_iter + 1, losses, snaps
+
+
+# --------------------------------------------------------------------------
+# column-sharded NMF: simulated on one process.
+# Shard g owns V[:, Cg] and W[Cg]; H is replicated.  W half-step is local, the
+# H half-step sums per-shard partial numerators/denominators (the all-reduce),
+# and relu/eps/regularisers are applied after the sum.
+# --------------------------------------------------------------------------
+def shard_bounds(C: int, world: int) -> List[Tuple[int, int]]:
+    base, rem = divmod(C, world)
+    out, s = [], 0
+    for g in range(world):
+        e = s + base + (1 if g < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def nmf_h_partials(Vg, Wg, H, beta):
+    """Per-shard (numerator, denominator) of the H half-step before relu/eps."""
+    S = nmf_reconstruct(H, Wg)
+    gn, gp = mu_terms(Vg, S, beta)
+    if gp is None:
+        return gn @ Wg, Wg.sum(0)
+    return gn @ Wg, gp @ Wg
+
+
+def nmf_fit_sharded(V, W0, H0, world: int, beta=1, n_iter=10, alpha=0, l1_ratio=0):
+    V = V.float()
+    W, H = W0.clone().float(), H0.clone().float()
+    gamma = gamma_of(beta)
+    l1, l2 = alpha * l1_ratio, alpha * (1 - l1_ratio)
+    bounds = shard_bounds(V.shape[1], world)
+    for _ in range(n_iter):
+        for (s, e) in bounds:
+            W[s:e] = nmf_w_step(V[:, s:e], W[s:e], H, beta, gamma, l1, l2)
+        num = torch.zeros_like(H)
+        den = None
+        for (s, e) in bounds:
+            n_g, d_g = nmf_h_partials(V[:, s:e], W[s:e], H, beta)
+            num += n_g
+            den = d_g if den is None else den + d_g
+        H = _apply(H, num, den, beta == 1, gamma, l1, l2)
+    return W, H

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference (torchnmf 0.3.5).
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference; the reference cannot travel to the GPU box, the vectors do.
+Nothing from the reference is copied: this script imports it, feeds it seeded
+inputs through its public constructor (``NMF(W=W0, H=H0)``), and stores inputs
+and outputs as plain arrays.
+
+    python tools/make_golden.py            # rewrites tests/golden/
+
+Sets:
+  g1_nmf_small   NMF 64x96 r8, every beta branch x regularisation, tol disabled
+  g2_cfg1        NMF 256x512 r16 beta=1, 50 iterations (BASELINE configs[0])
+  g3_early_stop  tol=1e-4 / max_iter=200: returned n_iter and final factors
+  g4_frozen      trainable_W=False and trainable_H=False
+  g5_nmfd        NMFD (1,33,50) r4 T=3 ; (1,65,300) r4 T=12 ; (2,20,64) r3 T=5
+  g6_beta_div    metrics.beta_div known answers incl. zeros
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get('NMF_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+import torchnmf  # noqa: E402
+from torchnmf import nmf as ref_nmf  # noqa: E402
+from torchnmf.metrics import beta_div as ref_beta_div  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+NO_STOP = -1e9  # (prev - loss) / loss_init < tol is never true -> all iterations run
+
+
+class _LossTap:
+    """Stand-in for tqdm that records what fit() reports (nmf.py:365, 403-404)."""
+    log = []
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def set_postfix(self, loss=None, **k):
+        _LossTap.log.append(float(loss))
+
+    def update(self, n):
+        pass
+
+
+ref_nmf.tqdm = _LossTap
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def run_ref(cls, V, W0, H0, beta, tol, max_iter, alpha=0.0, l1_ratio=0.0, tW=True, tH=True):
+    m = cls(W=W0, H=H0, trainable_W=tW, trainable_H=tH)
+    _LossTap.log = []
+    n = m.fit(V, beta, tol, max_iter, False, alpha, l1_ratio)
+    return m.W.data.clone(), m.H.data.clone(), n, list(_LossTap.log)
+
+
+def loss_of(cls, V, W, H, beta):
+    with torch.no_grad():
+        return float((ref_beta_div(cls.reconstruct(H, W), V, beta) * 2).sqrt())
+
+
+def g1():
+    g = torch.Generator().manual_seed(1001)
+    V = torch.rand(64, 96, generator=g)
+    W0 = torch.randn(96, 8, generator=g).abs()
+    H0 = torch.randn(64, 8, generator=g).abs()
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy(), 'v_shift_nonpos_beta': np.float32(1e-3)}
+    cases = []
+    for beta in [-1, 0, 0.5, 1, 1.5, 2, 3]:
+        Vb = V + 1e-3 if beta <= 0 else V
+        for (alpha, l1r) in [(0, 0), (0.1, 0), (0.1, 0.5), (0.1, 1.0)]:
+            ks = [1, 10, 50] if alpha == 0 else [50]
+            tag = f'b{beta}_a{alpha}_l{l1r}'
+            for k in ks:
+                W, H, n, losses = run_ref(ref_nmf.NMF, Vb, W0, H0, beta, NO_STOP, k, alpha, l1r)
+                assert n == k
+                out[f'{tag}_W{k}'] = W.numpy()
+                out[f'{tag}_H{k}'] = H.numpy()
+                if k == 50:
+                    out[f'{tag}_losses'] = np.array(losses, dtype=np.float64)
+            out[f'{tag}_loss_init'] = np.float64(loss_of(ref_nmf.NMF, Vb, W0, H0, beta))
+            cases.append(tag)
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'g1_nmf_small.npz'), **out)
+
+
+def g2():
+    g = torch.Generator().manual_seed(1002)
+    V = bf16_round(torch.rand(256, 512, generator=g))
+    W0 = torch.randn(512, 16, generator=g).abs()
+    H0 = torch.randn(256, 16, generator=g).abs()
+    out = {'V_bf16_bits': V.to(torch.bfloat16).view(torch.int16).numpy(), 'W0': W0.numpy(), 'H0': H0.numpy()}
+    for k in (10, 50):
+        W, H, n, losses = run_ref(ref_nmf.NMF, V, W0, H0, 1, NO_STOP, k)
+        out[f'W{k}'] = W.numpy()
+        out[f'H{k}'] = H.numpy()
+        out[f'losses{k}'] = np.array(losses, dtype=np.float64)
+    out['loss_init'] = np.float64(loss_of(ref_nmf.NMF, V, W0, H0, 1))
+    np.savez_compressed(os.path.join(OUT, 'g2_cfg1.npz'), **out)
+
+
+def g3():
+    g = torch.Generator().manual_seed(1003)
+    V = torch.rand(64, 96, generator=g)
+    W0 = torch.randn(96, 8, generator=g).abs()
+    H0 = torch.randn(64, 8, generator=g).abs()
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy()}
+    for beta in (0.5, 1, 2):
+        W, H, n, losses = run_ref(ref_nmf.NMF, V, W0, H0, beta, 1e-4, 200)
+        out[f'b{beta}_n_iter'] = np.int64(n)
+        out[f'b{beta}_W'] = W.numpy()
+        out[f'b{beta}_H'] = H.numpy()
+        out[f'b{beta}_losses'] = np.array(losses, dtype=np.float64)
+    # tol = 0 still stops when the loss goes up or stalls (nmf.py:405)
+    W, H, n, losses = run_ref(ref_nmf.NMF, V, W0, H0, 1, 0.0, 400)
+    out['tol0_n_iter'] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, 'g3_early_stop.npz'), **out)
+
+
+def g4():
+    g = torch.Generator().manual_seed(1004)
+    V = torch.rand(48, 80, generator=g)
+    W0 = torch.randn(80, 6, generator=g).abs()
+    H0 = torch.randn(48, 6, generator=g).abs()
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy()}
+    for beta in (1, 2):
+        for name, tW, tH in (('frozenW', False, True), ('frozenH', True, False)):
+            W, H, n, _ = run_ref(ref_nmf.NMF, V, W0, H0, beta, NO_STOP, 20, tW=tW, tH=tH)
+            out[f'b{beta}_{name}_W'] = W.numpy()
+            out[f'b{beta}_{name}_H'] = H.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g4_frozen.npz'), **out)
+
+
+def g5():
+    out = {}
+    shapes = {'doc': ((1, 33, 50), 4, 3), 'mid': ((1, 65, 300), 4, 12), 'batch': ((2, 20, 64), 3, 5)}
+    for name, ((B, C, L), R, T) in shapes.items():
+        g = torch.Generator().manual_seed(1005 + len(name))
+        V = torch.rand(B, C, L, generator=g)
+        W0 = torch.randn(C, R, T, generator=g).abs()
+        H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+        out[f'{name}_V'], out[f'{name}_W0'], out[f'{name}_H0'] = V.numpy(), W0.numpy(), H0.numpy()
+        for beta in (0.5, 1, 2):
+            W, H, n, losses = run_ref(ref_nmf.NMFD, V, W0, H0, beta, NO_STOP, 30)
+            out[f'{name}_b{beta}_W30'] = W.numpy()
+            out[f'{name}_b{beta}_H30'] = H.numpy()
+            out[f'{name}_b{beta}_losses'] = np.array(losses, dtype=np.float64)
+            out[f'{name}_b{beta}_loss_init'] = np.float64(loss_of(ref_nmf.NMFD, V, W0, H0, beta))
+        W, H, n, _ = run_ref(ref_nmf.NMFD, V, W0, H0, 1, NO_STOP, 10, alpha=0.1, l1_ratio=0.5)
+        out[f'{name}_reg_W10'], out[f'{name}_reg_H10'] = W.numpy(), H.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g5_nmfd.npz'), **out)
+
+
+def g6():
+    g = torch.Generator().manual_seed(1006)
+    xs = {'rand': torch.rand(100, generator=g), 'zero': torch.zeros(100)}
+    ys = {'rand': torch.rand(100, generator=g), 'zero': torch.zeros(100)}
+    out = {'x_rand': xs['rand'].numpy(), 'y_rand': ys['rand'].numpy()}
+    for beta in [-1, 0, 0.5, 1, 1.5, 2, 3]:
+        for xn, x in xs.items():
+            for yn, y in ys.items():
+                out[f'b{beta}_x{xn}_y{yn}'] = np.float64(float(ref_beta_div(x, y, beta)))
+    np.savez_compressed(os.path.join(OUT, 'g6_beta_div.npz'), **out)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)  # reproducible summation order
+    assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
+    for fn in (g1, g2, g3, g4, g5, g6):
+        fn()
+        print('wrote', fn.__name__)
+    with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
+        f.write(f'generated by tools/make_golden.py from torchnmf {torchnmf.__version__} '
+                f'(reference mounted at {REF}), torch {torch.__version__}, CPU fp32, 1 thread\n')
