@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused beta-divergence MU iterations of dense NMF on MI355X.
+
+    python bench.py                         # 1 GPU, BASELINE configs[1]: NMF 4096x65536 rank 128 beta=1 bf16
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one MU iteration (W half-step then H half-step, nmf.py:366-391 of the reference) over a synthetic
+V already resident in HBM in the engine's packed layout.  With N > 1 every rank owns its own 65536-column
+shard of V and of W (weak scaling: the problem is 4096 x (65536 N)); H is replicated and the H half-step does
+ONE all-reduce (RCCL) per iteration.  `value` is the whole-job algorithmic GFLOP/s (8 * rows * total_cols *
+rank flops per iteration); iterations/s is reported next to it.
+
+Printed JSON also carries
+  roofline      the fused kernel's achieved TFLOP/s (algorithmic flops per launch / mean launch time measured
+                live with hipEvents on the launching stream) against the dense bf16 MFMA peak, plus the same
+                launch expressed as HBM GB/s of algorithmic bytes;
+  cpu_baseline  the reference's ATen op sequence (oracle/aten_port.py, fp32) timed on this box's host cores
+                on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # spec; ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--rows', type=int, default=4096)
+    ap.add_argument('--cols', type=int, default=65536, help='columns PER GPU')
+    ap.add_argument('--rank', type=int, default=128)
+    ap.add_argument('--beta', type=float, default=1.0)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
+    ap.add_argument('--stage', type=int, default=None, help='0 = register staging, 1 = LDS-DMA (default)')
+    ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(V, W0, H0, beta, iters):
+    """Time the reference's op sequence on the host cores (bounded sample of the same workload)."""
+    from oracle import aten_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.set_flush_denormal(True)   # the reference's own advice (README.md:101-102)
+    aten_port.mu_iterations(V, W0, H0, beta, 1)          # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    aten_port.mu_iterations(V, W0, H0, beta, iters)
+    dt = (time.perf_counter() - t0) / iters
+    return dt, cores
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # RCCL
+        group = dist.group.WORLD
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+
+    from torchnmf_amd.engine import DenseMU, KernelTimer
+
+    N, C, R, beta = a.rows, a.cols, a.rank, a.beta
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()   # bf16-representable, U[0,1)
+    if beta <= 0:
+        V += 2.0 ** -7
+    gw = torch.Generator(device=dev).manual_seed(2000 + rank)
+    W = torch.randn(C, R, device=dev, generator=gw).abs_()             # the reference's init law (nmf.py:221)
+    gh = torch.Generator(device=dev).manual_seed(3000)
+    H = torch.randn(N, R, device=dev, generator=gh).abs_()             # replicated
+    W0c, H0c = (W.cpu(), H.cpu()) if (rank == 0 and world == 1 and a.cpu_iters > 0) else (None, None)
+
+    eng = DenseMU(V, W, H, beta, precision=a.precision, stage=a.stage, group=group)
+    Vc = V.cpu() if W0c is not None else None
+    del V
+    torch.cuda.synchronize()
+
+    def step():
+        eng.w_step()
+        eng.h_step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+    flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R     # 4 (6) contractions of 2NCR
+    total_gflops = flops_per_iter_gpu * world / (ms_per_step * 1e-3) / 1e9
+
+    # ---- roofline leg: the same steps again, with hipEvents around every fused launch
+    roof = None
+    if not a.no_roofline:
+        eng.timer = KernelTimer(4 * a.steps)
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        spans = eng.timer.spans()
+        eng.timer.close()
+        eng.timer = None
+        all_ms = spans.get('w', []) + spans.get('h', [])
+        avg_ms = sum(all_ms) / len(all_ms)
+        flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
+        elt = 2 if a.precision == 'bf16' else 4
+        bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
+        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                'kernel': 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
+                'avg_launch_ms': round(avg_ms, 5),
+                'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
+                'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
+                'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        'algorithmic_bytes_per_launch': int(bytes_per_launch)}}
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                pass
+
+    cpu = None
+    if Vc is not None:
+        dt, cores = cpu_baseline(Vc, W0c, H0c, beta, a.cpu_iters)
+        cpu = {'value': round(flops_per_iter_gpu / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+               'iters_per_s': round(1.0 / dt, 4), 's_per_iter': round(dt, 4),
+               'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same {N}x{C} rank-{R} beta={beta:g} '
+                         f'workload, fp32, reference op sequence (oracle/aten_port.py), loss evaluation excluded'}
+
+    if rank == 0:
+        out = {
+            'metric': f'MU GFLOP/s (algorithmic {"8" if beta == 1 else "12"}*N*C*R per iteration), dense NMF '
+                      f'{N}x{C} rank-{R} beta={beta:g}; MU iterations/s alongside',
+            'value': round(total_gflops, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms_per_step, 2),
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)', 'data': 'synthetic',
+            'config': {'workload': f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
+                                   f'H replicated, 1 all-reduce/iter' if world > 1 else
+                                   f'NMF {N}x{C} rank={R} beta={beta:g} (BASELINE configs[1])',
+                       'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
+                       'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
+                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

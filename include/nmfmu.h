@@ -1,0 +1,162 @@
+/* nmfmu.h -- C ABI of the MI355X-native NMF multiplicative-update engine.
+ *
+ * This is the drop-in boundary for the one hot path of yoyololicon/pytorch-NMF
+ * (torchnmf 0.3.5) that this project accelerates: the dense beta-divergence MU
+ * iteration of `torchnmf.nmf.NMF.fit` / `NMFD.fit`.  The reference has no FFI
+ * of its own (it is pure Python over ATen), so each entry point below names the
+ * reference code it replaces (file:line under the reference checkout).  A
+ * maintainer's binding (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer unless noted;
+ *  - the library never allocates device memory: the caller owns every buffer
+ *    and sizes it with the nmfmu_*_bytes() queries;
+ *  - every call enqueues work on `stream` (a hipStream_t passed as void*) and
+ *    returns without synchronising; no hidden host<->device sync;
+ *  - return value: 0 = NMFMU_OK, > 0 = a hipError_t, < 0 = NMFMU_ERR_*;
+ *  - re-entrant; one host thread per device.
+ *
+ * Orientation.  The reference factorises V (N x C) ~ H (N x R) @ W (C x R)^T
+ * (nmf.py:659-662).  A half-step updates one factor (the "owner", M rows) using
+ * the other (the "panel", K rows) and X = V (H half-step) or V^T (W half-step),
+ * stored in a kernel-specific tiled layout (see csrc/nmfmu_layout.h).
+ */
+#ifndef NMFMU_H_
+#define NMFMU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMFMU_ABI_VERSION 1
+
+#define NMFMU_OK 0
+#define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
+#define NMFMU_ERR_ARG (-3)         /* inconsistent sizes or null pointer */
+
+/* precision of the MFMA operands (accumulation is always fp32, factors are kept in fp32) */
+#define NMFMU_PREC_BF16 0   /* X stored bf16; operands bf16                                   */
+#define NMFMU_PREC_BF16X3 1 /* X stored fp32; operands split hi+lo, 3 MFMAs per product        */
+
+/* beta branches of nmf.py:61-74 / metrics.py:78-96 */
+#define NMFMU_BETA_KL 0  /* beta == 1 */
+#define NMFMU_BETA_EUC 1 /* beta == 2 */
+#define NMFMU_BETA_IS 2  /* beta == 0 */
+#define NMFMU_BETA_GEN 3 /* anything else */
+
+/* how the panel tile reaches LDS */
+#define NMFMU_STAGE_REG 0 /* global -> VGPR -> ds_write */
+#define NMFMU_STAGE_DMA 1 /* global_load_lds (LDS-DMA)  */
+
+/* One factor (W or H) as the engine sees it. */
+typedef struct nmfmu_factor {
+  float* f;           /* fp32 master, [rows][rank] row-major contiguous: the nn.Parameter storage (nmf.py:216-237) */
+  void* p1_hi;        /* bf16 row-major image  [rows_pad][r_pad]          (nmfmu_image_bytes)                     */
+  void* p1_lo;        /* low plane, BF16X3 only (else NULL)                                                        */
+  void* p2_hi;        /* bf16 transposed tiles [rows_pad/64][r_pad][64]                                            */
+  void* p2_lo;
+  float* colsum;      /* [r_pad]  sum over rows of f: the beta==1 denominators of nmf.py:122-131                   */
+  float* colsum_part; /* [rows_pad/64][r_pad] scratch for the deterministic two-stage column sum                   */
+  int32_t rows;
+  int32_t rows_pad;   /* nmfmu_pad_rows(rows) */
+} nmfmu_factor;
+
+/* One MU half-step: everything `_double_backward_update` (nmf.py:52-92) needs. */
+typedef struct nmfmu_step {
+  const void* xp;      /* X in fragment order: owner.rows_pad x panel.rows_pad (nmfmu_pack_x)                      */
+  nmfmu_factor owner;  /* the factor being updated */
+  nmfmu_factor panel;  /* the factor held fixed    */
+  float* slab_num;     /* [nsplit][owner.rows_pad][r_pad] partial numerators                                       */
+  float* slab_den;     /* same, partial denominators (beta != 1; may be NULL for beta == 1)                        */
+  int32_t rank;
+  int32_t r_pad;       /* nmfmu_pad_rank(rank) */
+  int32_t nsplit;      /* contraction-axis split (workgroups per owner block), nmfmu_choose_nsplit                 */
+  int32_t precision;   /* NMFMU_PREC_*  */
+  int32_t stage;       /* NMFMU_STAGE_* */
+  float beta;
+  float gamma;         /* nmf.py:341-346 */
+  float l1, l2;        /* nmf.py:348-349 */
+} nmfmu_step;
+
+/* ---- static queries (host only, no device work) ------------------------------------------------------------ */
+int nmfmu_abi_version(void);
+int nmfmu_pad_rows(int rows);             /* rows rounded up to the 128-row workgroup tile                        */
+int nmfmu_pad_rank(int rank);             /* 32 / 64 / 128 / 256, or NMFMU_ERR_UNSUPPORTED                         */
+int nmfmu_beta_kind(float beta);          /* NMFMU_BETA_*                                                          */
+int nmfmu_supported(int r_pad, int precision);
+int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int num_cu);
+size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision);
+size_t nmfmu_image_bytes(int rows_pad, int r_pad);            /* one plane of p1 or of p2                          */
+size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit);
+size_t nmfmu_colsum_part_bytes(int rows_pad, int r_pad);
+
+/* ---- one-time packing ----------------------------------------------------------------------------------------
+ * nmfmu_pack_x: V (fp32, rows x cols, row stride ld elements) -> fragment-order X.
+ *   transpose = 0: owner axis = V rows  (X = V,   H half-step and the loss)
+ *   transpose = 1: owner axis = V cols  (X = V^T, W half-step)
+ * Also performs the target validation of nmf.py:329-336 in the same pass:
+ *   flags[0] |= 1 if any element fails (v >= 0)   (negative or NaN)
+ *   flags[1]  = min over elements of the fp32 bit pattern (caller presets 0x7f800000); == 0 iff V.min() == 0
+ */
+int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, void* xp,
+                 int owner_rows_pad, int panel_rows_pad, uint32_t* flags, void* stream);
+
+/* nmfmu_pack_factor: build the bf16 images and the column sums from the fp32 master (after the user or
+ * load_state_dict changed W/H; the apply step keeps them current afterwards). */
+int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream);
+
+/* ---- the MU half-step ----------------------------------------------------------------------------------------
+ * nmfmu_mu_partial: reconstruct + both backward passes of nmf.py:376-378 / 389-391, fused:
+ *   slab_num[s] = sum over the s-th contraction chunk of  Gn(X, owner panel^T) @ panel      (nmf.py:77)
+ *   slab_den[s] = likewise with Gp                                                    (nmf.py:82, beta != 1)
+ */
+int nmfmu_mu_partial(const nmfmu_step* st, void* stream);
+
+/* nmfmu_slab_reduce: num_out = sum_s slab_num[s] (and den_out likewise unless NULL).  Used by the column-sharded
+ * multi-GPU path so that one all-reduce carries [owner.rows_pad x r_pad] floats. */
+int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream);
+
+/* nmfmu_mu_apply: nmf.py:78-92.  neg = relu(sum of `nslab` numerator slabs) + eps;
+ *   beta == 1: pos = kl_den[r]  (closed form nmf.py:122-131, no relu/eps)   else pos = relu(sum den slabs) + eps;
+ *   pos += l1; pos += l2 * f;  f *= (neg / pos) ** gamma;
+ * then refreshes owner's bf16 images and column sums.  num/den = NULL means "use st->slab_* with st->nsplit slabs".
+ */
+int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                   void* stream);
+
+/* ---- loss -----------------------------------------------------------------------------------------------------
+ * nmfmu_loss: beta_div(owner panel^T, X) of metrics.py:60-96 without materialising the reconstruction
+ * (replaces nmf.py:360-361 and 400-401).  loss_part: nmfmu_loss_part_count() floats of scratch; *out (device
+ * double) receives the divergence (NOT yet sqrt(2 x)).  rows/cols are the logical sizes of X.
+ */
+int nmfmu_loss_part_count(int owner_rows_pad, int panel_rows_pad, int num_cu);
+int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream);
+
+/* nmfmu_beta_div: metrics.beta_div(x, y, beta) on two plain fp32 device arrays of n elements.
+ * part: 1024 doubles of scratch. */
+int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double* part, double* out, void* stream);
+
+/* nmfmu_reconstruct: out[m][k] = sum_r owner[m][r] panel[k][r]  (NMF.reconstruct, nmf.py:691-693) computed from the
+ * fp32 masters with fp32 MFMA; out is row-major [owner.rows][panel.rows], ld elements per row. */
+int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int rank, float* out, int64_t ld,
+                      void* stream);
+
+/* ---- instrumentation ------------------------------------------------------------------------------------------
+ * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */
+int nmfmu_timer_create(int n_events, void** timer);
+int nmfmu_timer_record(void* timer, int idx, void* stream);
+int nmfmu_timer_elapsed_ms(void* timer, int idx_from, int idx_to, float* ms); /* synchronises on idx_to */
+int nmfmu_timer_destroy(void* timer);
+
+/* ---- self-test probes (used by tests only; they validate the hardware assumptions the kernels rest on) ------ */
+int nmfmu_probe_mfma(const uint16_t* a /*32x16 bf16 row-major*/, const uint16_t* b /*16x32*/, float* d /*32x32*/,
+                     void* stream);
+int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords /* multiple of 1024 */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMFMU_H_ */

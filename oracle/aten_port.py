@@ -1,0 +1,60 @@
+"""CPU baseline "port": the reference's MU loop with the reference's own ATen op sequence.
+
+TEST / BENCH INFRASTRUCTURE ONLY (used by bench.py's ``cpu_baseline`` leg and by tests).
+
+oracle/mu_oracle.py states the MU step in closed form.  The reference instead builds the
+reconstruction with ``F.linear`` and calls ``WH.backward(grad_output)`` twice
+(torchnmf/nmf.py:52-92, 366-391).  For a *timing* baseline the op sequence matters (autograd's
+saved tensors, the extra elementwise temporaries), so this file re-states the loop with that
+sequence: linear -> add(eps) -> div -> backward -> relu_/add_ -> div_ -> mul_.  The test-suite
+checks it is numerically identical to mu_oracle.fit (and hence to the golden vectors).
+"""
+import torch
+import torch.nn.functional as F
+
+from .mu_oracle import EPS, gamma_of
+
+
+def _grad_outputs(V, WH, beta):
+    if beta == 2:
+        return V, WH
+    if beta == 1:
+        return V / WH.add(EPS), None
+    if beta == 0:
+        gp = WH.add(EPS).reciprocal_()
+        return gp.square().mul_(V), gp
+    we = WH.add(EPS)
+    return we.pow(beta - 2).mul_(V), we.pow_(beta - 1)
+
+
+def _update(V, WH, p, beta, gamma, l1, l2, pos):
+    p.grad = None
+    gneg, gpos = _grad_outputs(V, WH, beta)
+    WH.backward(gneg, retain_graph=pos is None)
+    neg = p.grad.relu_().add_(EPS)
+    if pos is None:
+        p.grad = None
+        WH.backward(gpos)
+        pos = p.grad.relu_().add_(EPS)
+    if l1 > 0:
+        pos.add_(l1)
+    if l2 > 0:
+        pos = pos.add(p.data, alpha=l2)
+    mult = neg.div_(pos)
+    if gamma != 1:
+        mult.pow_(gamma)
+    p.data.mul_(mult)
+
+
+def mu_iterations(V, W0, H0, beta=1, n_iter=1, alpha=0.0, l1_ratio=0.0):
+    """Run ``n_iter`` MU iterations (no loss evaluation) and return (W, H)."""
+    W = torch.nn.Parameter(W0.clone().float())
+    H = torch.nn.Parameter(H0.clone().float())
+    gamma = gamma_of(beta)
+    l1, l2 = alpha * l1_ratio, alpha * (1 - l1_ratio)
+    for _ in range(n_iter):
+        pos = H.detach().sum(0, keepdim=True) if beta == 1 else None
+        _update(V, F.linear(H.detach(), W), W, beta, gamma, l1, l2, pos)
+        pos = W.detach().sum(0) if beta == 1 else None
+        _update(V, F.linear(H, W.detach()), H, beta, gamma, l1, l2, pos)
+    return W.data, H.data

@@ -1,0 +1,35 @@
+// Launchers of the auxiliary (non-MFMA) kernels; see nmfmu_aux.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmfmu {
+
+struct ApplyArgs {
+  float* f;             // fp32 master [rows][rank]
+  const float* num;     // [nslab][rows_pad][R_PAD]
+  const float* den;     // same or nullptr
+  const float* kl_den;  // [R_PAD] or nullptr
+  int nslab;
+  void* p1_hi;
+  void* p1_lo;
+  void* p2_hi;
+  void* p2_lo;
+  float* colsum_part;   // [rows_pad/64][R_PAD]
+  float* colsum;        // [R_PAD]
+  int rows, rank, rows_pad;
+  float l1, l2, gamma;
+};
+
+int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
+                  int k_pad, uint32_t* flags, hipStream_t s);
+int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s);
+int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, hipStream_t s);
+int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s);
+int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int kind, double* part, double* out,
+                    hipStream_t s);
+int launch_reconstruct(const float* A, int M, const float* B, int K, int R, float* out, int64_t ld, hipStream_t s);
+int launch_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, hipStream_t s);
+int launch_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, hipStream_t s);
+
+}  // namespace nmfmu

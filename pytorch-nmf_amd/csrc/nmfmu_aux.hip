@@ -1,0 +1,386 @@
+// Memory-bound companions of the fused MU kernel: packing, the MU "apply" step, reductions, probes.
+// All of them are HBM/latency bound; they are written for coalesced 16-byte traffic and deterministic
+// (fixed-order) reductions, not for MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "nmfmu_aux.h"
+#include "nmfmu_fused.h"
+
+namespace nmfmu {
+
+// ------------------------------------------------------------------------------------------------------------
+// pack_x: V fp32 (row-major, ld) -> fragment-order X (bf16 or fp32), zero padded.  One thread = one 16-byte chunk.
+// Fused with the validation passes of nmf.py:329-336 (any(v < 0 or NaN), min(v)).
+// ------------------------------------------------------------------------------------------------------------
+template <bool FP32, bool TRANSPOSE>
+__global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
+                                                     void* __restrict__ xp, int ktiles, int64_t nchunks,
+                                                     uint32_t* flags) {
+  constexpr int NQ = FP32 ? 8 : 4;
+  constexpr int EPC = FP32 ? 4 : 8;
+  const int M = TRANSPOSE ? cols : rows;  // owner axis length
+  const int K = TRANSPOSE ? rows : cols;
+  uint32_t bad = 0, mn = 0x7f800000u;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(c & 63);
+    int64_t r = c >> 6;
+    const int q = (int)(r % NQ);
+    r /= NQ;
+    const int w = (int)(r & 3);
+    r >>= 2;
+    const int64_t kt = r % ktiles;
+    const int64_t mb = r / ktiles;
+    const int64_t m = mb * 128 + w * 32 + (lane & 31);
+    const int64_t k0 = kt * 64 + 32 * (lane >> 5) + (int64_t)q * EPC;
+    float e[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int64_t k = k0 + i;
+      float x = 0.f;
+      if (m < M && k < K) {
+        x = TRANSPOSE ? v[k * ld + m] : v[m * ld + k];
+        bad |= !(x >= 0.f) ? 1u : 0u;
+        mn = min(mn, __builtin_bit_cast(uint32_t, x) & 0x7fffffffu);
+      }
+      e[i] = x;
+    }
+    u32x4 o;
+    if constexpr (FP32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(uint32_t, e[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = pack_bf16(e[2 * i], e[2 * i + 1]);
+    }
+    reinterpret_cast<u32x4*>(xp)[c] = o;
+  }
+  if (flags) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      bad |= __shfl_xor(bad, o, 64);
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (bad) atomicOr(&flags[0], 1u);
+      atomicMin(&flags[1], mn);
+    }
+  }
+}
+
+int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
+                  int k_pad, uint32_t* flags, hipStream_t s) {
+  const int ktiles = k_pad / kBK;
+  const int64_t nchunks = (int64_t)m_pad * k_pad * (fp32 ? 4 : 2) / 16;
+  const int grid = (int)std::min<int64_t>((nchunks + 255) / 256, 256 * 32);
+#define L(F, T) hipLaunchKernelGGL((pack_x_kernel<F, T>), dim3(grid), dim3(256), 0, s, v, ld, rows, cols, xp, ktiles, nchunks, flags)
+  if (fp32 && transpose) L(true, true);
+  else if (fp32) L(true, false);
+  else if (transpose) L(false, true);
+  else L(false, false);
+#undef L
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// apply: nmf.py:78-92 on a 64-row stripe of the owner factor, then re-emit that stripe's bf16 images (P1 rows,
+// one whole P2 tile) and its partial column sums.  PACK_ONLY skips the update (initial packing of W0 / H0).
+// ------------------------------------------------------------------------------------------------------------
+template <int R_PAD, bool X3, bool PACK_ONLY>
+__global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
+  constexpr int LDT = R_PAD + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [64][R_PAD + 1]
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * 64;
+  const size_t plane = (size_t)a.rows_pad * R_PAD;
+
+  for (int idx = tid; idx < 64 * R_PAD; idx += 256) {
+    const int rl = idx / R_PAD, r = idx - rl * R_PAD;
+    const int row = row0 + rl;
+    float f = 0.f;
+    if (row < a.rows && r < a.rank) {
+      f = a.f[(size_t)row * a.rank + r];
+      if constexpr (!PACK_ONLY) {
+        const size_t e = (size_t)row * R_PAD + r;
+        float neg = 0.f;
+        for (int s = 0; s < a.nslab; ++s) neg += a.num[s * plane + e];
+        neg = fmaxf(neg, 0.f) + kEps;  // nmf.py:78
+        float pos;
+        if (a.kl_den) {
+          pos = a.kl_den[r];  // closed form, no relu / eps (nmf.py:80 branch skipped)
+        } else {
+          pos = 0.f;
+          for (int s = 0; s < a.nslab; ++s) pos += a.den[s * plane + e];
+          pos = fmaxf(pos, 0.f) + kEps;  // nmf.py:83
+        }
+        if (a.l1 > 0.f) pos += a.l1;       // nmf.py:85-86
+        if (a.l2 > 0.f) pos += a.l2 * f;   // nmf.py:87-88
+        float mult = neg / pos;
+        if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+        f *= mult;
+        a.f[(size_t)row * a.rank + r] = f;
+      }
+    }
+    tile[rl * LDT + r] = f;
+  }
+  __syncthreads();
+
+  // P1: 64 rows x (R_PAD/8) sixteen-byte slots, swizzled inside each row
+  constexpr int SP = R_PAD / 8;
+  for (int idx = tid; idx < 64 * SP; idx += 256) {
+    const int rl = idx / SP, slot = idx - rl * SP;
+    const float* src = tile + rl * LDT + slot * 8;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = src[2 * i], x1 = src[2 * i + 1];
+      hi[i] = pack_bf16(x0, x1);
+      lo[i] = pack_bf16(x0 - bf16_lo(hi[i]), x1 - bf16_hi(hi[i]));
+    }
+    const int64_t off = p1_offset(row0 + rl, slot * 8, R_PAD);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_hi) + off) = hi;
+    if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_lo) + off) = lo;
+  }
+  // P2: tile blockIdx.x = [R_PAD][64]; slot = 8 consecutive factor rows of one rank column
+  for (int idx = tid; idx < R_PAD * 8; idx += 256) {
+    const int r = idx >> 3, slot = idx & 7;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = tile[(slot * 8 + 2 * i) * LDT + r], x1 = tile[(slot * 8 + 2 * i + 1) * LDT + r];
+      hi[i] = pack_bf16(x0, x1);
+      lo[i] = pack_bf16(x0 - bf16_lo(hi[i]), x1 - bf16_hi(hi[i]));
+    }
+    const int64_t off = p2_offset(row0 + slot * 8, r, R_PAD);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p2_hi) + off) = hi;
+    if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p2_lo) + off) = lo;
+  }
+  // partial column sums of this stripe (fixed order -> deterministic)
+  for (int r = tid; r < R_PAD; r += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int rl = 0; rl < 64; ++rl) s += tile[rl * LDT + r];
+    a.colsum_part[(size_t)blockIdx.x * R_PAD + r] = s;
+  }
+}
+
+// colsum[r] = sum_b part[b][r]; one block per 32 columns, 8 row groups, fixed combination order.
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int r_pad,
+                                                              float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  float s = 0.f;
+  for (int b = g; b < nblk; b += 8) s += part[(size_t)b * r_pad + col];
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    out[col] = t;
+  }
+}
+
+template <int R_PAD>
+int launch_apply_r(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
+  const int grid = a.rows_pad / 64;
+  const size_t lds = (size_t)64 * (R_PAD + 1) * sizeof(float);
+#define L(X, P)                                                                                                      \
+  {                                                                                                                  \
+    auto k = apply_kernel<R_PAD, X, P>;                                                                              \
+    if (lds > 64 * 1024) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                                  \
+      if (e != hipSuccess) return (int)e;                                                                            \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);                                                         \
+  }
+  if (x3 && pack_only) L(true, true)
+  else if (x3) L(true, false)
+  else if (pack_only) L(false, true)
+  else L(false, false)
+#undef L
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(R_PAD / 32), dim3(256), 0, s, a.colsum_part, grid, R_PAD, a.colsum);
+  return (int)hipGetLastError();
+}
+
+int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
+  switch (r_pad) {
+    case 32: return launch_apply_r<32>(a, x3, pack_only, s);
+    case 64: return launch_apply_r<64>(a, x3, pack_only, s);
+    case 128: return launch_apply_r<128>(a, x3, pack_only, s);
+    case 256: return launch_apply_r<256>(a, x3, pack_only, s);
+  }
+  return -2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// slab_reduce: out = sum_s slab[s]   (float4 streams)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float4* __restrict__ slab, int nslab, int64_t plane4,
+                                                          float4* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = slab[i];
+    for (int s = 1; s < nslab; ++s) {
+      const float4 v = slab[s * plane4 + i];
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    out[i] = acc;
+  }
+}
+
+int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, hipStream_t s) {
+  const int64_t plane4 = plane / 4;
+  const int grid = (int)std::min<int64_t>((plane4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(slab), nslab, plane4,
+                     reinterpret_cast<float4*>(out));
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// loss finalize: double-precision, fixed-order sum of the per-workgroup partials
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) sum_finalize_kernel(const T* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_finalize_kernel<float>, dim3(1), dim3(256), 0, s, part, n, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// metrics.beta_div(x, y, beta) on plain arrays (metrics.py:60-96): the public metric, not the fit hot loop.
+// ------------------------------------------------------------------------------------------------------------
+template <int BETA>
+__global__ void __launch_bounds__(256) beta_div_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       int64_t n, float beta, double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = (BETA == kEuc) ? x[i] : x[i] + kEps;
+    acc += (double)loss_elem<BETA>(s, y[i], beta);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int kind, double* part, double* out,
+                    hipStream_t s) {
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  switch (kind) {
+    case kKL: hipLaunchKernelGGL(beta_div_kernel<kKL>, dim3(grid), dim3(256), 0, s, x, y, n, beta, part); break;
+    case kEuc: hipLaunchKernelGGL(beta_div_kernel<kEuc>, dim3(grid), dim3(256), 0, s, x, y, n, beta, part); break;
+    case kIS: hipLaunchKernelGGL(beta_div_kernel<kIS>, dim3(grid), dim3(256), 0, s, x, y, n, beta, part); break;
+    default: hipLaunchKernelGGL(beta_div_kernel<kGen>, dim3(grid), dim3(256), 0, s, x, y, n, beta, part); break;
+  }
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(1), dim3(256), 0, s, part, grid, out);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// reconstruct: out[m][k] = sum_r A[m][r] B[k][r], fp32 in / fp32 out (NMF.reconstruct, nmf.py:691-693).
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one wave per 32x32 output tile, operands straight from global
+// (rank <= 256, both operand rows are contiguous in r).  Not on the fit hot loop.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) reconstruct_kernel(const float* __restrict__ A, int M, const float* __restrict__ B,
+                                                         int K, int R, float* __restrict__ out, int64_t ld) {
+  const int lane = threadIdx.x, j = lane & 31, hl = lane >> 5;
+  const int m = blockIdx.y * 32 + j;  // A-operand row (MFMA row i)
+  const int k = blockIdx.x * 32 + j;  // B-operand column (MFMA col j)
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* ap = A + (size_t)min(m, M - 1) * R;
+  const float* bp = B + (size_t)min(k, K - 1) * R;
+  for (int r0 = 0; r0 < R; r0 += 2) {  // wave-uniform trip count; the odd tail feeds zeros
+    const int r = r0 + hl;
+    const float av = r < R ? ap[r] : 0.f;
+    const float bv = r < R ? bp[r] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+  if (k < K) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = blockIdx.y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+      if (row < M) out[(size_t)row * ld + k] = acc[e];
+    }
+  }
+}
+
+int launch_reconstruct(const float* A, int M, const float* B, int K, int R, float* out, int64_t ld, hipStream_t s) {
+  dim3 grid((K + 31) / 32, (M + 31) / 32);
+  hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(64), 0, s, A, M, B, K, R, out, ld);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// probes: validate the two hardware assumptions everything rests on.
+// ------------------------------------------------------------------------------------------------------------
+// (1) v_mfma_f32_32x32x16_bf16 operand / result lane maps, exactly as the fused kernel uses them.
+__global__ void __launch_bounds__(64) probe_mfma_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                        float* __restrict__ d) {
+  const int lane = threadIdx.x, j = lane & 31, hl = lane >> 5;
+  u32x4 av, bv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // A[i = j][k = 8*hl + e], row-major 32x16 ; B[k][j], row-major 16x32
+    av[i] = (uint32_t)a[j * 16 + 8 * hl + 2 * i] | ((uint32_t)a[j * 16 + 8 * hl + 2 * i + 1] << 16);
+    bv[i] = (uint32_t)b[(8 * hl + 2 * i) * 32 + j] | ((uint32_t)b[(8 * hl + 2 * i + 1) * 32 + j] << 16);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  acc = mfma_bf16(av, bv, acc);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) d[((e & 3) + 8 * (e >> 2) + 4 * hl) * 32 + j] = acc[e];
+}
+
+int launch_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, hipStream_t s) {
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, s, a, b, d);
+  return (int)hipGetLastError();
+}
+
+// (2) global_load_lds: LDS destination = wave-uniform base + lane * 16, source per lane.
+__global__ void __launch_bounds__(256) probe_lds_dma_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                            int n_dwords) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int passes = n_dwords / 1024;  // 4 KiB per pass
+  for (int p = 0; p < passes; ++p) {
+    const char* g = reinterpret_cast<const char*>(src) + (size_t)p * 4096 + tid * 16;
+    char* l = smem + p * 4096 + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+  __syncthreads();
+  for (int i = tid; i < n_dwords; i += 256) dst[i] = reinterpret_cast<const uint32_t*>(smem)[i];
+}
+
+int launch_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, hipStream_t s) {
+  hipLaunchKernelGGL(probe_lds_dma_kernel, dim3(1), dim3(256), (size_t)n_dwords * 4, s, src, dst, n_dwords);
+  return (int)hipGetLastError();
+}
+
+}  // namespace nmfmu

@@ -1,0 +1,235 @@
+// C ABI (include/nmfmu.h) over the HIP kernels.  Thin: argument checks, grid sizing, dispatch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/nmfmu.h"
+#include "nmfmu_aux.h"
+#include "nmfmu_fused.h"
+
+using namespace nmfmu;
+
+namespace {
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s) {
+  if (!st || !st->xp || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
+  if (st->owner.rows_pad % kBM || st->panel.rows_pad % kBM) return NMFMU_ERR_ARG;
+  if (st->r_pad != pad_rank(st->rank) || st->nsplit < 1) return NMFMU_ERR_ARG;
+  const int x3 = st->precision == NMFMU_PREC_BF16X3 ? 1 : 0;
+  if (x3 && (!st->owner.p1_lo || !st->panel.p1_lo)) return NMFMU_ERR_ARG;
+  const int kind = nmfmu_beta_kind(st->beta);
+  FusedArgs a;
+  a.xp = st->xp;
+  a.p1_hi = static_cast<const uint16_t*>(st->panel.p1_hi);
+  a.p1_lo = static_cast<const uint16_t*>(st->panel.p1_lo);
+  a.p2_hi = static_cast<const uint16_t*>(st->panel.p2_hi);
+  a.p2_lo = static_cast<const uint16_t*>(st->panel.p2_lo);
+  a.a1_hi = static_cast<const uint16_t*>(st->owner.p1_hi);
+  a.a1_lo = static_cast<const uint16_t*>(st->owner.p1_lo);
+  a.slab_num = st->slab_num;
+  a.slab_den = st->slab_den;
+  a.loss_part = loss_part;
+  a.M = M;
+  a.K = K;
+  a.M_pad = st->owner.rows_pad;
+  a.ktiles = st->panel.rows_pad / kBK;
+  a.nsplit = st->nsplit;
+  a.tiles_per_split = (a.ktiles + st->nsplit - 1) / st->nsplit;
+  a.beta = st->beta;
+  if (mode == kModeMU) {
+    if (!a.slab_num || !a.p2_hi || (x3 && !a.p2_lo)) return NMFMU_ERR_ARG;
+    if (kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
+  } else if (!loss_part) {
+    return NMFMU_ERR_ARG;
+  }
+  const int grid = (st->owner.rows_pad / kBM) * st->nsplit;
+  const int stage = st->stage == NMFMU_STAGE_REG ? 0 : 1;
+  switch (st->r_pad) {
+    case 32: return launch_fused_r32(kind, x3, mode, stage, a, grid, s);
+    case 64: return launch_fused_r64(kind, x3, mode, stage, a, grid, s);
+    case 128: return launch_fused_r128(kind, x3, mode, stage, a, grid, s);
+    case 256: return launch_fused_r256(kind, x3, mode, stage, a, grid, s);
+  }
+  return NMFMU_ERR_UNSUPPORTED;
+}
+
+struct Timer {
+  std::vector<hipEvent_t> ev;
+};
+
+}  // namespace
+
+extern "C" {
+
+int nmfmu_abi_version(void) { return NMFMU_ABI_VERSION; }
+int nmfmu_pad_rows(int rows) { return rows <= 0 ? NMFMU_ERR_ARG : pad_rows(rows); }
+int nmfmu_pad_rank(int rank) {
+  const int r = pad_rank(rank);
+  return r < 0 ? NMFMU_ERR_UNSUPPORTED : r;
+}
+int nmfmu_beta_kind(float beta) {
+  if (beta == 1.f) return NMFMU_BETA_KL;
+  if (beta == 2.f) return NMFMU_BETA_EUC;
+  if (beta == 0.f) return NMFMU_BETA_IS;
+  return NMFMU_BETA_GEN;
+}
+int nmfmu_supported(int r_pad, int precision) {
+  if (r_pad != 32 && r_pad != 64 && r_pad != 128 && r_pad != 256) return 0;
+  if (precision == NMFMU_PREC_BF16) return 1;
+  if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
+  return 0;
+}
+
+int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int num_cu) {
+  if (owner_rows_pad <= 0 || panel_rows_pad <= 0) return NMFMU_ERR_ARG;
+  const int mblocks = owner_rows_pad / kBM;
+  const int ktiles = panel_rows_pad / kBK;
+  const int target = 2 * std::max(num_cu, 1);  // two workgroups per CU keep both wave slots of every SIMD busy
+  int ns = (target + mblocks - 1) / mblocks;
+  if (ns > 8) ns = (ns + 7) / 8 * 8;           // same-chunk workgroups then share an XCD (block b runs on XCD b % 8)
+  ns = std::min(ns, std::max(1, ktiles / 4));  // at least 4 tiles per workgroup to amortise prologue/epilogue
+  return std::max(ns, 1);
+}
+
+size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision) {
+  return (size_t)owner_rows_pad * (size_t)panel_rows_pad * (precision == NMFMU_PREC_BF16X3 ? 4 : 2);
+}
+size_t nmfmu_image_bytes(int rows_pad, int r_pad) { return (size_t)rows_pad * (size_t)r_pad * 2; }
+size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit) {
+  return (size_t)nsplit * (size_t)owner_rows_pad * (size_t)r_pad * 4;
+}
+size_t nmfmu_colsum_part_bytes(int rows_pad, int r_pad) { return (size_t)(rows_pad / 64) * (size_t)r_pad * 4; }
+
+int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, void* xp,
+                 int owner_rows_pad, int panel_rows_pad, uint32_t* flags, void* stream) {
+  if (!v || !xp || rows <= 0 || cols <= 0) return NMFMU_ERR_ARG;
+  const int m = transpose ? cols : rows, k = transpose ? rows : cols;
+  if (owner_rows_pad != pad_rows(m) || panel_rows_pad != pad_rows(k)) return NMFMU_ERR_ARG;
+  return launch_pack_x(v, ld, rows, cols, transpose != 0, precision == NMFMU_PREC_BF16X3, xp, owner_rows_pad,
+                       panel_rows_pad, flags, S(stream));
+}
+
+int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream) {
+  if (!fac || !fac->f || !fac->p1_hi || !fac->p2_hi || !fac->colsum || !fac->colsum_part) return NMFMU_ERR_ARG;
+  if (r_pad != pad_rank(rank) || fac->rows_pad != pad_rows(fac->rows)) return NMFMU_ERR_ARG;
+  const bool x3 = precision == NMFMU_PREC_BF16X3;
+  if (x3 && (!fac->p1_lo || !fac->p2_lo)) return NMFMU_ERR_ARG;
+  ApplyArgs a{};
+  a.f = fac->f;
+  a.p1_hi = fac->p1_hi, a.p1_lo = fac->p1_lo, a.p2_hi = fac->p2_hi, a.p2_lo = fac->p2_lo;
+  a.colsum_part = fac->colsum_part, a.colsum = fac->colsum;
+  a.rows = fac->rows, a.rank = rank, a.rows_pad = fac->rows_pad;
+  a.gamma = 1.f;
+  return launch_apply(r_pad, a, x3, /*pack_only=*/true, S(stream));
+}
+
+int nmfmu_mu_partial(const nmfmu_step* st, void* stream) {
+  if (!st) return NMFMU_ERR_ARG;
+  if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  return fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream));
+}
+
+int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream) {
+  if (!st || !num_out || !st->slab_num) return NMFMU_ERR_ARG;
+  const int64_t plane = (int64_t)st->owner.rows_pad * st->r_pad;
+  int e = launch_slab_reduce(st->slab_num, st->nsplit, plane, num_out, S(stream));
+  if (e) return e;
+  if (den_out) {
+    if (!st->slab_den) return NMFMU_ERR_ARG;
+    e = launch_slab_reduce(st->slab_den, st->nsplit, plane, den_out, S(stream));
+  }
+  return e;
+}
+
+int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                   void* stream) {
+  if (!st || !st->owner.f) return NMFMU_ERR_ARG;
+  const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
+  ApplyArgs a{};
+  a.f = st->owner.f;
+  a.num = num ? num : st->slab_num;
+  a.den = num ? den : st->slab_den;
+  a.nslab = num ? nslab : st->nsplit;
+  a.kl_den = kl ? kl_den : nullptr;
+  if (!a.num || a.nslab < 1) return NMFMU_ERR_ARG;
+  if (kl ? !a.kl_den : !a.den) return NMFMU_ERR_ARG;
+  a.p1_hi = st->owner.p1_hi, a.p1_lo = st->owner.p1_lo, a.p2_hi = st->owner.p2_hi, a.p2_lo = st->owner.p2_lo;
+  a.colsum_part = st->owner.colsum_part, a.colsum = st->owner.colsum;
+  a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
+  a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
+  if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
+  return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
+}
+
+int nmfmu_loss_part_count(int owner_rows_pad, int panel_rows_pad, int num_cu) {
+  const int ns = nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, num_cu);
+  return ns < 0 ? ns : (owner_rows_pad / kBM) * ns;
+}
+
+int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream) {
+  if (!st || !out) return NMFMU_ERR_ARG;
+  if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  int e = fused_dispatch(st, kModeLoss, loss_part, st->owner.rows, st->panel.rows, S(stream));
+  if (e) return e;
+  return launch_sum_finalize_f32(loss_part, (st->owner.rows_pad / kBM) * st->nsplit, out, S(stream));
+}
+
+int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double* part, double* out, void* stream) {
+  if (!x || !y || !part || !out || n < 0) return NMFMU_ERR_ARG;
+  return launch_beta_div(x, y, n, beta, nmfmu_beta_kind(beta), part, out, S(stream));
+}
+
+int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int rank, float* out, int64_t ld,
+                      void* stream) {
+  if (!owner || !panel || !out || m <= 0 || k <= 0 || rank <= 0 || ld < k) return NMFMU_ERR_ARG;
+  return launch_reconstruct(owner, m, panel, k, rank, out, ld, S(stream));
+}
+
+int nmfmu_timer_create(int n_events, void** timer) {
+  if (n_events <= 0 || !timer) return NMFMU_ERR_ARG;
+  Timer* t = new (std::nothrow) Timer;
+  if (!t) return NMFMU_ERR_ARG;
+  t->ev.resize(n_events);
+  for (auto& e : t->ev) {
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return (int)r;
+  }
+  *timer = t;
+  return NMFMU_OK;
+}
+int nmfmu_timer_record(void* timer, int idx, void* stream) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t || idx < 0 || idx >= (int)t->ev.size()) return NMFMU_ERR_ARG;
+  return (int)hipEventRecord(t->ev[idx], S(stream));
+}
+int nmfmu_timer_elapsed_ms(void* timer, int idx_from, int idx_to, float* ms) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t || !ms || idx_from < 0 || idx_to < 0 || idx_from >= (int)t->ev.size() || idx_to >= (int)t->ev.size())
+    return NMFMU_ERR_ARG;
+  hipError_t r = hipEventSynchronize(t->ev[idx_to]);
+  if (r != hipSuccess) return (int)r;
+  return (int)hipEventElapsedTime(ms, t->ev[idx_from], t->ev[idx_to]);
+}
+int nmfmu_timer_destroy(void* timer) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t) return NMFMU_ERR_ARG;
+  for (auto& e : t->ev) hipEventDestroy(e);
+  delete t;
+  return NMFMU_OK;
+}
+
+int nmfmu_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, void* stream) {
+  if (!a || !b || !d) return NMFMU_ERR_ARG;
+  return launch_probe_mfma(a, b, d, S(stream));
+}
+int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, void* stream) {
+  if (!src || !dst || n_dwords <= 0 || n_dwords % 1024 || n_dwords > 16384) return NMFMU_ERR_ARG;
+  return launch_probe_lds_dma(src, dst, n_dwords, S(stream));
+}
+
+}  // extern "C"

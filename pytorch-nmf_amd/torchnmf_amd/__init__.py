@@ -1,0 +1,12 @@
+"""torchnmf_amd -- MI355X-native multiplicative-update engine behind torchnmf's ``NMF`` / ``NMFD`` surface.
+
+    from torchnmf_amd.nmf import NMF
+    m = NMF(V.shape, rank=128).cuda()
+    n_iter = m.fit(V.cuda(), beta=1)
+
+Only the dense beta-divergence MU hot path of yoyololicon/pytorch-NMF is implemented.
+"""
+name = 'torchnmf_amd'
+__version__ = '0.1.0'
+
+from . import constants, metrics, nmf  # noqa: E402,F401

@@ -1,0 +1,104 @@
+"""ctypes binding of libnmfmu.so (the C ABI declared in include/nmfmu.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C
+pytorch-nmf_amd/csrc`` and sits next to this file.  There is NO fallback: if
+the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+LIB_NAME = 'libnmfmu.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+OK = 0
+ERR_UNSUPPORTED = -2
+ERR_ARG = -3
+PREC_BF16, PREC_BF16X3 = 0, 1
+STAGE_REG, STAGE_DMA = 0, 1
+BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
+
+PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
+
+
+class NmfmuError(RuntimeError):
+    pass
+
+
+class Factor(C.Structure):
+    """struct nmfmu_factor"""
+    _fields_ = [('f', C.c_void_p), ('p1_hi', C.c_void_p), ('p1_lo', C.c_void_p), ('p2_hi', C.c_void_p),
+                ('p2_lo', C.c_void_p), ('colsum', C.c_void_p), ('colsum_part', C.c_void_p), ('rows', C.c_int32),
+                ('rows_pad', C.c_int32)]
+
+
+class Step(C.Structure):
+    """struct nmfmu_step"""
+    _fields_ = [('xp', C.c_void_p), ('owner', Factor), ('panel', Factor), ('slab_num', C.c_void_p),
+                ('slab_den', C.c_void_p), ('rank', C.c_int32), ('r_pad', C.c_int32), ('nsplit', C.c_int32),
+                ('precision', C.c_int32), ('stage', C.c_int32), ('beta', C.c_float), ('gamma', C.c_float),
+                ('l1', C.c_float), ('l2', C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/nmfmu.h declares
+SIGNATURES = {
+    'nmfmu_abi_version': (C.c_int, []),
+    'nmfmu_pad_rows': (C.c_int, [C.c_int]),
+    'nmfmu_pad_rank': (C.c_int, [C.c_int]),
+    'nmfmu_beta_kind': (C.c_int, [C.c_float]),
+    'nmfmu_supported': (C.c_int, [C.c_int, C.c_int]),
+    'nmfmu_choose_nsplit': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_xp_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_image_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'nmfmu_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_colsum_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'nmfmu_pack_x': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                               C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_pack_factor': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
+    'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_mu_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_loss_part_count': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_loss': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_beta_div': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_reconstruct': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
+    'nmfmu_timer_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'nmfmu_timer_record': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_timer_elapsed_ms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    'nmfmu_timer_destroy': (C.c_int, [C.c_void_p]),
+    'nmfmu_probe_mfma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_probe_lds_dma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libnmfmu.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NmfmuError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
+                             f'g.build()"` or `make -C pytorch-nmf_amd/csrc`. torchnmf_amd has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+            fn.restype = res
+            fn.argtypes = args
+        if lib.nmfmu_abi_version() != 1:
+            raise NmfmuError('libnmfmu.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code == OK:
+        return
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(f'{what}: combination not supported by libnmfmu (rank > 256, or bf16x3 with rank > 128)')
+    if code == ERR_ARG:
+        raise ValueError(f'{what}: libnmfmu rejected the arguments')
+    raise NmfmuError(f'{what}: HIP error {code}')

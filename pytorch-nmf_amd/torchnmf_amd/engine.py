@@ -1,0 +1,285 @@
+"""Host-side orchestration of the dense MU iteration on one MI355X (optionally one shard of many).
+
+This is the part of ``torchnmf.nmf.BaseComponent.fit`` (nmf.py:297-409 of the
+reference) below the Python loop: buffers, packing, and the two half-steps,
+expressed as calls into the C ABI (include/nmfmu.h).  PyTorch is used for
+device memory, the current stream and ``torch.distributed`` only.
+
+Column sharding: every rank holds ``V[:, Cg]`` and
+``W[Cg]``; ``H`` is replicated.  The W half-step is local; the H half-step
+all-reduces one packed fp32 buffer ``[numerator | denominator]`` per iteration.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _capi
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    """The real backend: libnmfmu.so on the current ROCm device.  (Tests may substitute an object with
+    the same methods to exercise the host logic without a GPU; the product never does.)"""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); none is visible and there is no '
+                                   'CPU fallback')
+
+    # -- static queries
+    def pad_rows(self, rows: int) -> int:
+        return self.lib.nmfmu_pad_rows(rows)
+
+    def pad_rank(self, rank: int) -> int:
+        r = self.lib.nmfmu_pad_rank(rank)
+        _capi.check(r if r < 0 else 0, f'rank {rank}')
+        return r
+
+    def supported(self, r_pad: int, precision: int) -> bool:
+        return bool(self.lib.nmfmu_supported(r_pad, precision))
+
+    def choose_nsplit(self, m_pad: int, k_pad: int, device) -> int:
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        return self.lib.nmfmu_choose_nsplit(m_pad, k_pad, ncu)
+
+    @staticmethod
+    def stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def alloc(self, nbytes: int, device) -> torch.Tensor:
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+    # -- device work
+    def pack_x(self, V, transpose, precision, m_pad, k_pad, flags):
+        xp = self.alloc(self.lib.nmfmu_xp_bytes(m_pad, k_pad, precision), V.device)
+        _capi.check(self.lib.nmfmu_pack_x(V.data_ptr(), V.stride(0), V.shape[0], V.shape[1], int(transpose), precision,
+                                          xp.data_ptr(), m_pad, k_pad, _ptr(flags), self.stream()), 'nmfmu_pack_x')
+        return xp
+
+    def pack_factor(self, fac: 'FactorBuf', rank, r_pad, precision):
+        _capi.check(self.lib.nmfmu_pack_factor(C.byref(fac.struct), rank, r_pad, precision, self.stream()),
+                    'nmfmu_pack_factor')
+
+    def mu_partial(self, st: 'StepBuf'):
+        _capi.check(self.lib.nmfmu_mu_partial(C.byref(st.struct), self.stream()), 'nmfmu_mu_partial')
+
+    def slab_reduce(self, st, num_out, den_out):
+        _capi.check(self.lib.nmfmu_slab_reduce(C.byref(st.struct), _ptr(num_out), _ptr(den_out), self.stream()),
+                    'nmfmu_slab_reduce')
+
+    def mu_apply(self, st, num, den, nslab, kl_den):
+        _capi.check(self.lib.nmfmu_mu_apply(C.byref(st.struct), _ptr(num), _ptr(den), nslab, _ptr(kl_den),
+                                            self.stream()), 'nmfmu_mu_apply')
+
+    def loss(self, st, loss_part, out):
+        _capi.check(self.lib.nmfmu_loss(C.byref(st.struct), _ptr(loss_part), _ptr(out), self.stream()), 'nmfmu_loss')
+
+
+class KernelTimer:
+    """hipEvent pairs around chosen launches, recorded on the launching stream (nmfmu_timer_* of the C ABI)."""
+
+    def __init__(self, n_events: int):
+        self.lib = _capi.load()
+        self.h = C.c_void_p()
+        _capi.check(self.lib.nmfmu_timer_create(n_events, C.byref(self.h)), 'nmfmu_timer_create')
+        self.n = n_events
+        self.next = 0
+        self.tags = []
+
+    def mark(self, tag: str):
+        if self.next >= self.n:
+            return
+        _capi.check(self.lib.nmfmu_timer_record(self.h, self.next, torch.cuda.current_stream().cuda_stream),
+                    'nmfmu_timer_record')
+        self.tags.append(tag)
+        self.next += 1
+
+    def spans(self):
+        """{tag: [ms, ...]} for consecutive (tag+'<', tag+'>') marks."""
+        out = {}
+        ms = C.c_float()
+        for i in range(self.next - 1):
+            a, b = self.tags[i], self.tags[i + 1]
+            if a.endswith('<') and b == a[:-1] + '>':
+                _capi.check(self.lib.nmfmu_timer_elapsed_ms(self.h, i, i + 1, C.byref(ms)), 'nmfmu_timer_elapsed_ms')
+                out.setdefault(a[:-1], []).append(ms.value)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.nmfmu_timer_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class FactorBuf:
+    """Device state of one factor: the fp32 master (the nn.Parameter's storage) plus its bf16 images."""
+
+    def __init__(self, data: torch.Tensor, r_pad: int, precision: int, backend):
+        assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
+        self.f = data
+        self.rows, self.rank = data.shape
+        self.rows_pad = backend.pad_rows(self.rows)
+        dev = data.device
+        nimg = self.rows_pad * r_pad * 2
+        x3 = precision == _capi.PREC_BF16X3
+        self.p1_hi = backend.alloc(nimg, dev)
+        self.p2_hi = backend.alloc(nimg, dev)
+        self.p1_lo = backend.alloc(nimg, dev) if x3 else None
+        self.p2_lo = backend.alloc(nimg, dev) if x3 else None
+        self.colsum = torch.zeros(r_pad, dtype=torch.float32, device=dev)
+        self.colsum_part = torch.zeros((self.rows_pad // 64) * r_pad, dtype=torch.float32, device=dev)
+        self.struct = _capi.Factor(_ptr(self.f), _ptr(self.p1_hi), _ptr(self.p1_lo), _ptr(self.p2_hi),
+                                   _ptr(self.p2_lo), _ptr(self.colsum), _ptr(self.colsum_part), self.rows,
+                                   self.rows_pad)
+
+
+class StepBuf:
+    """One half-step: X in fragment order, owner/panel factors, partial-sum slabs."""
+
+    def __init__(self, xp, owner: FactorBuf, panel: FactorBuf, rank, r_pad, nsplit, precision, stage, beta, gamma, l1,
+                 l2, need_den: bool):
+        self.xp, self.owner, self.panel = xp, owner, panel
+        self.nsplit, self.r_pad = nsplit, r_pad
+        dev = owner.f.device
+        self.plane = owner.rows_pad * r_pad
+        self.slab_num = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev)
+        self.slab_den = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev) if need_den else None
+        self.struct = _capi.Step(_ptr(xp), owner.struct, panel.struct, _ptr(self.slab_num), _ptr(self.slab_den), rank,
+                                 r_pad, nsplit, precision, stage, beta, gamma, l1, l2)
+
+
+def mu_gamma(beta: float) -> float:
+    """MU exponent of nmf.py:341-346."""
+    if beta < 1:
+        return 1.0 / (2.0 - beta)
+    if beta > 2:
+        return 1.0 / (beta - 1.0)
+    return 1.0
+
+
+class DenseMU:
+    """Engine for ``NMF.fit``: V (N, C) ~ H (N, R) @ W (C, R)^T on the current device.
+
+    ``W`` / ``H`` are the parameters' ``.data`` tensors and are updated in place
+    (nmf.py:92).  With ``group`` set, ``V`` / ``W`` are this rank's column shard.
+    """
+
+    def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
+                 update_W=True, update_H=True):
+        self.be = backend if backend is not None else HipBackend()
+        self.group = group
+        self.beta = float(beta)
+        self.kl = self.beta == 1.0
+        N, Cc = V.shape
+        R = W.shape[1]
+        assert W.shape == (Cc, R) and H.shape == (N, R)
+        self.rank = R
+        self.r_pad = self.be.pad_rank(R)
+        if precision in (None, 'auto'):
+            precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
+        if precision not in _capi.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
+        self.precision_name = precision
+        self.precision = _capi.PRECISIONS[precision]
+        if not self.be.supported(self.r_pad, self.precision):
+            raise NotImplementedError(f'precision {precision!r} is not available for rank {R} (padded {self.r_pad})')
+        if stage is None:
+            stage = _capi.STAGE_DMA
+        gamma = mu_gamma(self.beta)
+        dev = V.device
+
+        self.fW = FactorBuf(W, self.r_pad, self.precision, self.be)
+        self.fH = FactorBuf(H, self.r_pad, self.precision, self.be)
+        # validation flags of nmf.py:329-336: [any(!(v >= 0)), min bit pattern]
+        self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
+        n_pad, c_pad = self.fH.rows_pad, self.fW.rows_pad
+        # H half-step and loss: owner axis N, contraction over C
+        xp_h = self.be.pack_x(V, False, self.precision, n_pad, c_pad, self.flags)
+        ns_h = self.be.choose_nsplit(n_pad, c_pad, dev)
+        self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, self.beta, gamma, l1,
+                              l2, need_den=not self.kl)
+        self.step_w = None
+        if update_W:
+            xp_w = self.be.pack_x(V, True, self.precision, c_pad, n_pad, None)
+            ns_w = self.be.choose_nsplit(c_pad, n_pad, dev)
+            self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, self.beta, gamma,
+                                  l1, l2, need_den=not self.kl)
+        self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
+        self.refresh_images()
+        self.loss_part = torch.empty(max((n_pad // 128) * ns_h, 1), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        if group is not None:
+            # [numerator | denominator (N x R for beta != 1, else R column sums)] -> ONE all-reduce per iteration
+            tail = self.r_pad if self.kl else self.step_h.plane
+            self.xbuf = torch.empty(self.step_h.plane + tail, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------
+    def refresh_images(self):
+        """Re-derive bf16 images / column sums from the fp32 masters (after external edits of W / H)."""
+        self.be.pack_factor(self.fW, self.rank, self.r_pad, self.precision)
+        self.be.pack_factor(self.fH, self.rank, self.r_pad, self.precision)
+
+    def target_flags(self):
+        """(has_negative_or_nan, has_zero) over the whole (possibly sharded) target.  One host sync."""
+        fl = self.flags.clone()
+        if self.group is not None:
+            import torch.distributed as dist
+            bad = fl[0:1].clone()
+            mn = fl[1:2].clone()
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+            fl = torch.cat([bad, mn])
+        bad, mn = (int(x) for x in fl.tolist())
+        return bool(bad), mn == 0
+
+    def _partial(self, st, tag):
+        if self.timer is None:
+            self.be.mu_partial(st)
+        else:
+            self.timer.mark(tag + '<')
+            self.be.mu_partial(st)
+            self.timer.mark(tag + '>')
+
+    def w_step(self):
+        """nmf.py:367-378.  Local even when sharded: W rows belong to this rank's columns."""
+        st = self.step_w
+        self._partial(st, 'w')
+        self.be.mu_apply(st, None, None, 0, self.fH.colsum if self.kl else None)
+
+    def h_step(self):
+        """nmf.py:380-391, with the freshly updated W."""
+        st = self.step_h
+        self._partial(st, 'h')
+        if self.group is None:
+            self.be.mu_apply(st, None, None, 0, self.fW.colsum if self.kl else None)
+            return
+        import torch.distributed as dist
+        num = self.xbuf[:st.plane]
+        tail = self.xbuf[st.plane:]
+        if self.kl:
+            self.be.slab_reduce(st, num, None)
+            tail.copy_(self.fW.colsum)
+        else:
+            self.be.slab_reduce(st, num, tail)
+        dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+        if self.kl:
+            self.be.mu_apply(st, num, None, 1, tail)
+        else:
+            self.be.mu_apply(st, num, tail, 1, None)
+
+    def divergence(self) -> float:
+        """beta_div(H W^T, V) (nmf.py:360-361 / 400-401), summed over shards.  One host sync."""
+        self.be.loss(self.step_h, self.loss_part, self.loss_out)
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.loss_out, op=dist.ReduceOp.SUM, group=self.group)
+        return float(self.loss_out.item())

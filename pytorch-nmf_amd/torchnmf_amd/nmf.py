@@ -1,0 +1,227 @@
+"""``torchnmf.nmf``-compatible module surface over the MI355X MU engine.
+
+Mirrors the public behaviour of the reference's ``BaseComponent`` / ``NMF`` /
+``NMFD`` (torchnmf/nmf.py:173-409, 641-779): same constructor arguments,
+attributes (``W``, ``H``, ``rank``, ``out_channels``, ``kernel_size``),
+``forward`` / ``reconstruct`` / ``fit`` signatures, return values and error
+types.  What differs is *where* the arithmetic happens: every compute entry
+point runs hand-written HIP kernels on the module's ROCm device through the C
+ABI of ``include/nmfmu.h``; there is no CPU path (a CPU-resident module raises
+on ``forward`` / ``fit``).
+
+Out of scope for this engine: sparse targets,
+``sparse_fit``, NMF2D/NMF3D, autograd through ``forward``.
+"""
+from __future__ import annotations
+
+import os
+from collections.abc import Iterable
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi
+from .constants import eps  # noqa: F401  (re-exported like the reference)
+
+__all__ = ['BaseComponent', 'NMF', 'NMFD']
+
+
+def _new_factor(spec, trainable: bool, label: str):
+    """Turn a constructor argument into (Parameter | None, inferred rank | None) -- nmf.py:213-237."""
+    if isinstance(spec, Tensor):
+        assert bool(torch.all(spec >= 0.)), f"Tensor {label} should be non-negative."
+        p = nn.Parameter(torch.empty(*spec.size()), requires_grad=trainable)
+        p.data.copy_(spec)
+        return p, p.shape[1]
+    if isinstance(spec, Iterable):
+        shape = tuple(spec)
+        # like the reference, a shape always yields a trainable factor drawn from |N(0, 1)|
+        return nn.Parameter(torch.randn(*shape).abs()), shape[1]
+    return None, None
+
+
+def _require_device(t: Tensor, what: str) -> None:
+    if t.device.type != 'cuda':
+        raise _capi.NmfmuError(f'{what}: tensors live on {t.device}; torchnmf_amd computes on an MI355X only -- move '
+                               f'the module and its inputs with .cuda() (there is no CPU fallback)')
+
+
+class BaseComponent(nn.Module):
+    """Base of the NMF modules (reference: nmf.py:173-292)."""
+
+    def __init__(self, rank: Optional[int] = None, W=None, H=None, trainable_W: bool = True, trainable_H: bool = True):
+        super().__init__()
+        w_param, w_rank = _new_factor(W, trainable_W, 'W')
+        h_param, h_rank = _new_factor(H, trainable_H, 'H')
+        self.register_parameter('W', w_param)
+        self.register_parameter('H', h_param)
+        inferred = h_rank if h_rank is not None else w_rank
+        if inferred is None:
+            assert rank, "A rank should be given when W and H are not available!"
+        else:
+            if h_param is not None:
+                assert h_param.shape[1] == inferred, "Latent size of H does not match with others!"
+            if w_param is not None:
+                assert w_param.shape[1] == inferred, "Latent size of W does not match with others!"
+                self.out_channels = w_param.shape[0]
+                if w_param.ndim > 2:
+                    self.kernel_size = tuple(w_param.shape[2:])
+            rank = inferred
+        self.rank = rank
+
+    def extra_repr(self) -> str:
+        parts = [str(self.rank)]
+        if self.W is not None:
+            parts.append(f'out_channels={self.out_channels}')
+            if hasattr(self, 'kernel_size'):
+                parts.append(f'kernel_size={self.kernel_size}')
+        return ', '.join(parts)
+
+    def forward(self, H: Tensor = None, W: Tensor = None) -> Tensor:
+        """Reconstruction with the module's own factors substituted for missing arguments (nmf.py:261-284)."""
+        H = self.H if H is None else H
+        W = self.W if W is None else W
+        assert H is not None
+        assert W is not None
+        return self.reconstruct(H, W)
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor) -> Tensor:
+        raise NotImplementedError
+
+    def _make_engine(self, V, beta, l1, l2, precision, group):
+        raise NotImplementedError
+
+    def sparse_fit(self, *args, **kwargs):
+        raise NotImplementedError('sparse_fit (Hoyer-projected gradient, nmf.py:411-599) is outside the MU hot path '
+                                  'this engine implements')
+
+    @torch.no_grad()
+    def fit(self, V: Tensor, beta: float = 1, tol: float = 1e-4, max_iter: int = 200, verbose: bool = False,
+            alpha: float = 0, l1_ratio: float = 0, *, precision: Optional[str] = None, process_group=None) -> int:
+        """Minimise the beta-divergence between ``V`` and the model by multiplicative updates.
+
+        Same contract as the reference (nmf.py:297-409): W half-step, then H
+        half-step with the new W, every iteration; every 10th iteration the loss
+        ``sqrt(2 * beta_div)`` is evaluated and the loop stops once
+        ``(previous - loss) / loss_init < tol``.  Returns the number of iterations.
+
+        Extra keyword-only arguments (not in the reference):
+          precision      'bf16x3' (default where available: split-bf16 MFMA, matches the fp32 reference to
+                         ~1e-5), 'bf16' (fastest; V and operands rounded to bf16), or None/'auto'.
+                         The environment variable TORCHNMF_AMD_PRECISION overrides the default.
+          process_group  a torch.distributed group: V and W are then this rank's column shard
+                         (V[:, Cg], W[Cg]); H is replicated.
+        """
+        if V.is_sparse:
+            raise NotImplementedError('sparse targets (nmf.py:95-119, 602-638) are outside this engine\'s scope')
+        W, H = self.W, self.H
+        assert W is not None and H is not None
+        _require_device(V, 'fit')
+        _require_device(W, 'fit')
+        _require_device(H, 'fit')
+        if precision is None:
+            precision = os.environ.get('TORCHNMF_AMD_PRECISION', 'auto')
+        beta = float(beta)
+        l1 = float(alpha * l1_ratio)        # nmf.py:348-349
+        l2 = float(alpha * (1 - l1_ratio))
+        V = V.detach()
+        if V.dtype != torch.float32:
+            V = V.float()
+        eng = self._make_engine(V, beta, l1, l2, precision, process_group)
+
+        has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
+        assert not has_bad, "Target should be non-negative."
+        if has_zero and beta <= 0:
+            raise ValueError("When beta <= 0 and V contains zeros, the training process may diverge. "
+                             "Please add small values to V, or use a positive beta value.")
+
+        loss_init = (2.0 * eng.divergence()) ** 0.5   # nmf.py:355-363
+        previous = loss_init
+        pbar = None
+        if verbose:
+            from tqdm import tqdm
+            pbar = tqdm(total=max_iter)
+        n_iter = -1
+        try:
+            for n_iter in range(max_iter):
+                if W.requires_grad:
+                    eng.w_step()
+                if H.requires_grad:
+                    eng.h_step()
+                if n_iter % 10 == 9:
+                    loss = (2.0 * eng.divergence()) ** 0.5
+                    if pbar is not None:
+                        pbar.set_postfix(loss=loss)
+                        pbar.update(10)
+                    if (previous - loss) / loss_init < tol:
+                        break
+                    previous = loss
+        finally:
+            if pbar is not None:
+                pbar.close()
+        return n_iter + 1
+
+
+class NMF(BaseComponent):
+    """Non-negative matrix factorisation ``V (N, C) ~ H (N, R) @ W (C, R)^T`` (reference: nmf.py:641-697)."""
+
+    def __init__(self, Vshape=None, rank: Optional[int] = None, **kwargs):
+        if isinstance(Vshape, Iterable):
+            n_rows, n_cols = Vshape
+            rank = rank if rank else n_cols
+            kwargs['W'] = (n_cols, rank)
+            kwargs['H'] = (n_rows, rank)
+        super().__init__(rank, **kwargs)
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor) -> Tensor:
+        """``H @ W.T`` (nmf.py:691-693) by an exact-fp32 MFMA kernel on the device."""
+        _require_device(H, 'reconstruct')
+        _require_device(W, 'reconstruct')
+        assert H.dim() == 2 and W.dim() == 2 and H.shape[1] == W.shape[1]
+        lib = _capi.load()
+        Hc = H.detach().float().contiguous()
+        Wc = W.detach().float().contiguous()
+        out = torch.empty(Hc.shape[0], Wc.shape[0], dtype=torch.float32, device=H.device)
+        _capi.check(lib.nmfmu_reconstruct(Hc.data_ptr(), Hc.shape[0], Wc.data_ptr(), Wc.shape[0], Hc.shape[1],
+                                          out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream),
+                    'nmfmu_reconstruct')
+        return out
+
+    def _make_engine(self, V, beta, l1, l2, precision, group):
+        from .engine import DenseMU
+        assert V.dim() == 2 and V.shape == (self.H.shape[0], self.W.shape[0]), \
+            f'V must be {(self.H.shape[0], self.W.shape[0])}, got {tuple(V.shape)}'
+        for p in (self.W, self.H):
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+        return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
+                       update_W=self.W.requires_grad, update_H=self.H.requires_grad)
+
+
+class NMFD(BaseComponent):
+    """1-D convolutive NMF ``V[b,c,l] ~ sum_t sum_r W[c,r,t] H[b,r,l-t]`` (reference: nmf.py:700-779)."""
+
+    def __init__(self, Vshape=None, rank: Optional[int] = None, T=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            if isinstance(T, Iterable):
+                T, = tuple(T)
+            batch, n_chan, length = Vshape
+            rank = rank if rank else n_chan
+            kwargs['W'] = (n_chan, rank, T)
+            kwargs['H'] = (batch, rank, length - T + 1)
+        super().__init__(rank, **kwargs)
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor) -> Tensor:
+        from .nmfd_engine import reconstruct as _recon
+        return _recon(H, W)
+
+    def _make_engine(self, V, beta, l1, l2, precision, group):
+        from .nmfd_engine import ConvMU
+        if group is not None:
+            raise NotImplementedError('NMFD is not sharded (replicas only): sharding L needs a (T-1)-column halo')
+        return ConvMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
+                      update_W=self.W.requires_grad, update_H=self.H.requires_grad)

@@ -115,3 +115,14 @@ def test_sharded_simulation_matches_unsharded(world, beta):
     Ws, Hs = O.nmf_fit_sharded(V, W0, H0, world, beta=beta, n_iter=20)
     W, H, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 20)
     assert rel_err(Ws, W) < 5e-6 and rel_err(Hs, H) < 5e-6
+
+
+@pytest.mark.parametrize('beta', [0, 0.5, 1, 2])
+def test_aten_port_equals_closed_form(beta):
+    """bench.py times oracle/aten_port.py as the CPU baseline; it must be the same maths as the oracle."""
+    from oracle import aten_port
+    g = load_golden('g1_nmf_small')
+    V = t(g['V']) + (1e-3 if beta <= 0 else 0.0)
+    Wp, Hp = aten_port.mu_iterations(V, t(g['W0']), t(g['H0']), beta, 10, alpha=0.1, l1_ratio=0.5)
+    W, H, _, _, _ = O.fit(V, t(g['W0']), t(g['H0']), beta, NO_STOP, 10, 0.1, 0.5)
+    assert rel_err(Wp, W) < 2e-6 and rel_err(Hp, H) < 2e-6
