@@ -276,9 +276,12 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
       for (int d = 0; d < 8; ++d) {
         float x0, x1;
         if constexpr (X3) {
-          const u32x4 c = x[4 * tt + (d >> 1)];
-          x0 = __builtin_bit_cast(float, c[2 * (d & 1)]);
-          x1 = __builtin_bit_cast(float, c[2 * (d & 1) + 1]);
+          // NB: extract to scalars first -- __builtin_bit_cast on an ext-vector ELEMENT lvalue reads element 0
+          // (hipcc 7.2), which silently turned every 16-byte chunk into a splat of its first float.
+          const uint32_t u0 = x[4 * tt + (d >> 1)][2 * (d & 1)];
+          const uint32_t u1 = x[4 * tt + (d >> 1)][2 * (d & 1) + 1];
+          x0 = __builtin_bit_cast(float, u0);
+          x1 = __builtin_bit_cast(float, u1);
         } else {
           const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
           x0 = bf16_lo(w);
