@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--stage', type=int, default=None, help='0 = register staging, 1 = LDS-DMA (default)')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
     return ap.parse_args()
 
 
@@ -93,7 +94,7 @@ def main():
     H = torch.randn(N, R, device=dev, generator=gh).abs_()             # replicated
     W0c, H0c = (W.cpu(), H.cpu()) if (rank == 0 and world == 1 and a.cpu_iters > 0) else (None, None)
 
-    eng = DenseMU(V, W, H, beta, precision=a.precision, stage=a.stage, group=group)
+    eng = DenseMU(V, W, H, beta, precision=a.precision, stage=a.stage, group=group, block_rows=a.block_rows)
     Vc = V.cpu() if W0c is not None else None
     del V
     torch.cuda.synchronize()
@@ -179,7 +180,7 @@ def main():
                                    f'NMF {N}x{C} rank={R} beta={beta:g} (BASELINE configs[1])',
                        'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
-                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit},
+                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -59,7 +59,7 @@ typedef struct nmfmu_factor {
   void* p2_hi;        /* bf16 transposed tiles [rows_pad/64][r_pad][64]                                            */
   void* p2_lo;
   float* colsum;      /* [r_pad]  sum over rows of f: the beta==1 denominators of nmf.py:122-131                   */
-  float* colsum_part; /* [rows_pad/64][r_pad] scratch for the deterministic two-stage column sum                   */
+  float* colsum_part; /* nmfmu_colsum_part_bytes(): scratch for the deterministic two-stage column sum            */
   int32_t rows;
   int32_t rows_pad;   /* nmfmu_pad_rows(rows) */
 } nmfmu_factor;
@@ -76,6 +76,7 @@ typedef struct nmfmu_step {
   int32_t nsplit;      /* contraction-axis split (workgroups per owner block), nmfmu_choose_nsplit                 */
   int32_t precision;   /* NMFMU_PREC_*  */
   int32_t stage;       /* NMFMU_STAGE_* */
+  int32_t block_rows;  /* owner rows per workgroup tile: nmfmu_block_rows(); xp must have been packed with it        */
   float beta;
   float gamma;         /* nmf.py:341-346 */
   float l1, l2;        /* nmf.py:348-349 */
@@ -83,11 +84,12 @@ typedef struct nmfmu_step {
 
 /* ---- static queries (host only, no device work) ------------------------------------------------------------ */
 int nmfmu_abi_version(void);
-int nmfmu_pad_rows(int rows);             /* rows rounded up to the 128-row workgroup tile                        */
+int nmfmu_pad_rows(int rows);             /* rows rounded up to a multiple of 256                                  */
 int nmfmu_pad_rank(int rank);             /* 32 / 64 / 128 / 256, or NMFMU_ERR_UNSUPPORTED                         */
 int nmfmu_beta_kind(float beta);          /* NMFMU_BETA_*                                                          */
 int nmfmu_supported(int r_pad, int precision);
-int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int num_cu);
+int nmfmu_block_rows(int r_pad, int precision, float beta); /* 128 or 256: owner rows per workgroup tile          */
+int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu);
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision);
 size_t nmfmu_image_bytes(int rows_pad, int r_pad);            /* one plane of p1 or of p2                          */
 size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit);
@@ -101,7 +103,7 @@ size_t nmfmu_colsum_part_bytes(int rows_pad, int r_pad);
  *   flags[0] |= 1 if any element fails (v >= 0)   (negative or NaN)
  *   flags[1]  = min over elements of the fp32 bit pattern (caller presets 0x7f800000); == 0 iff V.min() == 0
  */
-int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, void* xp,
+int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, int block_rows, void* xp,
                  int owner_rows_pad, int panel_rows_pad, uint32_t* flags, void* stream);
 
 /* nmfmu_pack_factor: build the bf16 images and the column sums from the fp32 master (after the user or
@@ -132,7 +134,7 @@ int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int
  * (replaces nmf.py:360-361 and 400-401).  loss_part: nmfmu_loss_part_count() floats of scratch; *out (device
  * double) receives the divergence (NOT yet sqrt(2 x)).  rows/cols are the logical sizes of X.
  */
-int nmfmu_loss_part_count(int owner_rows_pad, int panel_rows_pad, int num_cu);
+int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit);
 int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream);
 
 /* nmfmu_beta_div: metrics.beta_div(x, y, beta) on two plain fp32 device arrays of n elements.

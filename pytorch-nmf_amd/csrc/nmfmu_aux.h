@@ -15,14 +15,14 @@ struct ApplyArgs {
   void* p1_lo;
   void* p2_hi;
   void* p2_lo;
-  float* colsum_part;   // [rows_pad/64][R_PAD]
+  float* colsum_part;   // [rows_pad/16][R_PAD] (worst case)
   float* colsum;        // [R_PAD]
   int rows, rank, rows_pad;
   float l1, l2, gamma;
 };
 
 int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
-                  int k_pad, uint32_t* flags, hipStream_t s);
+                  int k_pad, uint32_t* flags, int G, hipStream_t s);
 int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s);
 int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, hipStream_t s);
 int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s);

@@ -17,7 +17,7 @@ namespace nmfmu {
 template <bool FP32, bool TRANSPOSE>
 __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
                                                      void* __restrict__ xp, int ktiles, int64_t nchunks,
-                                                     uint32_t* flags) {
+                                                     uint32_t* flags, int G) {
   constexpr int NQ = FP32 ? 8 : 4;
   constexpr int EPC = FP32 ? 4 : 8;
   const int M = TRANSPOSE ? cols : rows;  // owner axis length
@@ -28,11 +28,13 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
     int64_t r = c >> 6;
     const int q = (int)(r % NQ);
     r /= NQ;
+    const int g = (int)(r % G);
+    r /= G;
     const int w = (int)(r & 3);
     r >>= 2;
     const int64_t kt = r % ktiles;
     const int64_t mb = r / ktiles;
-    const int64_t m = mb * 128 + w * 32 + (lane & 31);
+    const int64_t m = mb * (128 * G) + w * (32 * G) + g * 32 + (lane & 31);
     const int64_t k0 = kt * 64 + 32 * (lane >> 5) + (int64_t)q * EPC;
     float e[EPC];
 #pragma unroll
@@ -70,11 +72,11 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
 }
 
 int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
-                  int k_pad, uint32_t* flags, hipStream_t s) {
+                  int k_pad, uint32_t* flags, int G, hipStream_t s) {
   const int ktiles = k_pad / kBK;
   const int64_t nchunks = (int64_t)m_pad * k_pad * (fp32 ? 4 : 2) / 16;
   const int grid = (int)std::min<int64_t>((nchunks + 255) / 256, 256 * 32);
-#define L(F, T) hipLaunchKernelGGL((pack_x_kernel<F, T>), dim3(grid), dim3(256), 0, s, v, ld, rows, cols, xp, ktiles, nchunks, flags)
+#define L(F, T) hipLaunchKernelGGL((pack_x_kernel<F, T>), dim3(grid), dim3(256), 0, s, v, ld, rows, cols, xp, ktiles, nchunks, flags, G)
   if (fp32 && transpose) L(true, true);
   else if (fp32) L(true, false);
   else if (transpose) L(false, true);
@@ -87,73 +89,96 @@ int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose
 // apply: nmf.py:78-92 on a 64-row stripe of the owner factor, then re-emit that stripe's bf16 images (P1 rows,
 // one whole P2 tile) and its partial column sums.  PACK_ONLY skips the update (initial packing of W0 / H0).
 // ------------------------------------------------------------------------------------------------------------
-template <int R_PAD, bool X3, bool PACK_ONLY>
+template <int R_PAD, bool X3, bool PACK_ONLY, int ROWS>
 __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
-  constexpr int LDT = R_PAD + 1;
+  // ROWS = 64 (one whole P2 tile per block) for tall factors, 16 for short ones so that the grid still fills the chip.
+  constexpr int LDT = R_PAD + 1;  // odd leading dimension: the P2 column reads below stay <= 2-way bank conflicted
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* tile = reinterpret_cast<float*>(smem_raw);  // [64][R_PAD + 1]
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [ROWS][LDT]
   const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * 64;
+  const int row0 = blockIdx.x * ROWS;
   const size_t plane = (size_t)a.rows_pad * R_PAD;
+  constexpr int R4 = R_PAD / 4;
 
-  for (int idx = tid; idx < 64 * R_PAD; idx += 256) {
-    const int rl = idx / R_PAD, r = idx - rl * R_PAD;
+  for (int idx = tid; idx < ROWS * R4; idx += 256) {
+    const int rl = idx / R4, r = (idx - rl * R4) * 4;
     const int row = row0 + rl;
-    float f = 0.f;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < a.rows && r < a.rank) {
-      f = a.f[(size_t)row * a.rank + r];
+      const float* fp = a.f + (size_t)row * a.rank + r;
+      const int nv = min(4, a.rank - r);
+      for (int i = 0; i < nv; ++i) f[i] = fp[i];
       if constexpr (!PACK_ONLY) {
         const size_t e = (size_t)row * R_PAD + r;
-        float neg = 0.f;
-        for (int s = 0; s < a.nslab; ++s) neg += a.num[s * plane + e];
-        neg = fmaxf(neg, 0.f) + kEps;  // nmf.py:78
-        float pos;
-        if (a.kl_den) {
-          pos = a.kl_den[r];  // closed form, no relu / eps (nmf.py:80 branch skipped)
-        } else {
-          pos = 0.f;
-          for (int s = 0; s < a.nslab; ++s) pos += a.den[s * plane + e];
-          pos = fmaxf(pos, 0.f) + kEps;  // nmf.py:83
+        float4 n4 = *reinterpret_cast<const float4*>(a.num + e);
+        for (int s = 1; s < a.nslab; ++s) {
+          const float4 v = *reinterpret_cast<const float4*>(a.num + s * plane + e);
+          n4.x += v.x, n4.y += v.y, n4.z += v.z, n4.w += v.w;
         }
-        if (a.l1 > 0.f) pos += a.l1;       // nmf.py:85-86
-        if (a.l2 > 0.f) pos += a.l2 * f;   // nmf.py:87-88
-        float mult = neg / pos;
-        if (a.gamma != 1.f) mult = powf(mult, a.gamma);
-        f *= mult;
-        a.f[(size_t)row * a.rank + r] = f;
+        float neg[4] = {n4.x, n4.y, n4.z, n4.w};
+        float pos[4];
+        if (a.kl_den) {  // closed form, no relu / eps (nmf.py:80 branch skipped)
+          const float4 d4 = *reinterpret_cast<const float4*>(a.kl_den + r);
+          pos[0] = d4.x, pos[1] = d4.y, pos[2] = d4.z, pos[3] = d4.w;
+        } else {
+          float4 d4 = *reinterpret_cast<const float4*>(a.den + e);
+          for (int s = 1; s < a.nslab; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(a.den + s * plane + e);
+            d4.x += v.x, d4.y += v.y, d4.z += v.z, d4.w += v.w;
+          }
+          pos[0] = fmaxf(d4.x, 0.f) + kEps, pos[1] = fmaxf(d4.y, 0.f) + kEps;  // nmf.py:83
+          pos[2] = fmaxf(d4.z, 0.f) + kEps, pos[3] = fmaxf(d4.w, 0.f) + kEps;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < nv) {
+            const float ng = fmaxf(neg[i], 0.f) + kEps;  // nmf.py:78
+            float ps = pos[i];
+            if (a.l1 > 0.f) ps += a.l1;         // nmf.py:85-86
+            if (a.l2 > 0.f) ps += a.l2 * f[i];  // nmf.py:87-88
+            float mult = ng / ps;
+            if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+            f[i] *= mult;
+            a.f[(size_t)row * a.rank + r + i] = f[i];
+          }
+        }
       }
     }
-    tile[rl * LDT + r] = f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[rl * LDT + r + i] = f[i];
   }
   __syncthreads();
 
-  // P1: 64 rows x (R_PAD/8) sixteen-byte slots, swizzled inside each row
+  // P1: ROWS rows x (R_PAD/8) sixteen-byte slots, swizzled inside each row
   constexpr int SP = R_PAD / 8;
-  for (int idx = tid; idx < 64 * SP; idx += 256) {
+  for (int idx = tid; idx < ROWS * SP; idx += 256) {
     const int rl = idx / SP, slot = idx - rl * SP;
     const float* src = tile + rl * LDT + slot * 8;
     u32x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float x0 = src[2 * i], x1 = src[2 * i + 1];
-      hi[i] = pack_bf16(x0, x1);
-      lo[i] = pack_bf16(x0 - bf16_lo(hi[i]), x1 - bf16_hi(hi[i]));
+      const uint32_t h = pack_bf16(x0, x1);
+      hi[i] = h;
+      lo[i] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
     }
     const int64_t off = p1_offset(row0 + rl, slot * 8, R_PAD);
     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_hi) + off) = hi;
     if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_lo) + off) = lo;
   }
-  // P2: tile blockIdx.x = [R_PAD][64]; slot = 8 consecutive factor rows of one rank column
-  for (int idx = tid; idx < R_PAD * 8; idx += 256) {
-    const int r = idx >> 3, slot = idx & 7;
+  // P2: [R_PAD][64] tiles; this block owns ROWS/8 of the 8 slots (8 consecutive factor rows each) of every rank row
+  constexpr int NS = ROWS / 8;
+  for (int idx = tid; idx < R_PAD * NS; idx += 256) {
+    const int r = idx / NS, sl = idx - r * NS;
     u32x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float x0 = tile[(slot * 8 + 2 * i) * LDT + r], x1 = tile[(slot * 8 + 2 * i + 1) * LDT + r];
-      hi[i] = pack_bf16(x0, x1);
-      lo[i] = pack_bf16(x0 - bf16_lo(hi[i]), x1 - bf16_hi(hi[i]));
+      const float x0 = tile[(sl * 8 + 2 * i) * LDT + r], x1 = tile[(sl * 8 + 2 * i + 1) * LDT + r];
+      const uint32_t h = pack_bf16(x0, x1);
+      hi[i] = h;
+      lo[i] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
     }
-    const int64_t off = p2_offset(row0 + slot * 8, r, R_PAD);
+    const int64_t off = p2_offset(row0 + sl * 8, r, R_PAD);
     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p2_hi) + off) = hi;
     if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p2_lo) + off) = lo;
   }
@@ -161,36 +186,43 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   for (int r = tid; r < R_PAD; r += 256) {
     float s = 0.f;
 #pragma unroll 8
-    for (int rl = 0; rl < 64; ++rl) s += tile[rl * LDT + r];
+    for (int rl = 0; rl < ROWS; ++rl) s += tile[rl * LDT + r];
     a.colsum_part[(size_t)blockIdx.x * R_PAD + r] = s;
   }
 }
 
-// colsum[r] = sum_b part[b][r]; one block per 32 columns, 8 row groups, fixed combination order.
+// colsum[r] = sum_b part[b][r].  One block per 32 columns: 8 float4 column groups x 32 row groups, combined in a
+// fixed order (deterministic), each thread striding over the partials so a 1024-stripe factor needs 32 loads per thread.
 __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int r_pad,
                                                               float* __restrict__ out) {
-  __shared__ float red[8][32];
-  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
-  float s = 0.f;
-  for (int b = g; b < nblk; b += 8) s += part[(size_t)b * r_pad + col];
-  red[g][c] = s;
+  __shared__ float4 red[32][8];
+  const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int col = blockIdx.x * 32 + c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = g; b < nblk; b += 32) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * r_pad + col);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  red[g][c4] = s;
   __syncthreads();
   if (g == 0) {
-    float t = 0.f;
+    float4 t = red[0][c4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i][c];
-    out[col] = t;
+    for (int i = 1; i < 32; ++i) {
+      const float4 v = red[i][c4];
+      t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + col) = t;
   }
 }
 
-template <int R_PAD>
-int launch_apply_r(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
-  const int grid = a.rows_pad / 64;
-  const size_t lds = (size_t)64 * (R_PAD + 1) * sizeof(float);
+template <int R_PAD, int ROWS>
+int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
+  const int grid = a.rows_pad / ROWS;
+  const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float);
 #define L(X, P)                                                                                                      \
   {                                                                                                                  \
-    auto k = apply_kernel<R_PAD, X, P>;                                                                              \
+    auto k = apply_kernel<R_PAD, X, P, ROWS>;                                                                        \
     if (lds > 64 * 1024) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds);                                                                  \
@@ -207,6 +239,13 @@ int launch_apply_r(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   if (e) return e;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(R_PAD / 32), dim3(256), 0, s, a.colsum_part, grid, R_PAD, a.colsum);
   return (int)hipGetLastError();
+}
+
+template <int R_PAD>
+int launch_apply_r(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
+  // short factors (few 64-row stripes) get 16-row stripes so that >= ~256 workgroups exist
+  if (a.rows_pad / 64 < 512) return launch_apply_rr<R_PAD, 16>(a, x3, pack_only, s);
+  return launch_apply_rr<R_PAD, 64>(a, x3, pack_only, s);
 }
 
 int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {

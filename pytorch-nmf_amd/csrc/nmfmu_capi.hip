@@ -18,7 +18,9 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s) {
   if (!st || !st->xp || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
-  if (st->owner.rows_pad % kBM || st->panel.rows_pad % kBM) return NMFMU_ERR_ARG;
+  if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
+  if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
+  const int G = st->block_rows / 128;
   if (st->r_pad != pad_rank(st->rank) || st->nsplit < 1) return NMFMU_ERR_ARG;
   const int x3 = st->precision == NMFMU_PREC_BF16X3 ? 1 : 0;
   if (x3 && (!st->owner.p1_lo || !st->panel.p1_lo)) return NMFMU_ERR_ARG;
@@ -47,13 +49,13 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   } else if (!loss_part) {
     return NMFMU_ERR_ARG;
   }
-  const int grid = (st->owner.rows_pad / kBM) * st->nsplit;
+  const int grid = (st->owner.rows_pad / st->block_rows) * st->nsplit;
   const int stage = st->stage == NMFMU_STAGE_REG ? 0 : 1;
   switch (st->r_pad) {
-    case 32: return launch_fused_r32(kind, x3, mode, stage, a, grid, s);
-    case 64: return launch_fused_r64(kind, x3, mode, stage, a, grid, s);
-    case 128: return launch_fused_r128(kind, x3, mode, stage, a, grid, s);
-    case 256: return launch_fused_r256(kind, x3, mode, stage, a, grid, s);
+    case 32: return launch_fused_r32(kind, x3, mode, stage, G, a, grid, s);
+    case 64: return launch_fused_r64(kind, x3, mode, stage, G, a, grid, s);
+    case 128: return launch_fused_r128(kind, x3, mode, stage, G, a, grid, s);
+    case 256: return launch_fused_r256(kind, x3, mode, stage, G, a, grid, s);
   }
   return NMFMU_ERR_UNSUPPORTED;
 }
@@ -85,11 +87,18 @@ int nmfmu_supported(int r_pad, int precision) {
   return 0;
 }
 
-int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int num_cu) {
-  if (owner_rows_pad <= 0 || panel_rows_pad <= 0) return NMFMU_ERR_ARG;
-  const int mblocks = owner_rows_pad / kBM;
+int nmfmu_block_rows(int r_pad, int precision, float beta) {
+  // 256-row tiles (two 32-row groups per wave, one wave per SIMD with the whole register file) where the
+  // accumulators fit: bf16 operands, beta == 1, padded rank <= 128.  Everything else uses 128-row tiles.
+  return has_g2(r_pad, nmfmu_beta_kind(beta), precision == NMFMU_PREC_BF16X3, kModeMU) ? 256 : 128;
+}
+
+int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu) {
+  if (owner_rows_pad <= 0 || panel_rows_pad <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
+  const int mblocks = owner_rows_pad / block_rows;
   const int ktiles = panel_rows_pad / kBK;
-  const int target = 2 * std::max(num_cu, 1);  // two workgroups per CU keep both wave slots of every SIMD busy
+  // 128-row tiles run two workgroups per CU (both wave slots of every SIMD); 256-row tiles run one.
+  const int target = (block_rows == 128 ? 2 : 1) * std::max(num_cu, 1);
   int ns = (target + mblocks - 1) / mblocks;
   if (ns > 8) ns = (ns + 7) / 8 * 8;           // same-chunk workgroups then share an XCD (block b runs on XCD b % 8)
   ns = std::min(ns, std::max(1, ktiles / 4));  // at least 4 tiles per workgroup to amortise prologue/epilogue
@@ -103,15 +112,15 @@ size_t nmfmu_image_bytes(int rows_pad, int r_pad) { return (size_t)rows_pad * (s
 size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit) {
   return (size_t)nsplit * (size_t)owner_rows_pad * (size_t)r_pad * 4;
 }
-size_t nmfmu_colsum_part_bytes(int rows_pad, int r_pad) { return (size_t)(rows_pad / 64) * (size_t)r_pad * 4; }
+size_t nmfmu_colsum_part_bytes(int rows_pad, int r_pad) { return (size_t)(rows_pad / 16) * (size_t)r_pad * 4; }
 
-int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, void* xp,
+int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, int precision, int block_rows, void* xp,
                  int owner_rows_pad, int panel_rows_pad, uint32_t* flags, void* stream) {
-  if (!v || !xp || rows <= 0 || cols <= 0) return NMFMU_ERR_ARG;
+  if (!v || !xp || rows <= 0 || cols <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int m = transpose ? cols : rows, k = transpose ? rows : cols;
   if (owner_rows_pad != pad_rows(m) || panel_rows_pad != pad_rows(k)) return NMFMU_ERR_ARG;
   return launch_pack_x(v, ld, rows, cols, transpose != 0, precision == NMFMU_PREC_BF16X3, xp, owner_rows_pad,
-                       panel_rows_pad, flags, S(stream));
+                       panel_rows_pad, flags, block_rows / 128, S(stream));
 }
 
 int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream) {
@@ -166,9 +175,9 @@ int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
 }
 
-int nmfmu_loss_part_count(int owner_rows_pad, int panel_rows_pad, int num_cu) {
-  const int ns = nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, num_cu);
-  return ns < 0 ? ns : (owner_rows_pad / kBM) * ns;
+int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit) {
+  if (block_rows != 128 && block_rows != 256) return NMFMU_ERR_ARG;
+  return (owner_rows_pad / block_rows) * nsplit;
 }
 
 int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream) {
@@ -176,7 +185,7 @@ int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream
   if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
   int e = fused_dispatch(st, kModeLoss, loss_part, st->owner.rows, st->panel.rows, S(stream));
   if (e) return e;
-  return launch_sum_finalize_f32(loss_part, (st->owner.rows_pad / kBM) * st->nsplit, out, S(stream));
+  return launch_sum_finalize_f32(loss_part, (st->owner.rows_pad / st->block_rows) * st->nsplit, out, S(stream));
 }
 
 int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double* part, double* out, void* stream) {

@@ -64,8 +64,11 @@ struct FusedArgs {
   float beta;
 };
 
-template <int R_PAD, int BETA, bool X3, int MODE>
+// G = 32-row groups per wave: G = 1 -> 128-row workgroup tile, 2 waves/SIMD; G = 2 -> 256-row tile, every LDS
+// operand read feeds two MFMAs and the wave has the whole 512-register file (one wave per SIMD).
+template <int R_PAD, int BETA, bool X3, int MODE, int G = 1>
 struct FusedCfg {
+  static constexpr int BM = 128 * G;
   static constexpr int KS = R_PAD / 16;      // k-steps of GEMM1 (contraction over rank)
   static constexpr int RT = R_PAD / 32;      // 32-wide rank tiles of GEMM2's output
   static constexpr int ROWB = 2 * R_PAD;     // bytes per P1 row
@@ -82,7 +85,7 @@ struct FusedCfg {
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
-  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128) ? 1 : 2;
+  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1) ? 1 : 2;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -144,9 +147,10 @@ __device__ __forceinline__ float loss_elem(float s, float x, float beta) {
   }
 }
 
-template <int R_PAD, int BETA, bool X3, int MODE, int STAGE>
-__global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) fused_kernel(const FusedArgs a) {
-  using C = FusedCfg<R_PAD, BETA, X3, MODE>;
+template <int R_PAD, int BETA, bool X3, int MODE, int STAGE, int G>
+__global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW)) fused_kernel(const FusedArgs a) {
+  using C = FusedCfg<R_PAD, BETA, X3, MODE, G>;
+  constexpr int BM = C::BM;
   constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, NQ = C::NQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -159,20 +163,22 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
   const int ks = blockIdx.x - mb * a.nsplit;
   const int t0 = ks * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.ktiles);
-  const int m = mb * kBM + wave * 32 + j;
+  const int m0 = mb * BM + wave * (32 * G) + j;  // row of group g is m0 + 32 * g
 
   // ---- owner fragments (B operand of GEMM1): row m, rank slice 16*kk + 8*hl .. +7
-  u32x4 qh[KS];
-  u32x4 ql[X3 ? KS : 1];
-  {
+  u32x4 qh[G][KS];
+  u32x4 ql[G][X3 ? KS : 1];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int m = m0 + 32 * g;
     const int sw = ((m >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
     const char* rowh = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m * ROWB;
     const char* rowl = reinterpret_cast<const char*>(a.a1_lo) + (size_t)m * ROWB;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int off = (kk * 32 + hl * 16) ^ sw;
-      qh[kk] = ld16(rowh + off);
-      if constexpr (X3) ql[kk] = ld16(rowl + off);
+      qh[g][kk] = ld16(rowh + off);
+      if constexpr (X3) ql[g][kk] = ld16(rowl + off);
     }
   }
 
@@ -194,23 +200,29 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) b_off[tt][m2] = ((4 * hl + 2 * tt + m2) << 4) ^ (((j >> 1) & 7) << 4);
 
-  f32x16 on[C::LOSS ? 1 : RT];
-  f32x16 op[C::TWO_ACC ? RT : 1];
+  f32x16 on[G][C::LOSS ? 1 : RT];
+  f32x16 op[G][C::TWO_ACC ? RT : 1];
 #pragma unroll
-  for (int rt = 0; rt < (C::LOSS ? 1 : RT); ++rt)
+  for (int g = 0; g < G; ++g) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) on[rt][e] = 0.f;
+    for (int rt = 0; rt < (C::LOSS ? 1 : RT); ++rt)
 #pragma unroll
-  for (int rt = 0; rt < (C::TWO_ACC ? RT : 1); ++rt)
+      for (int e = 0; e < 16; ++e) on[g][rt][e] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) op[rt][e] = 0.f;
+    for (int rt = 0; rt < (C::TWO_ACC ? RT : 1); ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) op[g][rt][e] = 0.f;
+  }
   float lacc = 0.f;
 
-  const char* xbase = reinterpret_cast<const char*>(a.xp) + ((size_t)mb * a.ktiles * 4 + wave) * (NQ * 1024) + lane * 16;
-  auto load_x = [&](int t, u32x4(&x)[NQ]) {
-    const char* p = xbase + (size_t)t * (4 * NQ * 1024);
+  const char* xbase =
+      reinterpret_cast<const char*>(a.xp) + ((size_t)mb * a.ktiles * 4 + wave) * (G * NQ * 1024) + lane * 16;
+  auto load_x = [&](int t, u32x4(&x)[G][NQ]) {
+    const char* p = xbase + (size_t)t * (4 * G * NQ * 1024);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = ld16(p + q * 1024);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) x[g][q] = ld16(p + (g * NQ + q) * 1024);
   };
 
   // ---- panel staging: every image tile is one contiguous, pre-swizzled block in HBM
@@ -248,62 +260,71 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
     }
   };
 
-  auto compute = [&](int t, int buf, const u32x4(&x)[NQ]) {
+  auto compute = [&](int t, int buf, const u32x4(&x)[G][NQ]) {
     const char* sb = smem + buf * C::STAGE_BYTES;
     // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank
-    f32x16 s[2];
+    f32x16 s[G][2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[tt][e] = (BETA == kEuc) ? 0.f : kEps;
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[g][tt][e] = (BETA == kEuc) ? 0.f : kEps;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         const int off = a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
         const u32x4 ah = ld16(sb + C::P1HI + off);
         if constexpr (X3) {
           const u32x4 al = ld16(sb + C::P1LO + off);
-          s[tt] = mfma_bf16(al, qh[kk], s[tt]);
-          s[tt] = mfma_bf16(ah, ql[kk], s[tt]);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            s[g][tt] = mfma_bf16(al, qh[g][kk], s[g][tt]);
+            s[g][tt] = mfma_bf16(ah, ql[g][kk], s[g][tt]);
+          }
         }
-        s[tt] = mfma_bf16(ah, qh[kk], s[tt]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[g][tt] = mfma_bf16(ah, qh[g][kk], s[g][tt]);
       }
     }
     // ---------------- elementwise: Gn / Gp (or the loss terms), packed to bf16 A operands
-    uint32_t gnh[2][8], gnl[X3 ? 2 : 1][8], gph[C::TWO_ACC ? 2 : 1][8], gpl[(C::TWO_ACC && X3) ? 2 : 1][8];
+    uint32_t gnh[G][2][8], gnl[G][X3 ? 2 : 1][8], gph[G][C::TWO_ACC ? 2 : 1][8], gpl[G][(C::TWO_ACC && X3) ? 2 : 1][8];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        float x0, x1;
-        if constexpr (X3) {
-          // NB: extract to scalars first -- __builtin_bit_cast on an ext-vector ELEMENT lvalue reads element 0
-          // (hipcc 7.2), which silently turned every 16-byte chunk into a splat of its first float.
-          const uint32_t u0 = x[4 * tt + (d >> 1)][2 * (d & 1)];
-          const uint32_t u1 = x[4 * tt + (d >> 1)][2 * (d & 1) + 1];
-          x0 = __builtin_bit_cast(float, u0);
-          x1 = __builtin_bit_cast(float, u1);
-        } else {
-          const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
-          x0 = bf16_lo(w);
-          x1 = bf16_hi(w);
-        }
-        const float s0 = s[tt][2 * d], s1 = s[tt][2 * d + 1];
-        if constexpr (C::LOSS) {
-          const int k0 = t * kBK + 32 * hl + 16 * tt + 2 * d;
-          const bool rowok = m < a.M;
-          lacc += (rowok && k0 < a.K) ? loss_elem<BETA>(s0, x0, a.beta) : 0.f;
-          lacc += (rowok && k0 + 1 < a.K) ? loss_elem<BETA>(s1, x1, a.beta) : 0.f;
-        } else {
-          float n0, n1, p0, p1;
-          mu_elem<BETA>(s0, x0, a.beta, n0, p0);
-          mu_elem<BETA>(s1, x1, a.beta, n1, p1);
-          const uint32_t nh = pack_bf16(n0, n1);
-          gnh[tt][d] = nh;
-          if constexpr (X3) gnl[tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
-          if constexpr (C::TWO_ACC) {
-            const uint32_t ph = pack_bf16(p0, p1);
-            gph[tt][d] = ph;
-            if constexpr (X3) gpl[tt][d] = pack_bf16(p0 - bf16_lo(ph), p1 - bf16_hi(ph));
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          float x0, x1;
+          if constexpr (X3) {
+            // NB: extract to scalars first -- __builtin_bit_cast on an ext-vector ELEMENT lvalue reads element 0
+            // (hipcc 7.2), which silently turned every 16-byte chunk into a splat of its first float.
+            const uint32_t u0 = x[g][4 * tt + (d >> 1)][2 * (d & 1)];
+            const uint32_t u1 = x[g][4 * tt + (d >> 1)][2 * (d & 1) + 1];
+            x0 = __builtin_bit_cast(float, u0);
+            x1 = __builtin_bit_cast(float, u1);
+          } else {
+            const uint32_t w = x[g][2 * tt + (d >> 2)][d & 3];
+            x0 = bf16_lo(w);
+            x1 = bf16_hi(w);
+          }
+          const float s0 = s[g][tt][2 * d], s1 = s[g][tt][2 * d + 1];
+          if constexpr (C::LOSS) {
+            const int k0 = t * kBK + 32 * hl + 16 * tt + 2 * d;
+            const bool rowok = m0 + 32 * g < a.M;
+            lacc += (rowok && k0 < a.K) ? loss_elem<BETA>(s0, x0, a.beta) : 0.f;
+            lacc += (rowok && k0 + 1 < a.K) ? loss_elem<BETA>(s1, x1, a.beta) : 0.f;
+          } else {
+            float n0, n1, p0, p1;
+            mu_elem<BETA>(s0, x0, a.beta, n0, p0);
+            mu_elem<BETA>(s1, x1, a.beta, n1, p1);
+            const uint32_t nh = pack_bf16(n0, n1);
+            gnh[g][tt][d] = nh;
+            if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
+            if constexpr (C::TWO_ACC) {
+              const uint32_t ph = pack_bf16(p0, p1);
+              gph[g][tt][d] = ph;
+              if constexpr (X3) gpl[g][tt][d] = pack_bf16(p0 - bf16_lo(ph), p1 - bf16_hi(ph));
+            }
           }
         }
       }
@@ -318,24 +339,31 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
           for (int m2 = 0; m2 < 2; ++m2) {
             const int off = rt * 4096 + b_row + b_off[tt][m2];
             const u32x4 bh = ld16(sb + C::P2HI + off);
-            const u32x4 nh = {gnh[tt][4 * m2], gnh[tt][4 * m2 + 1], gnh[tt][4 * m2 + 2], gnh[tt][4 * m2 + 3]};
-            if constexpr (X3) {
-              const u32x4 bl = ld16(sb + C::P2LO + off);
-              const u32x4 nl = {gnl[tt][4 * m2], gnl[tt][4 * m2 + 1], gnl[tt][4 * m2 + 2], gnl[tt][4 * m2 + 3]};
-              on[rt] = mfma_bf16(nl, bh, on[rt]);
-              on[rt] = mfma_bf16(nh, bl, on[rt]);
-              if constexpr (C::TWO_ACC) {
-                const u32x4 ph = {gph[tt][4 * m2], gph[tt][4 * m2 + 1], gph[tt][4 * m2 + 2], gph[tt][4 * m2 + 3]};
-                const u32x4 pl = {gpl[tt][4 * m2], gpl[tt][4 * m2 + 1], gpl[tt][4 * m2 + 2], gpl[tt][4 * m2 + 3]};
-                op[rt] = mfma_bf16(pl, bh, op[rt]);
-                op[rt] = mfma_bf16(ph, bl, op[rt]);
-                op[rt] = mfma_bf16(ph, bh, op[rt]);
+            u32x4 bl;
+            if constexpr (X3) bl = ld16(sb + C::P2LO + off);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const u32x4 nh = {gnh[g][tt][4 * m2], gnh[g][tt][4 * m2 + 1], gnh[g][tt][4 * m2 + 2],
+                                gnh[g][tt][4 * m2 + 3]};
+              if constexpr (X3) {
+                const u32x4 nl = {gnl[g][tt][4 * m2], gnl[g][tt][4 * m2 + 1], gnl[g][tt][4 * m2 + 2],
+                                  gnl[g][tt][4 * m2 + 3]};
+                on[g][rt] = mfma_bf16(nl, bh, on[g][rt]);
+                on[g][rt] = mfma_bf16(nh, bl, on[g][rt]);
               }
-            } else if constexpr (C::TWO_ACC) {
-              const u32x4 ph = {gph[tt][4 * m2], gph[tt][4 * m2 + 1], gph[tt][4 * m2 + 2], gph[tt][4 * m2 + 3]};
-              op[rt] = mfma_bf16(ph, bh, op[rt]);
+              on[g][rt] = mfma_bf16(nh, bh, on[g][rt]);
+              if constexpr (C::TWO_ACC) {
+                const u32x4 ph = {gph[g][tt][4 * m2], gph[g][tt][4 * m2 + 1], gph[g][tt][4 * m2 + 2],
+                                  gph[g][tt][4 * m2 + 3]};
+                if constexpr (X3) {
+                  const u32x4 pl = {gpl[g][tt][4 * m2], gpl[g][tt][4 * m2 + 1], gpl[g][tt][4 * m2 + 2],
+                                    gpl[g][tt][4 * m2 + 3]};
+                  op[g][rt] = mfma_bf16(pl, bh, op[g][rt]);
+                  op[g][rt] = mfma_bf16(ph, bl, op[g][rt]);
+                }
+                op[g][rt] = mfma_bf16(ph, bh, op[g][rt]);
+              }
             }
-            on[rt] = mfma_bf16(nh, bh, on[rt]);
           }
         }
       }
@@ -344,7 +372,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
 
   // ---------------- main loop over the chunk's tiles (double-buffered panel, X one tile ahead)
   if (t0 < t1) {
-    u32x4 xc[NQ], xn[NQ];
+    u32x4 xc[G][NQ], xn[G][NQ];
     stage_issue(t0, 0);
     load_x(t0, xc);
     stage_commit(0);
@@ -360,7 +388,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) xc[q] = xn[q];
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xc[g][q] = xn[g][q];
     }
   }
 
@@ -375,31 +405,34 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE>::MINW)) 
     if (tid == 0) a.loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   } else {
     // accumulator register e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column 32*rt + j
-    const size_t slab = ((size_t)ks * a.M_pad + (size_t)mb * kBM + wave * 32) * R_PAD;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int g = 0; g < G; ++g) {
+      const size_t slab = ((size_t)ks * a.M_pad + (size_t)mb * BM + wave * (32 * G) + 32 * g) * R_PAD;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * hl;
-        const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
-        a.slab_num[idx] = on[rt][e];
-        if constexpr (C::TWO_ACC) a.slab_den[idx] = op[rt][e];
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * hl;
+          const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
+          a.slab_num[idx] = on[g][rt][e];
+          if constexpr (C::TWO_ACC) a.slab_den[idx] = op[g][rt][e];
+        }
       }
     }
   }
 }
 
 // Host-side launcher, one per (R_PAD) translation unit.
-int launch_fused_r32(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s);
-int launch_fused_r64(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s);
-int launch_fused_r128(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s);
-int launch_fused_r256(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s);
+int launch_fused_r32(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
+int launch_fused_r64(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
+int launch_fused_r128(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
+int launch_fused_r256(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
 
-template <int R_PAD, int BETA, bool X3, int MODE, int STAGE>
+template <int R_PAD, int BETA, bool X3, int MODE, int STAGE, int G>
 int launch_one(const FusedArgs& a, int grid, hipStream_t s) {
-  using C = FusedCfg<R_PAD, BETA, X3, MODE>;
+  using C = FusedCfg<R_PAD, BETA, X3, MODE, G>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
-  auto kern = fused_kernel<R_PAD, BETA, X3, MODE, STAGE>;
+  auto kern = fused_kernel<R_PAD, BETA, X3, MODE, STAGE, G>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -411,10 +444,23 @@ int launch_one(const FusedArgs& a, int grid, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// Which (beta, precision, mode) combinations get the 256-row (G = 2) tile: only those whose accumulators fit the
+// 512-register file without spilling -- beta == 1 numerators and the loss, bf16 operands, padded rank <= 128.
+constexpr bool has_g2(int r_pad, int beta, bool x3, int mode) {
+  return !x3 && r_pad <= 128 && (beta == kKL || mode == kModeLoss);
+}
+
 template <int R_PAD, bool ALLOW_X3>
-int launch_fused_dispatch(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s) {
-#define NMFMU_CASE(B, X, M, S) \
-  if (beta_kind == B && x3 == (X ? 1 : 0) && mode == M && stage == S) return launch_one<R_PAD, B, X, M, S>(a, grid, s);
+int launch_fused_dispatch(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid,
+                          hipStream_t s) {
+#define NMFMU_CASE(B, X, M, S)                                                                       \
+  if (beta_kind == B && x3 == (X ? 1 : 0) && mode == M && stage == S) {                              \
+    if (g == 1) return launch_one<R_PAD, B, X, M, S, 1>(a, grid, s);                                 \
+    if constexpr (has_g2(R_PAD, B, X, M)) {                                                          \
+      if (g == 2) return launch_one<R_PAD, B, X, M, S, 2>(a, grid, s);                               \
+    }                                                                                                \
+    return -2;                                                                                       \
+  }
 #define NMFMU_CASE_BETA(X, M, S) NMFMU_CASE(kKL, X, M, S) NMFMU_CASE(kEuc, X, M, S) NMFMU_CASE(kIS, X, M, S) NMFMU_CASE(kGen, X, M, S)
   NMFMU_CASE_BETA(false, kModeMU, 0)
   NMFMU_CASE_BETA(false, kModeMU, 1)

@@ -2,7 +2,7 @@
 #include "nmfmu_fused.h"
 
 namespace nmfmu {
-int launch_fused_r128(int beta_kind, int x3, int mode, int stage, const FusedArgs& a, int grid, hipStream_t s) {
-  return launch_fused_dispatch<128, true>(beta_kind, x3, mode, stage, a, grid, s);
+int launch_fused_r128(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s) {
+  return launch_fused_dispatch<128, true>(beta_kind, x3, mode, stage, g, a, grid, s);
 }
 }  // namespace nmfmu

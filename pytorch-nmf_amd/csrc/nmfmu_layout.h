@@ -18,8 +18,9 @@
 //      reads 1 KiB of consecutive bytes and lands directly in the lane that
 //      holds the matching MFMA accumulator element (no LDS trip for X).
 //
-//      chunk index = (((mb*ktiles + kt)*4 + w)*NQ + q)*64 + l      (16 B each)
-//      row   m = mb*128 + w*32 + (l & 31)
+//      With G = 1 or 2 thirty-two-row groups per wave (workgroup tile = 128*G rows):
+//      chunk index = ((((mb*ktiles + kt)*4 + w)*G + g)*NQ + q)*64 + l      (16 B each)
+//      row   m = mb*128*G + w*32*G + g*32 + (l & 31)
 //      bf16: NQ = 4, element e (0..7) of chunk q is column  kt*64 + 32*(l>>5) + 8*q + e
 //      fp32: NQ = 8, element e (0..3) of chunk q is column  kt*64 + 32*(l>>5) + 4*q + e
 //
@@ -47,7 +48,8 @@
 
 namespace nmfmu {
 
-constexpr int kBM = 128;  // owner rows per workgroup (4 waves x 32)
+constexpr int kBM = 128;      // owner rows per workgroup for G = 1 (4 waves x 32); 256 for G = 2
+constexpr int kRowPad = 256;  // every factor's row count is padded to this (covers both tile heights and 64-row k tiles)
 constexpr int kBK = 64;   // contraction columns per tile
 constexpr int kWaves = 4;
 
@@ -81,10 +83,13 @@ NMFMU_HD int64_t p2_offset(int64_t row, int r, int r_pad) {
 }
 
 // element offset (in elements, not bytes) of X[m][k] inside Xp
-NMFMU_HD int64_t xp_index(int64_t m, int64_t k, int64_t ktiles, bool fp32) {
-  const int64_t mb = m >> 7;
-  const int w = (int)((m >> 5) & 3);
-  const int j = (int)(m & 31);
+NMFMU_HD int64_t xp_index(int64_t m, int64_t k, int64_t ktiles, bool fp32, int G) {
+  const int bm = 128 * G;
+  const int64_t mb = m / bm;
+  const int ml = (int)(m % bm);
+  const int w = ml / (32 * G);
+  const int g = (ml / 32) % G;
+  const int j = ml & 31;
   const int64_t kt = k >> 6;
   const int kl = (int)(k & 63);
   const int hl = kl >> 5;
@@ -94,10 +99,10 @@ NMFMU_HD int64_t xp_index(int64_t m, int64_t k, int64_t ktiles, bool fp32) {
   const int q = kk / epc;
   const int e = kk % epc;
   const int lane = hl * 32 + j;
-  return ((((mb * ktiles + kt) * 4 + w) * nq + q) * 64 + lane) * epc + e;
+  return (((((mb * ktiles + kt) * 4 + w) * G + g) * nq + q) * 64 + lane) * epc + e;
 }
 
-NMFMU_HD int pad_rows(int rows) { return (rows + kBM - 1) / kBM * kBM; }
+NMFMU_HD int pad_rows(int rows) { return (rows + kRowPad - 1) / kRowPad * kRowPad; }
 
 NMFMU_HD int pad_rank(int r) {
   if (r <= 0) return -1;

@@ -38,7 +38,7 @@ class Step(C.Structure):
     """struct nmfmu_step"""
     _fields_ = [('xp', C.c_void_p), ('owner', Factor), ('panel', Factor), ('slab_num', C.c_void_p),
                 ('slab_den', C.c_void_p), ('rank', C.c_int32), ('r_pad', C.c_int32), ('nsplit', C.c_int32),
-                ('precision', C.c_int32), ('stage', C.c_int32), ('beta', C.c_float), ('gamma', C.c_float),
+                ('precision', C.c_int32), ('stage', C.c_int32), ('block_rows', C.c_int32), ('beta', C.c_float), ('gamma', C.c_float),
                 ('l1', C.c_float), ('l2', C.c_float)]
 
 
@@ -49,13 +49,14 @@ SIGNATURES = {
     'nmfmu_pad_rank': (C.c_int, [C.c_int]),
     'nmfmu_beta_kind': (C.c_int, [C.c_float]),
     'nmfmu_supported': (C.c_int, [C.c_int, C.c_int]),
-    'nmfmu_choose_nsplit': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_block_rows': (C.c_int, [C.c_int, C.c_int, C.c_float]),
+    'nmfmu_choose_nsplit': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_xp_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_image_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'nmfmu_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_colsum_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
-    'nmfmu_pack_x': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                               C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_pack_x': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_pack_factor': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -47,9 +47,12 @@ class HipBackend:
     def supported(self, r_pad: int, precision: int) -> bool:
         return bool(self.lib.nmfmu_supported(r_pad, precision))
 
-    def choose_nsplit(self, m_pad: int, k_pad: int, device) -> int:
+    def block_rows(self, r_pad: int, precision: int, beta: float) -> int:
+        return self.lib.nmfmu_block_rows(r_pad, precision, beta)
+
+    def choose_nsplit(self, m_pad: int, k_pad: int, block_rows: int, device) -> int:
         ncu = torch.cuda.get_device_properties(device).multi_processor_count
-        return self.lib.nmfmu_choose_nsplit(m_pad, k_pad, ncu)
+        return self.lib.nmfmu_choose_nsplit(m_pad, k_pad, block_rows, ncu)
 
     @staticmethod
     def stream() -> int:
@@ -59,10 +62,11 @@ class HipBackend:
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
     # -- device work
-    def pack_x(self, V, transpose, precision, m_pad, k_pad, flags):
+    def pack_x(self, V, transpose, precision, block_rows, m_pad, k_pad, flags):
         xp = self.alloc(self.lib.nmfmu_xp_bytes(m_pad, k_pad, precision), V.device)
         _capi.check(self.lib.nmfmu_pack_x(V.data_ptr(), V.stride(0), V.shape[0], V.shape[1], int(transpose), precision,
-                                          xp.data_ptr(), m_pad, k_pad, _ptr(flags), self.stream()), 'nmfmu_pack_x')
+                                          block_rows, xp.data_ptr(), m_pad, k_pad, _ptr(flags), self.stream()),
+                    'nmfmu_pack_x')
         return xp
 
     def pack_factor(self, fac: 'FactorBuf', rank, r_pad, precision):
@@ -136,7 +140,7 @@ class FactorBuf:
         self.p1_lo = backend.alloc(nimg, dev) if x3 else None
         self.p2_lo = backend.alloc(nimg, dev) if x3 else None
         self.colsum = torch.zeros(r_pad, dtype=torch.float32, device=dev)
-        self.colsum_part = torch.zeros((self.rows_pad // 64) * r_pad, dtype=torch.float32, device=dev)
+        self.colsum_part = torch.zeros((self.rows_pad // 16) * r_pad, dtype=torch.float32, device=dev)
         self.struct = _capi.Factor(_ptr(self.f), _ptr(self.p1_hi), _ptr(self.p1_lo), _ptr(self.p2_hi),
                                    _ptr(self.p2_lo), _ptr(self.colsum), _ptr(self.colsum_part), self.rows,
                                    self.rows_pad)
@@ -145,16 +149,16 @@ class FactorBuf:
 class StepBuf:
     """One half-step: X in fragment order, owner/panel factors, partial-sum slabs."""
 
-    def __init__(self, xp, owner: FactorBuf, panel: FactorBuf, rank, r_pad, nsplit, precision, stage, beta, gamma, l1,
-                 l2, need_den: bool):
+    def __init__(self, xp, owner: FactorBuf, panel: FactorBuf, rank, r_pad, nsplit, precision, stage, block_rows, beta,
+                 gamma, l1, l2, need_den: bool):
         self.xp, self.owner, self.panel = xp, owner, panel
-        self.nsplit, self.r_pad = nsplit, r_pad
+        self.nsplit, self.r_pad, self.block_rows = nsplit, r_pad, block_rows
         dev = owner.f.device
         self.plane = owner.rows_pad * r_pad
         self.slab_num = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev)
         self.slab_den = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev) if need_den else None
         self.struct = _capi.Step(_ptr(xp), owner.struct, panel.struct, _ptr(self.slab_num), _ptr(self.slab_den), rank,
-                                 r_pad, nsplit, precision, stage, beta, gamma, l1, l2)
+                                 r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2)
 
 
 def mu_gamma(beta: float) -> float:
@@ -174,7 +178,7 @@ class DenseMU:
     """
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
-                 update_W=True, update_H=True):
+                 update_W=True, update_H=True, block_rows=None):
         self.be = backend if backend is not None else HipBackend()
         self.group = group
         self.beta = float(beta)
@@ -202,20 +206,22 @@ class DenseMU:
         # validation flags of nmf.py:329-336: [any(!(v >= 0)), min bit pattern]
         self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
         n_pad, c_pad = self.fH.rows_pad, self.fW.rows_pad
+        br = self.be.block_rows(self.r_pad, self.precision, self.beta) if block_rows is None else block_rows
+        self.block_rows = br
         # H half-step and loss: owner axis N, contraction over C
-        xp_h = self.be.pack_x(V, False, self.precision, n_pad, c_pad, self.flags)
-        ns_h = self.be.choose_nsplit(n_pad, c_pad, dev)
-        self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, self.beta, gamma, l1,
-                              l2, need_den=not self.kl)
+        xp_h = self.be.pack_x(V, False, self.precision, br, n_pad, c_pad, self.flags)
+        ns_h = self.be.choose_nsplit(n_pad, c_pad, br, dev)
+        self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, br, self.beta, gamma,
+                              l1, l2, need_den=not self.kl)
         self.step_w = None
         if update_W:
-            xp_w = self.be.pack_x(V, True, self.precision, c_pad, n_pad, None)
-            ns_w = self.be.choose_nsplit(c_pad, n_pad, dev)
-            self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, self.beta, gamma,
-                                  l1, l2, need_den=not self.kl)
+            xp_w = self.be.pack_x(V, True, self.precision, br, c_pad, n_pad, None)
+            ns_w = self.be.choose_nsplit(c_pad, n_pad, br, dev)
+            self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, br, self.beta,
+                                  gamma, l1, l2, need_den=not self.kl)
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
         self.refresh_images()
-        self.loss_part = torch.empty(max((n_pad // 128) * ns_h, 1), dtype=torch.float32, device=dev)
+        self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
         if group is not None:
             # [numerator | denominator (N x R for beta != 1, else R column sums)] -> ONE all-reduce per iteration

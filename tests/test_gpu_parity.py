@@ -70,7 +70,8 @@ def test_probe_lds_dma_is_lane_linear(dev):
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('prec', ['bf16', 'bf16x3'])
 @pytest.mark.parametrize('transpose', [False, True])
-def test_pack_x_layout_and_flags(dev, prec, transpose):
+@pytest.mark.parametrize('block_rows', [128, 256])
+def test_pack_x_layout_and_flags(dev, prec, transpose, block_rows):
     from test_layout_emulation import xp_index
     from torchnmf_amd import _capi
     from torchnmf_amd.engine import HipBackend
@@ -81,14 +82,14 @@ def test_pack_x_layout_and_flags(dev, prec, transpose):
     M, K = (200, 150) if transpose else (150, 200)
     m_pad, k_pad = be.pad_rows(M), be.pad_rows(K)
     flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
-    xp = be.pack_x(V.to(dev), transpose, _capi.PRECISIONS[prec], m_pad, k_pad, flags)
+    xp = be.pack_x(V.to(dev), transpose, _capi.PRECISIONS[prec], block_rows, m_pad, k_pad, flags)
     torch.cuda.synchronize()
     fp32 = prec == 'bf16x3'
     got = (xp.view(torch.float32) if fp32 else xp.view(torch.bfloat16).float()).cpu().numpy()
     X = (V.t() if transpose else V).numpy()
     want = np.zeros(m_pad * k_pad, dtype=np.float32)
     mm, kk = np.meshgrid(np.arange(M), np.arange(K), indexing='ij')
-    idx = np.vectorize(lambda a, b: xp_index(int(a), int(b), k_pad // 64, fp32))(mm, kk)
+    idx = np.vectorize(lambda a, b: xp_index(int(a), int(b), k_pad // 64, fp32, block_rows // 128))(mm, kk)
     want[idx.reshape(-1)] = X.reshape(-1)
     np.testing.assert_array_equal(got, want)
     assert flags.tolist() == [0, 0]
@@ -97,7 +98,7 @@ def test_pack_x_layout_and_flags(dev, prec, transpose):
         V2 = V.clone()
         V2[5, 5] = badval
         flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
-        be.pack_x(V2.to(dev), transpose, _capi.PRECISIONS[prec], m_pad, k_pad, flags)
+        be.pack_x(V2.to(dev), transpose, _capi.PRECISIONS[prec], block_rows, m_pad, k_pad, flags)
         assert flags.tolist()[0] == 1
 
 
@@ -138,11 +139,12 @@ def test_pack_factor_images(dev, rank):
 # ----------------------------------------------------------------------------------------------------------
 # single half-steps against the oracle (every beta branch, both precisions, both staging modes)
 # ----------------------------------------------------------------------------------------------------------
-def _one_iter(dev, V, W0, H0, beta, prec, stage, alpha=0.0, l1r=0.0):
+def _one_iter(dev, V, W0, H0, beta, prec, stage, alpha=0.0, l1r=0.0, block_rows=None):
     from torchnmf_amd.engine import DenseMU
     W = W0.clone().to(dev).contiguous()
     H = H0.clone().to(dev).contiguous()
-    eng = DenseMU(V.to(dev), W, H, beta, alpha * l1r, alpha * (1 - l1r), precision=prec, stage=stage)
+    eng = DenseMU(V.to(dev), W, H, beta, alpha * l1r, alpha * (1 - l1r), precision=prec, stage=stage,
+                  block_rows=block_rows)
     loss0 = eng.divergence()
     eng.w_step()
     torch.cuda.synchronize()
@@ -174,14 +176,15 @@ def test_half_steps_bf16x3(dev, beta, stage):
 
 @pytest.mark.parametrize('beta', [1, 2, 0.5])
 @pytest.mark.parametrize('stage', [0, 1])
-def test_half_steps_bf16(dev, beta, stage):
+@pytest.mark.parametrize('block_rows', [128, None])   # None = the engine's choice (256-row tiles for beta == 1)
+def test_half_steps_bf16(dev, beta, stage, block_rows):
     from oracle import mu_oracle as O
     g = torch.Generator().manual_seed(12)
     N, C, R = 384, 1100, 64
     V = torch.rand(N, C, generator=g).bfloat16().float()
     W0 = torch.randn(C, R, generator=g).abs()
     H0 = torch.randn(N, R, generator=g).abs()
-    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, beta, 'bf16', stage)
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, beta, 'bf16', stage, block_rows=block_rows)
     gam = O.gamma_of(beta)
     Wr = O.nmf_w_step(V, W0, H0, beta, gam)
     Hr = O.nmf_h_step(V, Wr, H0, beta, gam)

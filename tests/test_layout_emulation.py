@@ -32,14 +32,16 @@ def p2_offset(row, r, r_pad):  # in bf16 elements
     return kt * r_pad * 64 + r * 64 + ((slot ^ ((r >> 1) & 7)) << 3) + (kl & 7)
 
 
-def xp_index(m, k, ktiles, fp32):
-    mb, w, j = m >> 7, (m >> 5) & 3, m & 31
+def xp_index(m, k, ktiles, fp32, G=1):
+    bm = 128 * G
+    mb, ml = m // bm, m % bm
+    w, g, j = ml // (32 * G), (ml // 32) % G, ml & 31
     kt, kl = k >> 6, k & 63
     hl, kk = kl >> 5, kl & 31
     nq, epc = (8, 4) if fp32 else (4, 8)
     q, e = kk // epc, kk % epc
     lane = hl * 32 + j
-    return ((((mb * ktiles + kt) * 4 + w) * nq + q) * 64 + lane) * epc + e
+    return (((((mb * ktiles + kt) * 4 + w) * G + g) * nq + q) * 64 + lane) * epc + e
 
 
 # ---- the MFMA as documented (cdna_hip_programming.md section 3) ---------------------------------------------
@@ -166,9 +168,10 @@ def test_image_layouts_are_bijections(r_pad):
 
 
 @pytest.mark.parametrize('fp32', [False, True])
-def test_xp_layout_is_a_bijection(fp32):
-    M, K = 256, 192
-    idx = {xp_index(m, k, K // 64, fp32) for m in range(M) for k in range(K)}
+@pytest.mark.parametrize('G', [1, 2])
+def test_xp_layout_is_a_bijection(fp32, G):
+    M, K = 512, 192
+    idx = {xp_index(m, k, K // 64, fp32, G) for m in range(M) for k in range(K)}
     assert idx == set(range(M * K))
 
 
