@@ -88,9 +88,11 @@ int nmfmu_supported(int r_pad, int precision) {
 }
 
 int nmfmu_block_rows(int r_pad, int precision, float beta) {
-  // 256-row tiles (two 32-row groups per wave, one wave per SIMD with the whole register file) where the
-  // accumulators fit: bf16 operands, beta == 1, padded rank <= 128.  Everything else uses 128-row tiles.
-  return has_g2(r_pad, nmfmu_beta_kind(beta), precision == NMFMU_PREC_BF16X3, kModeMU) ? 256 : 128;
+  // 128-row tiles (two workgroups per CU, two waves per SIMD) measure faster than the 256-row variant (one wave per
+  // SIMD, every LDS operand read shared by two MFMAs) on MI355X today: 0.154 vs 0.179 ms per half-step at
+  // 4096x65536 r128.  The 256-row kernels stay built and selectable (block_rows = 256) where has_g2() holds.
+  (void)r_pad, (void)precision, (void)beta;
+  return 128;
 }
 
 int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu) {

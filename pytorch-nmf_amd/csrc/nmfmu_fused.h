@@ -35,6 +35,16 @@
 
 #include "nmfmu_layout.h"
 
+#ifndef NMFMU_PIN_SCHED
+#define NMFMU_PIN_SCHED 1
+#endif
+#ifndef NMFMU_ORDER
+#define NMFMU_ORDER 1   // 1: interleave accumulators in both GEMMs
+#endif
+#ifndef NMFMU_ABLATE
+#define NMFMU_ABLATE 0  // timing experiments only (results are WRONG when non-zero): 1 no elementwise, 2 no barrier/DMA
+#endif                  // after the first tile, 3 no X loads after the first tile, 4 no GEMM1, 5 no GEMM2
+
 namespace nmfmu {
 
 constexpr float kEps = 1.1920928955078125e-07f;  // constants.py:3 of the reference
@@ -262,29 +272,59 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 
   auto compute = [&](int t, int buf, const u32x4(&x)[G][NQ]) {
     const char* sb = smem + buf * C::STAGE_BYTES;
-    // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank
+    // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank.
+    // The panel operands are fetched through a PF-deep register ring so that PF-1 ds_read_b128 are always in
+    // flight behind the MFMA that is issuing (hipcc otherwise emits read -> lgkmcnt(0) -> mfma, one at a time).
     f32x16 s[G][2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[g][tt][e] = (BETA == kEuc) ? 0.f : kEps;
+    {
+      constexpr int NSTEP = 2 * KS;
+      constexpr int PF = NSTEP < 4 ? NSTEP : 4;
+      u32x4 ring_h[PF];
+      u32x4 ring_l[X3 ? PF : 1];
+      // step -> (kk, tt): the two S^T tiles alternate, so consecutive MFMAs never share an accumulator
+      auto a_off = [&](int step) {
+        const int tt = NMFMU_ORDER ? (step & 1) : step / KS, kk = NMFMU_ORDER ? (step >> 1) : step % KS;
+        return a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
+      };
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const int off = a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
-        const u32x4 ah = ld16(sb + C::P1HI + off);
-        if constexpr (X3) {
-          const u32x4 al = ld16(sb + C::P1LO + off);
+      for (int p = 0; p < PF; ++p) {
+        ring_h[p] = ld16(sb + C::P1HI + a_off(p));
+        if constexpr (X3) ring_l[p] = ld16(sb + C::P1LO + a_off(p));
+      }
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
+      for (int step = 0; step < (NMFMU_ABLATE == 4 ? 2 : NSTEP); ++step) {
+        const int tt = NMFMU_ORDER ? (step & 1) : step / KS, kk = NMFMU_ORDER ? (step >> 1) : step % KS;
+        const u32x4 ah = ring_h[step % PF];
+        u32x4 al;
+        if constexpr (X3) al = ring_l[step % PF];
+        if (step + PF < NSTEP) {
+          ring_h[step % PF] = ld16(sb + C::P1HI + a_off(step + PF));
+          if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P1LO + a_off(step + PF));
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if constexpr (X3) {
             s[g][tt] = mfma_bf16(al, qh[g][kk], s[g][tt]);
             s[g][tt] = mfma_bf16(ah, ql[g][kk], s[g][tt]);
           }
+          s[g][tt] = mfma_bf16(ah, qh[g][kk], s[g][tt]);
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) s[g][tt] = mfma_bf16(ah, qh[g][kk], s[g][tt]);
       }
+#if NMFMU_PIN_SCHED
+      // pin the software pipeline: PF reads up front, then one read behind every MFMA group
+      __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 0);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        __builtin_amdgcn_sched_group_barrier(0x008, G * (X3 ? 3 : 1), 0);
+        if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
+      }
+#endif
     }
     // ---------------- elementwise: Gn / Gp (or the loss terms), packed to bf16 A operands
     uint32_t gnh[G][2][8], gnl[G][X3 ? 2 : 1][8], gph[G][C::TWO_ACC ? 2 : 1][8], gpl[G][(C::TWO_ACC && X3) ? 2 : 1][8];
@@ -315,6 +355,11 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
             lacc += (rowok && k0 + 1 < a.K) ? loss_elem<BETA>(s1, x1, a.beta) : 0.f;
           } else {
             float n0, n1, p0, p1;
+#if NMFMU_ABLATE == 1
+            n0 = s0, n1 = s1, p0 = x0, p1 = x1;
+            gnh[g][tt][d] = __builtin_bit_cast(uint32_t, s0) ^ x[g][0][d & 3];
+            continue;
+#endif
             mu_elem<BETA>(s0, x0, a.beta, n0, p0);
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
             const uint32_t nh = pack_bf16(n0, n1);
@@ -331,42 +376,65 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     }
     // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
     if constexpr (!C::LOSS) {
+      constexpr int NSTEP = RT * 4;
+      constexpr int PF = 4;
+      u32x4 ring_h[PF];
+      u32x4 ring_l[X3 ? PF : 1];
+      // step -> ((tt, m2), rt): rank tiles innermost, so consecutive MFMAs cycle through the RT accumulators
+      auto b_offs = [&](int step) {
+        const int rt = NMFMU_ORDER ? step % RT : step >> 2;
+        const int c = NMFMU_ORDER ? step / RT : step & 3;
+        return rt * 4096 + b_row + b_off[c >> 1][c & 1];
+      };
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
+      for (int p = 0; p < PF; ++p) {
+        ring_h[p] = ld16(sb + C::P2HI + b_offs(p));
+        if constexpr (X3) ring_l[p] = ld16(sb + C::P2LO + b_offs(p));
+      }
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+      for (int step = 0; step < (NMFMU_ABLATE == 5 ? RT : NSTEP); ++step) {
+        const int rt = NMFMU_ORDER ? step % RT : step >> 2;
+        const int c = NMFMU_ORDER ? step / RT : step & 3;
+        const int tt = c >> 1, m2 = c & 1;
+        const u32x4 bh = ring_h[step % PF];
+        u32x4 bl;
+        if constexpr (X3) bl = ring_l[step % PF];
+        if (step + PF < NSTEP) {
+          ring_h[step % PF] = ld16(sb + C::P2HI + b_offs(step + PF));
+          if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P2LO + b_offs(step + PF));
+        }
 #pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2) {
-            const int off = rt * 4096 + b_row + b_off[tt][m2];
-            const u32x4 bh = ld16(sb + C::P2HI + off);
-            u32x4 bl;
-            if constexpr (X3) bl = ld16(sb + C::P2LO + off);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              const u32x4 nh = {gnh[g][tt][4 * m2], gnh[g][tt][4 * m2 + 1], gnh[g][tt][4 * m2 + 2],
-                                gnh[g][tt][4 * m2 + 3]};
-              if constexpr (X3) {
-                const u32x4 nl = {gnl[g][tt][4 * m2], gnl[g][tt][4 * m2 + 1], gnl[g][tt][4 * m2 + 2],
-                                  gnl[g][tt][4 * m2 + 3]};
-                on[g][rt] = mfma_bf16(nl, bh, on[g][rt]);
-                on[g][rt] = mfma_bf16(nh, bl, on[g][rt]);
-              }
-              on[g][rt] = mfma_bf16(nh, bh, on[g][rt]);
-              if constexpr (C::TWO_ACC) {
-                const u32x4 ph = {gph[g][tt][4 * m2], gph[g][tt][4 * m2 + 1], gph[g][tt][4 * m2 + 2],
-                                  gph[g][tt][4 * m2 + 3]};
-                if constexpr (X3) {
-                  const u32x4 pl = {gpl[g][tt][4 * m2], gpl[g][tt][4 * m2 + 1], gpl[g][tt][4 * m2 + 2],
-                                    gpl[g][tt][4 * m2 + 3]};
-                  op[g][rt] = mfma_bf16(pl, bh, op[g][rt]);
-                  op[g][rt] = mfma_bf16(ph, bl, op[g][rt]);
-                }
-                op[g][rt] = mfma_bf16(ph, bh, op[g][rt]);
-              }
+        for (int g = 0; g < G; ++g) {
+          const u32x4 nh = {gnh[g][tt][4 * m2], gnh[g][tt][4 * m2 + 1], gnh[g][tt][4 * m2 + 2],
+                            gnh[g][tt][4 * m2 + 3]};
+          if constexpr (X3) {
+            const u32x4 nl = {gnl[g][tt][4 * m2], gnl[g][tt][4 * m2 + 1], gnl[g][tt][4 * m2 + 2],
+                              gnl[g][tt][4 * m2 + 3]};
+            on[g][rt] = mfma_bf16(nl, bh, on[g][rt]);
+            on[g][rt] = mfma_bf16(nh, bl, on[g][rt]);
+          }
+          on[g][rt] = mfma_bf16(nh, bh, on[g][rt]);
+          if constexpr (C::TWO_ACC) {
+            const u32x4 ph = {gph[g][tt][4 * m2], gph[g][tt][4 * m2 + 1], gph[g][tt][4 * m2 + 2],
+                              gph[g][tt][4 * m2 + 3]};
+            if constexpr (X3) {
+              const u32x4 pl = {gpl[g][tt][4 * m2], gpl[g][tt][4 * m2 + 1], gpl[g][tt][4 * m2 + 2],
+                                gpl[g][tt][4 * m2 + 3]};
+              op[g][rt] = mfma_bf16(pl, bh, op[g][rt]);
+              op[g][rt] = mfma_bf16(ph, bl, op[g][rt]);
             }
+            op[g][rt] = mfma_bf16(ph, bh, op[g][rt]);
           }
         }
       }
+#if NMFMU_PIN_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        __builtin_amdgcn_sched_group_barrier(0x008, G * (X3 ? 3 : 1) * (C::TWO_ACC ? 2 : 1), 1);
+        if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
+      }
+#endif
     }
   };
 
@@ -380,6 +448,16 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     for (int t = t0; t < t1; ++t) {
       const int buf = (t - t0) & 1;
       const bool more = t + 1 < t1;
+#if NMFMU_ABLATE == 2
+      if (more) load_x(t + 1, xn);
+      compute(t, 0, xc);
+#elif NMFMU_ABLATE == 3
+      if (more) stage_issue(t + 1, buf ^ 1);
+      compute(t, buf, xc);
+      if (more) stage_commit(buf ^ 1);
+      __syncthreads();
+      continue;
+#else
       if (more) {
         stage_issue(t + 1, buf ^ 1);
         load_x(t + 1, xn);
@@ -387,6 +465,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       compute(t, buf, xc);
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
+#endif
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll

@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 LIB_NAME = 'libnmfmu.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.environ.get('NMFMU_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# (NMFMU_LIB: experiment hook for kernel-variant builds, e.g. `make VARIANT=_x EXTRA=-DNMFMU_ORDER=0`)
 
 OK = 0
 ERR_UNSUPPORTED = -2
