@@ -161,6 +161,11 @@ class StepBuf:
                                  r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2)
 
 
+# Factory of the compute backend.  It is HipBackend in the product; the CPU test-suite swaps in an oracle-backed
+# stand-in (tests/cpu_backend.py) to exercise the host logic (sharding, all-reduce packing, fit loop) without a GPU.
+DEFAULT_BACKEND_FACTORY = HipBackend
+
+
 def mu_gamma(beta: float) -> float:
     """MU exponent of nmf.py:341-346."""
     if beta < 1:
@@ -179,7 +184,7 @@ class DenseMU:
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
                  update_W=True, update_H=True, block_rows=None):
-        self.be = backend if backend is not None else HipBackend()
+        self.be = backend if backend is not None else DEFAULT_BACKEND_FACTORY()
         self.group = group
         self.beta = float(beta)
         self.kl = self.beta == 1.0

@@ -1,0 +1,80 @@
+"""world_size-2 CPU tests (gloo) of the column-sharded MU path.
+
+Each rank owns V[:, Cg] and W[Cg]; H is replicated.  The W half-step is local, the H half-step all-reduces ONE
+packed buffer [numerator | denominator]; validation flags and the loss are all-reduced too.  Compute is done by
+the oracle-backed stand-in backend (tests/cpu_backend.py); what is under test is torchnmf_amd's host logic,
+which is the same code that runs over RCCL on the GPUs.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, rel_err
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, beta, alpha, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cpu_backend import OracleBackend
+        from oracle import mu_oracle as O
+        from torchnmf_amd import engine
+        from torchnmf_amd import nmf as anmf
+        from torchnmf_amd.nmf import NMF
+        engine.DEFAULT_BACKEND_FACTORY = OracleBackend
+        anmf._require_device = lambda t_, what: None
+        torch.set_num_threads(1)
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g1_nmf_small.npz'))
+        V = torch.from_numpy(g['V']) + (1e-3 if beta <= 0 else 0.0)
+        W0, H0 = torch.from_numpy(g['W0']), torch.from_numpy(g['H0'])
+        s, e = O.shard_bounds(V.shape[1], world)[rank]
+        m = NMF(W=W0[s:e].clone(), H=H0.clone())
+        n = m.fit(V[:, s:e].contiguous(), beta, 1e-4, 60, alpha=alpha, l1_ratio=0.5, process_group=dist.group.WORLD)
+        torch.save({'W': m.W.data, 'H': m.H.data, 'n': n, 's': s, 'e': e}, os.path.join(out_dir, f'r{rank}.pt'))
+        # negative entries on ONE rank must fail the assertion on EVERY rank (flags are all-reduced)
+        Vbad = V[:, s:e].clone()
+        if rank == 1:
+            Vbad[0, 0] = -1.0
+        try:
+            NMF(W=W0[s:e].clone(), H=H0.clone()).fit(Vbad, beta, 1e-4, 2, process_group=dist.group.WORLD)
+            raised = False
+        except AssertionError:
+            raised = True
+        torch.save(raised, os.path.join(out_dir, f'bad{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('beta,alpha', [(1, 0.0), (2, 0.1), (0.5, 0.0)])
+def test_column_sharded_fit_world2(tmp_path, beta, alpha):
+    from oracle import mu_oracle as O
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), beta, alpha, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    g = load_golden('g1_nmf_small')
+    V = torch.from_numpy(g['V'])
+    W0, H0 = torch.from_numpy(g['W0']), torch.from_numpy(g['H0'])
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 60, alpha, 0.5)
+    assert all(p['n'] == nr for p in parts)                      # same stop decision on every rank
+    W = torch.cat([p['W'] for p in parts])
+    assert rel_err(W, Wr) < 1e-5
+    for p in parts:                                              # H identical (replicated) and right
+        assert rel_err(p['H'], Hr) < 1e-5
+    assert torch.equal(parts[0]['H'], parts[1]['H'])
+    assert all(torch.load(tmp_path / f'bad{r}.pt') for r in range(world))

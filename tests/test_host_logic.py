@@ -1,0 +1,164 @@
+"""CPU tests of the host side: module surface (mirrors the reference's tests/test_nmf.py constructor tests),
+error behaviour, the fit() driver semantics (with the oracle-backed stand-in backend), and the C ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, rel_err
+from torchnmf_amd import _capi, engine
+from torchnmf_amd import nmf as anmf
+from torchnmf_amd.nmf import NMF, NMFD, BaseComponent
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+# ---- constructors: reference tests/test_nmf.py:8-66 -----------------------------------------------------
+@pytest.mark.parametrize('W', [(50, 8), torch.rand(50, 8), None])
+@pytest.mark.parametrize('H', [(100, 8), torch.rand(100, 8), None])
+def test_base_valid_construct(W, H):
+    m = BaseComponent(8, W, H)
+    assert (m.H is None) == (H is None) and (m.W is None) == (W is None)
+    assert m.rank == 8
+
+
+@pytest.mark.parametrize('rank, W, H', [
+    (None, None, None),
+    (None, (50, 8), (100, 10)),
+    (None, torch.rand(50, 8), (100, 10)),
+    (None, torch.randn(50, 8), (100, 8)),
+    (None, (50, 8), torch.rand(100, 10)),
+    (None, (50, 8), torch.randn(100, 8)),
+    (None, torch.rand(50, 8), torch.rand(100, 10)),
+    (None, torch.randn(50, 8), torch.rand(100, 8)),
+    (None, torch.rand(50, 8), torch.randn(100, 8)),
+])
+def test_base_invalid_construct(rank, W, H):
+    with pytest.raises(AssertionError):
+        BaseComponent(rank, W, H)
+
+
+def test_nmf_shapes_and_attributes():
+    m = NMF((100, 50))
+    assert m.W.shape == (50, 50) and m.H.shape == (100, 50) and m.rank == 50 and m.out_channels == 50
+    m = NMF((20, 30), 5)
+    assert m.W.shape == (30, 5) and m.H.shape == (20, 5)
+    assert bool(torch.all(m.W >= 0)) and bool(torch.all(m.H >= 0))
+    assert 'out_channels=30' in repr(m)
+    for bad in [(100, 50, 50), (100,)]:
+        with pytest.raises(Exception):
+            NMF(bad)
+
+
+def test_nmfd_shapes_and_attributes():
+    m = NMFD((1, 33, 50), 16, 3)
+    assert m.W.shape == (33, 16, 3) and m.H.shape == (1, 16, 48) and m.kernel_size == (3,)
+    assert 'kernel_size=(3,)' in repr(m)
+    for bad in [(100, 50), (100,), (100, 50) * 2]:
+        with pytest.raises(Exception):
+            NMFD(bad)
+
+
+def test_trainable_flags_and_state_dict_roundtrip():
+    W0, H0 = torch.rand(30, 4), torch.rand(20, 4)
+    m = NMF(W=W0, H=H0, trainable_W=False)
+    assert not m.W.requires_grad and m.H.requires_grad
+    assert torch.equal(m.W.data, W0) and m.W.data.data_ptr() != W0.data_ptr()
+    m2 = NMF((20, 30), 4)
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2.W.data, W0) and torch.equal(m2.H.data, H0)
+    assert [n for n, _ in m.named_parameters()] == ['W', 'H']
+
+
+def test_forward_needs_both_factors():
+    with pytest.raises(AssertionError):
+        BaseComponent(4, (10, 4), None)()
+
+
+def test_no_cpu_fallback():
+    """Compute entry points refuse CPU tensors instead of silently computing on the host."""
+    m = NMF((20, 30), 4)
+    with pytest.raises(RuntimeError):
+        m()
+    with pytest.raises(RuntimeError):
+        m.fit(torch.rand(20, 30))
+    from torchnmf_amd.metrics import beta_div
+    with pytest.raises(RuntimeError):
+        beta_div(torch.rand(5), torch.rand(5), 1)
+    with pytest.raises(RuntimeError):
+        engine.HipBackend()          # no ROCm device in this container
+    with pytest.raises(NotImplementedError):
+        m.fit(torch.rand(20, 30).to_sparse())
+    with pytest.raises(NotImplementedError):
+        m.sparse_fit(torch.rand(20, 30))
+
+
+# ---- the C ABI surface ------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'nmfmu.h')).read()
+    declared = set(re.findall(r'\b(nmfmu_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_static_queries():
+    lib = _capi.load()
+    assert lib.nmfmu_abi_version() == 1
+    assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
+    assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
+    assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED
+    assert [lib.nmfmu_beta_kind(b) for b in (1.0, 2.0, 0.0, 0.5, -1.0)] == [0, 1, 2, 3, 3]
+    assert lib.nmfmu_supported(128, _capi.PREC_BF16X3) == 1 and lib.nmfmu_supported(256, _capi.PREC_BF16X3) == 0
+    assert lib.nmfmu_choose_nsplit(4096, 65536, 128, 256) == 16      # 32 owner blocks x 16 chunks = 512 workgroups
+    assert lib.nmfmu_choose_nsplit(65536, 4096, 128, 256) == 1
+    assert lib.nmfmu_choose_nsplit(256, 256, 128, 256) == 1          # tiny problems are not split below 4 tiles
+    assert lib.nmfmu_xp_bytes(4096, 65536, _capi.PREC_BF16) == 4096 * 65536 * 2
+    assert lib.nmfmu_slab_bytes(4096, 128, 16) == 16 * 4096 * 128 * 4
+    # struct layouts agree with the header (sizeof via a known-good packing: 7 pointers + 2 int32)
+    assert ctypes.sizeof(_capi.Factor) == 64 and ctypes.sizeof(_capi.Step) == 8 + 64 * 2 + 16 + 4 * 6 + 4 * 4
+
+
+# ---- fit() driver semantics on the stand-in backend -------------------------------------------------------
+@pytest.fixture
+def cpu_engine(monkeypatch):
+    from cpu_backend import OracleBackend
+    monkeypatch.setattr(engine, 'DEFAULT_BACKEND_FACTORY', OracleBackend)
+    monkeypatch.setattr(anmf, '_require_device', lambda t_, what: None)
+
+
+@pytest.mark.parametrize('beta', [0.5, 1, 2])
+def test_fit_loop_early_stop_matches_reference(cpu_engine, beta):
+    g = load_golden('g3_early_stop')
+    m = NMF(W=t(g['W0']), H=t(g['H0']))
+    n = m.fit(t(g['V']), beta, 1e-4, 200)
+    assert n == int(g[f'b{beta}_n_iter'])
+    assert rel_err(m.W.data, g[f'b{beta}_W']) < 5e-6 and rel_err(m.H.data, g[f'b{beta}_H']) < 5e-6
+
+
+@pytest.mark.parametrize('name,tW,tH', [('frozenW', False, True), ('frozenH', True, False)])
+def test_fit_loop_respects_frozen_factors(cpu_engine, name, tW, tH):
+    g = load_golden('g4_frozen')
+    m = NMF(W=t(g['W0']), H=t(g['H0']), trainable_W=tW, trainable_H=tH)
+    m.fit(t(g['V']), 1, -1e9, 20)
+    assert rel_err(m.W.data, g[f'b1_{name}_W']) < 5e-6 and rel_err(m.H.data, g[f'b1_{name}_H']) < 5e-6
+
+
+def test_fit_loop_validation_and_verbose(cpu_engine, capsys):
+    m = NMF((20, 30), 4)
+    V = torch.rand(20, 30)
+    assert m.fit(V, 1, 0, 30, verbose=True) <= 30
+    V[0, 0] = 0
+    with pytest.raises(ValueError):
+        m.fit(V, beta=0)
+    V[0, 0] = -1
+    with pytest.raises(AssertionError):
+        m.fit(V)
+    with pytest.raises(ValueError):
+        m.fit(torch.rand(20, 30), precision='fp64')
