@@ -146,6 +146,62 @@ int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double
 int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int rank, float* out, int64_t ld,
                       void* stream);
 
+
+/* ---- convolutive NMF (NMFD, nmf.py:700-779) --------------------------------------------------------------------
+ * NMFD is dense NMF on unfolded operands with effective rank R*T: with W (C,R,T) viewed as Wm (C x R*T) and
+ * Hu[(b,l)][(r,t)] = H[b][r][l-t], the reconstruction F.conv1d(H, W.flip(2), padding=T-1) (nmf.py:776-779) is
+ * Wm Hu^T and both conv-backward passes (nmf.py:77, 82) are GEMMs too.  The entry points below are the pieces
+ * NMFD.fit is assembled from (torchnmf_amd/nmfd_engine.py shows the order).  All matrices are zero padded to
+ * multiples of 128 in every dimension; bf16 operands are (hi[, lo]) planes with the contraction index contiguous.
+ */
+#define NMFMU_EPI_RATIO 0 /* D = A B^T (+eps); Gn = f(D, x) [and Gp, beta != 1] stored as bf16 planes (nmf.py:61-74)   */
+#define NMFMU_EPI_F32 1   /* D stored as fp32                                                                         */
+#define NMFMU_EPI_LOSS 2  /* beta_div(D, x) partial per workgroup into out[(m_pad/128) * (n_pad/128)] (metrics.py)    */
+
+typedef struct nmfmu_gemm_desc {
+  const void* a_hi; /* [m_pad][k_pad] bf16 */
+  const void* a_lo; /* BF16X3 only */
+  const void* b_hi; /* [n_pad][k_pad] bf16 */
+  const void* b_lo;
+  int32_t m_pad, n_pad, k_pad;
+  int32_t precision; /* NMFMU_PREC_* */
+  float beta;
+  const float* x;   /* [m_pad][n_pad] fp32 target (RATIO, LOSS) */
+  void* gn_hi;      /* RATIO outputs, [m_pad][n_pad] bf16 */
+  void* gn_lo;
+  void* gp_hi;      /* beta != 1 */
+  void* gp_lo;
+  float* out;       /* F32: [m_pad][n_pad]; LOSS: partials */
+  int32_t m_valid, n_valid; /* LOSS: logical extent */
+} nmfmu_gemm_desc;
+
+int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
+
+/* Strided 2-D gather of an fp32 tensor into a zero-padded row-major matrix (fp32 copy and/or bf16 hi[,lo] planes):
+ *   dst[row][col] = src[(row / row_inner) * row_outer_stride + (row % row_inner) * row_inner_stride
+ *                     + (col / col_inner) * col_outer_stride + (col % col_inner) * col_inner_stride]
+ * Covers V (B,C,L) -> [c][(b,l)] and [(b,l)][c], and W (C,R*T) -> Wm / Wm^T.  Optional validation flags as in
+ * nmfmu_pack_x (nmf.py:329-336). */
+int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t row_outer_stride, int64_t row_inner_stride,
+                 int col_inner, int64_t col_outer_stride, int64_t col_inner_stride, int rows_pad, int cols_pad,
+                 float* dst_f32, void* dst_hi, void* dst_lo, uint32_t* flags, void* stream);
+
+/* Toeplitz unfold of H (batch, rank, lh): hu [(b,l)][(r,t)] (bl_pad x rp_pad) and hut [(r,t)][(b,l)]. */
+int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, void* hu_hi, void* hu_lo, void* hut_hi,
+                      void* hut_lo, int bl_pad, int rp_pad, void* stream);
+
+/* out[r] = sum over outer o and inner i of src[o][r][i]: the closed-form beta == 1 denominators (nmf.py:122-131). */
+int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* out, void* stream);
+
+/* nmf.py:78-92 for W (channels, rank, taps) in place; num/den fp32 [c_pad][rp_pad]; kl_den[rank] or den. */
+int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                       const float* kl_den, int rp_pad, float l1, float l2, float gamma, void* stream);
+
+/* Folds y[(r,t)][(b,l)] (fp32 [rp_pad][bl_pad]) along the taps, neg[b][r][j] = sum_t y[(r,t)][(b,j+t)], then
+ * nmf.py:78-92 for H (batch, rank, lh) in place. */
+int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
+                            const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */
 int nmfmu_timer_create(int n_events, void** timer);

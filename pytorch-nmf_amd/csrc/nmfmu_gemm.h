@@ -1,0 +1,197 @@
+// NT GEMM for the convolutive (NMFD) path:  D[m][n] = sum_k A[m][k] * B[n][k]
+//
+// NMFD (nmf.py:700-779 of the reference) is dense NMF on unfolded operands with an effective rank R*T (3200 at
+// BASELINE configs[3]), far too wide to keep the second GEMM's accumulators in registers the way the dense fused
+// kernel does.  Its MU iteration is therefore four plain GEMMs (reconstruction for each half-step, W numerator,
+// H numerator before folding) whose elementwise work rides in the epilogue:
+//
+//   EPI_RATIO  D = S:  Gn = f(S, X) (and Gp for beta != 1) written as bf16 (hi[, lo]) planes, row-major [m][n]
+//   EPI_F32    D written as fp32 row-major
+//   EPI_LOSS   beta-divergence of D against X, one partial per workgroup
+//
+// Both operands are bf16 planes (hi[, lo]) with k contiguous, zero padded to multiples of 128 in every dimension.
+// 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles), BK = 64, LDS double buffered by
+// LDS-DMA.  The 128-byte LDS rows are XOR-swizzled on the DMA *source* side (linear LDS destination) and on the
+// ds_read side, which makes every ds_read_b128 conflict free (same analysis as the P2 image of nmfmu_layout.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nmfmu_fused.h"
+
+namespace nmfmu {
+
+enum GemmEpi : int { kEpiRatio = 0, kEpiF32 = 1, kEpiLoss = 2 };
+
+struct GemmArgs {
+  const uint16_t* a_hi;  // [m_pad][k_pad]
+  const uint16_t* a_lo;
+  const uint16_t* b_hi;  // [n_pad][k_pad]
+  const uint16_t* b_lo;
+  int m_pad, n_pad, k_pad;
+  // epilogue operands
+  const float* x;        // [m_pad][n_pad] fp32 (ratio / loss)
+  uint16_t* gn_hi;       // ratio outputs, [m_pad][n_pad]
+  uint16_t* gn_lo;
+  uint16_t* gp_hi;
+  uint16_t* gp_lo;
+  float* out;            // EPI_F32: [m_pad][n_pad];  EPI_LOSS: [gridDim.x * gridDim.y] partials
+  int m_valid, n_valid;  // loss masking
+  float beta;
+};
+
+template <bool X3>
+struct GemmCfg {
+  static constexpr int BM = 128, BN = 128, BK = 64;
+  static constexpr int TILE = BM * BK * 2;          // bytes of one operand-plane tile (16 KiB)
+  static constexpr int NPL = X3 ? 2 : 1;
+  static constexpr int STAGE = 2 * NPL * TILE;      // A planes then B planes
+  static constexpr int LDS_BYTES = 2 * STAGE;
+};
+
+template <bool X3, int EPI, int BETA>
+__global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
+  using C = GemmCfg<X3>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hl = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bm = blockIdx.y, bn = blockIdx.x;
+  const int ktiles = a.k_pad / C::BK;
+  const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
+
+  // DMA source pointers: thread handles chunk c = p*256 + tid of a tile: row = c >> 3, LDS slot = c & 7,
+  // source slot = slot ^ ((row >> 1) & 7)
+  const char* src[2 * C::NPL];
+  {
+    const char* bases[4] = {reinterpret_cast<const char*>(a.a_hi), reinterpret_cast<const char*>(a.a_lo),
+                            reinterpret_cast<const char*>(a.b_hi), reinterpret_cast<const char*>(a.b_lo)};
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+      for (int pl = 0; pl < C::NPL; ++pl)
+        src[op * C::NPL + pl] = bases[op * 2 + pl] + (size_t)(op == 0 ? bm : bn) * 128 * ldk;
+  }
+  const int row_t = tid >> 3;                                   // + 32 * p
+  const int sslot = (tid & 7) ^ ((row_t >> 1) & 7);             // (row >> 1) & 7 is the same for every pass (32 | 16)
+  const size_t thr_off = (size_t)row_t * ldk + sslot * 16;
+
+  auto stage_issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int im = 0; im < 2 * C::NPL; ++im) {
+      const char* s0 = src[im] + thr_off + (size_t)kt * (C::BK * 2);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        char* dst = smem + buf * C::STAGE + im * C::TILE + p * 4096 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (size_t)p * 32 * ldk),
+                                         (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = (EPI != kEpiF32 && BETA != kEuc) ? kEps : 0.f;
+
+  const int a_rowoff = (wm * 64 + j) * 128;  // + mi * 4096
+  const int b_rowoff = (wn * 64 + j) * 128;
+  const int swz = ((j >> 1) & 7) << 4;
+
+  stage_issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
+    const char* sb = smem + buf * C::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int so = ((2 * ks + hl) << 4) ^ swz;
+      u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = ld16(sb + a_rowoff + i * 4096 + so);
+        bh[i] = ld16(sb + C::NPL * C::TILE + b_rowoff + i * 4096 + so);
+        if constexpr (X3) {
+          al[i] = ld16(sb + C::TILE + a_rowoff + i * 4096 + so);
+          bl[i] = ld16(sb + 3 * C::TILE + b_rowoff + i * 4096 + so);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if constexpr (X3) {
+            acc[mi][ni] = mfma_bf16(al[mi], bh[ni], acc[mi][ni]);
+            acc[mi][ni] = mfma_bf16(ah[mi], bl[ni], acc[mi][ni]);
+          }
+          acc[mi][ni] = mfma_bf16(ah[mi], bh[ni], acc[mi][ni]);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: accumulator e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column j
+  float lacc = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = bn * 128 + wn * 64 + ni * 32 + j;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm * 128 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const size_t idx = (size_t)m * a.n_pad + n;
+        const float s = acc[mi][ni][e];
+        if constexpr (EPI == kEpiF32) {
+          a.out[idx] = s;
+        } else if constexpr (EPI == kEpiLoss) {
+          const float x = a.x[idx];
+          lacc += (m < a.m_valid && n < a.n_valid) ? loss_elem<BETA>(s, x, a.beta) : 0.f;
+        } else {
+          const float x = a.x[idx];
+          float gn, gp;
+          mu_elem<BETA>(s, x, a.beta, gn, gp);
+          const uint32_t nh = pack_bf16(gn, 0.f);
+          a.gn_hi[idx] = (uint16_t)nh;
+          if constexpr (X3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
+          if constexpr (BETA != kKL) {
+            const uint32_t ph = pack_bf16(gp, 0.f);
+            a.gp_hi[idx] = (uint16_t)ph;
+            if constexpr (X3) a.gp_lo[idx] = (uint16_t)pack_bf16(gp - bf16_lo(ph), 0.f);
+          }
+        }
+      }
+    }
+  if constexpr (EPI == kEpiLoss) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lacc += __shfl_xor(lacc, o, 64);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = lacc;
+    __syncthreads();
+    if (tid == 0) a.out[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+template <bool X3, int EPI, int BETA>
+int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
+  using C = GemmCfg<X3>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_pad / 128, a.m_pad / 128), dim3(256), C::LDS_BYTES, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_gemm(int x3, int epi, int beta_kind, const GemmArgs& a, hipStream_t s);
+
+}  // namespace nmfmu

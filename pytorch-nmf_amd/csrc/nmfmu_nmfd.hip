@@ -1,0 +1,296 @@
+// Convolutive NMF (NMFD, nmf.py:700-779 of the reference) on MI355X: GEMM instantiations + the small
+// memory-bound kernels around them (strided packing, Toeplitz unfold of H, fold + MU apply).
+//
+// With W (C, R, T) viewed as Wm (C x R*T) and Hu[(b,l)][(r,t)] = H[b][r][l-t] (zero outside 0 <= l-t < Lh):
+//   reconstruction   S[c][(b,l)]  = sum_{r'} Wm[c][r'] Hu[(b,l)][r']                    (nmf.py:776-779)
+//   W numerator      num[c][r']   = sum_{(b,l)} Gn[c][(b,l)] Hu[(b,l)][r']              (conv backward wrt W)
+//   H numerator      Y[r'][(b,l)] = sum_c Wm[c][r'] Gn[c][(b,l)] ;  neg[b][r][j] = sum_t Y[(r,t)][(b,j+t)]
+//   beta == 1 denominators: sum_{b,j} H[b][r][j]  and  sum_{c,t} W[c][r][t]              (nmf.py:122-131)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/nmfmu.h"
+#include "nmfmu_gemm.h"
+
+namespace nmfmu {
+
+int launch_gemm(int x3, int epi, int beta_kind, const GemmArgs& a, hipStream_t s) {
+#define G1(X, E, B) \
+  if (x3 == (X ? 1 : 0) && epi == E && beta_kind == B) return launch_gemm_one<X, E, B>(a, s);
+#define GB(X, E) G1(X, E, kKL) G1(X, E, kEuc) G1(X, E, kIS) G1(X, E, kGen)
+  GB(false, kEpiRatio) GB(true, kEpiRatio) GB(false, kEpiLoss) GB(true, kEpiLoss)
+  if (epi == kEpiF32) return x3 ? launch_gemm_one<true, kEpiF32, kEuc>(a, s) : launch_gemm_one<false, kEpiF32, kEuc>(a, s);
+#undef GB
+#undef G1
+  return -2;
+}
+
+// dst[row][col] (padded, zero filled) = src[(row / rin) * ros + (row % rin) * ris + (col / cin) * cos + (col % cin) * cis]
+struct Pack2D {
+  const float* src;
+  int rows, cols;
+  int rin, cin;
+  int64_t ros, ris, cos, cis;
+  int rows_pad, cols_pad;
+};
+
+__device__ __forceinline__ float pack2d_get(const Pack2D& p, int row, int col) {
+  if (row >= p.rows || col >= p.cols) return 0.f;
+  return p.src[(int64_t)(row / p.rin) * p.ros + (int64_t)(row % p.rin) * p.ris + (int64_t)(col / p.cin) * p.cos +
+               (int64_t)(col % p.cin) * p.cis];
+}
+
+// one thread = 8 consecutive columns of one row
+template <bool BF16>
+__global__ void __launch_bounds__(256) pack2d_kernel(Pack2D p, float* dst_f32, uint16_t* dst_hi, uint16_t* dst_lo,
+                                                     uint32_t* flags) {
+  const int64_t n8 = (int64_t)p.rows_pad * (p.cols_pad / 8);
+  uint32_t bad = 0, mn = 0x7f800000u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / (p.cols_pad / 8)), c0 = (int)(i % (p.cols_pad / 8)) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = pack2d_get(p, row, c0 + e);
+      if (flags && row < p.rows && c0 + e < p.cols) {
+        bad |= !(v[e] >= 0.f) ? 1u : 0u;
+        mn = min(mn, __builtin_bit_cast(uint32_t, v[e]) & 0x7fffffffu);
+      }
+    }
+    const size_t o = (size_t)row * p.cols_pad + c0;
+    if constexpr (BF16) {
+      u32x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t h = pack_bf16(v[2 * e], v[2 * e + 1]);
+        hi[e] = h;
+        lo[e] = pack_bf16(v[2 * e] - bf16_lo(h), v[2 * e + 1] - bf16_hi(h));
+      }
+      *reinterpret_cast<u32x4*>(dst_hi + o) = hi;
+      if (dst_lo) *reinterpret_cast<u32x4*>(dst_lo + o) = lo;
+    } else {
+      *reinterpret_cast<float4*>(dst_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(dst_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+  if (flags) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      bad |= __shfl_xor(bad, o, 64);
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (bad) atomicOr(&flags[0], 1u);
+      atomicMin(&flags[1], mn);
+    }
+  }
+}
+
+// Toeplitz unfold of H (B, R, Lh): Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], both bf16 (hi[, lo]) zero padded.
+__global__ void __launch_bounds__(256) conv_unfold_kernel(const float* __restrict__ H, int B, int R, int Lh, int T,
+                                                          uint16_t* hu_hi, uint16_t* hu_lo, uint16_t* hut_hi,
+                                                          uint16_t* hut_lo, int bl_pad, int rp_pad) {
+  const int L = Lh + T - 1;
+  const int64_t n_hu = (int64_t)bl_pad * (rp_pad / 8), n_hut = (int64_t)rp_pad * (bl_pad / 8);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_hu + n_hut; i += (int64_t)gridDim.x * 256) {
+    const bool tr = i >= n_hu;
+    const int64_t k = tr ? i - n_hu : i;
+    float v[8];
+    size_t o;
+    if (!tr) {  // row (b,l), 8 consecutive (r,t)
+      const int row = (int)(k / (rp_pad / 8)), c0 = (int)(k % (rp_pad / 8)) * 8;
+      const int b = row / L, l = row % L;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rp = c0 + e, r = rp / T, t = rp % T, jx = l - t;
+        v[e] = (row < B * L && rp < R * T && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+      }
+      o = (size_t)row * rp_pad + c0;
+    } else {    // row (r,t), 8 consecutive (b,l)
+      const int row = (int)(k / (bl_pad / 8)), c0 = (int)(k % (bl_pad / 8)) * 8;
+      const int r = row / T, t = row % T;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = c0 + e, b = col / L, l = col % L, jx = l - t;
+        v[e] = (row < R * T && col < B * L && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+      }
+      o = (size_t)row * bl_pad + c0;
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t h = pack_bf16(v[2 * e], v[2 * e + 1]);
+      hi[e] = h;
+      lo[e] = pack_bf16(v[2 * e] - bf16_lo(h), v[2 * e + 1] - bf16_hi(h));
+    }
+    uint16_t* dh = tr ? hut_hi : hu_hi;
+    uint16_t* dl = tr ? hut_lo : hu_lo;
+    *reinterpret_cast<u32x4*>(dh + o) = hi;
+    if (dl) *reinterpret_cast<u32x4*>(dl + o) = lo;
+  }
+}
+
+// out[r] = sum_{o, i} src[(o * R + r) * inner + i]   (one workgroup per r, fixed order)
+__global__ void __launch_bounds__(256) rank_sums_kernel(const float* __restrict__ src, int outer, int R, int inner,
+                                                        float* __restrict__ out) {
+  __shared__ float red[256];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  const int64_t n = (int64_t)outer * inner;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t o = i / inner, ii = i % inner;
+    s += src[((size_t)o * R + r) * inner + ii];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] = red[0];
+}
+
+__device__ __forceinline__ float mu_update(float f, float neg, float pos, bool closed_form, float l1, float l2,
+                                           float gamma) {
+  neg = fmaxf(neg, 0.f) + kEps;                       // nmf.py:78
+  if (!closed_form) pos = fmaxf(pos, 0.f) + kEps;     // nmf.py:83
+  if (l1 > 0.f) pos += l1;
+  if (l2 > 0.f) pos += l2 * f;
+  float mult = neg / pos;
+  if (gamma != 1.f) mult = powf(mult, gamma);
+  return f * mult;
+}
+
+// W (C, R*T) in place.  num/den: fp32 [c_pad][rp_pad].  kl_den[r] = sum_{b,j} H[b][r][j] for beta == 1.
+__global__ void __launch_bounds__(256) conv_apply_w_kernel(float* __restrict__ W, int C, int RT, int T,
+                                                           const float* __restrict__ num, const float* __restrict__ den,
+                                                           const float* __restrict__ kl_den, int rp_pad, float l1,
+                                                           float l2, float gamma) {
+  const int64_t n = (int64_t)C * RT;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / RT), rp = (int)(i % RT);
+    const size_t o = (size_t)c * rp_pad + rp;
+    const float pos = kl_den ? kl_den[rp / T] : den[o];
+    W[i] = mu_update(W[i], num[o], pos, kl_den != nullptr, l1, l2, gamma);
+  }
+}
+
+// H (B, R, Lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)], Y fp32 [rp_pad][bl_pad].
+__global__ void __launch_bounds__(256) conv_fold_apply_h_kernel(float* __restrict__ H, int B, int R, int Lh, int T,
+                                                                const float* __restrict__ ynum,
+                                                                const float* __restrict__ yden,
+                                                                const float* __restrict__ kl_den, int bl_pad, float l1,
+                                                                float l2, float gamma) {
+  const int L = Lh + T - 1;
+  const int64_t n = (int64_t)B * R * Lh;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int jx = (int)(i % Lh), r = (int)((i / Lh) % R), b = (int)(i / ((int64_t)Lh * R));
+    const size_t base = (size_t)r * T * bl_pad + (size_t)b * L + jx;
+    float neg = 0.f, pos = 0.f;
+    for (int t = 0; t < T; ++t) neg += ynum[base + (size_t)t * bl_pad + t];
+    if (kl_den) {
+      pos = kl_den[r];
+    } else {
+      for (int t = 0; t < T; ++t) pos += yden[base + (size_t)t * bl_pad + t];
+    }
+    H[i] = mu_update(H[i], neg, pos, kl_den != nullptr, l1, l2, gamma);
+  }
+}
+
+}  // namespace nmfmu
+
+using namespace nmfmu;
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
+}  // namespace
+
+extern "C" {
+
+int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
+  if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
+  if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % 128 || d->k_pad % 128)
+    return NMFMU_ERR_ARG;
+  const int x3 = d->precision == NMFMU_PREC_BF16X3;
+  if (x3 && (!d->a_lo || !d->b_lo)) return NMFMU_ERR_ARG;
+  const int kind = nmfmu_beta_kind(d->beta);
+  GemmArgs a{};
+  a.a_hi = (const uint16_t*)d->a_hi, a.a_lo = (const uint16_t*)d->a_lo;
+  a.b_hi = (const uint16_t*)d->b_hi, a.b_lo = (const uint16_t*)d->b_lo;
+  a.m_pad = d->m_pad, a.n_pad = d->n_pad, a.k_pad = d->k_pad;
+  a.x = d->x;
+  a.gn_hi = (uint16_t*)d->gn_hi, a.gn_lo = (uint16_t*)d->gn_lo, a.gp_hi = (uint16_t*)d->gp_hi, a.gp_lo = (uint16_t*)d->gp_lo;
+  a.out = d->out;
+  a.m_valid = d->m_valid, a.n_valid = d->n_valid;
+  a.beta = d->beta;
+  if (epilogue == NMFMU_EPI_RATIO) {
+    if (!a.x || !a.gn_hi || (x3 && !a.gn_lo)) return NMFMU_ERR_ARG;
+    if (kind != NMFMU_BETA_KL && (!a.gp_hi || (x3 && !a.gp_lo))) return NMFMU_ERR_ARG;
+  } else if (epilogue == NMFMU_EPI_F32) {
+    if (!a.out) return NMFMU_ERR_ARG;
+  } else if (epilogue == NMFMU_EPI_LOSS) {
+    if (!a.x || !a.out) return NMFMU_ERR_ARG;
+  } else {
+    return NMFMU_ERR_ARG;
+  }
+  return launch_gemm(x3, epilogue, kind, a, S(stream));
+}
+
+int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t row_outer_stride, int64_t row_inner_stride,
+                 int col_inner, int64_t col_outer_stride, int64_t col_inner_stride, int rows_pad, int cols_pad,
+                 float* dst_f32, void* dst_hi, void* dst_lo, uint32_t* flags, void* stream) {
+  if (!src || rows <= 0 || cols <= 0 || rows_pad < rows || cols_pad < cols || cols_pad % 8 || row_inner <= 0 ||
+      col_inner <= 0)
+    return NMFMU_ERR_ARG;
+  if (!dst_f32 && !dst_hi) return NMFMU_ERR_ARG;
+  Pack2D p{src, rows, cols, row_inner, col_inner, row_outer_stride, row_inner_stride, col_outer_stride,
+           col_inner_stride, rows_pad, cols_pad};
+  const int grid = grid_for((int64_t)rows_pad * (cols_pad / 8));
+  if (dst_f32) {
+    hipLaunchKernelGGL(pack2d_kernel<false>, dim3(grid), dim3(256), 0, S(stream), p, dst_f32, nullptr, nullptr, flags);
+    flags = nullptr;
+  }
+  if (dst_hi)
+    hipLaunchKernelGGL(pack2d_kernel<true>, dim3(grid), dim3(256), 0, S(stream), p, nullptr, (uint16_t*)dst_hi,
+                       (uint16_t*)dst_lo, flags);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, void* hu_hi, void* hu_lo, void* hut_hi,
+                      void* hut_lo, int bl_pad, int rp_pad, void* stream) {
+  if (!h || !hu_hi || !hut_hi || batch <= 0 || rank <= 0 || lh <= 0 || taps <= 0) return NMFMU_ERR_ARG;
+  if (bl_pad < batch * (lh + taps - 1) || rp_pad < rank * taps || bl_pad % 8 || rp_pad % 8) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)bl_pad * (rp_pad / 8) * 2;
+  hipLaunchKernelGGL(conv_unfold_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                     (uint16_t*)hu_hi, (uint16_t*)hu_lo, (uint16_t*)hut_hi, (uint16_t*)hut_lo, bl_pad, rp_pad);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* out, void* stream) {
+  if (!src || !out || outer <= 0 || rank <= 0 || inner <= 0) return NMFMU_ERR_ARG;
+  hipLaunchKernelGGL(rank_sums_kernel, dim3(rank), dim3(256), 0, S(stream), src, outer, rank, inner, out);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                       const float* kl_den, int rp_pad, float l1, float l2, float gamma, void* stream) {
+  if (!w || !num || (!den && !kl_den) || rp_pad < rank * taps) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)channels * rank * taps;
+  hipLaunchKernelGGL(conv_apply_w_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
+                     den, kl_den, rp_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
+                            const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream) {
+  if (!h || !y_num || (!y_den && !kl_den) || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * rank * lh;
+  hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                     y_num, y_den, kl_den, bl_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

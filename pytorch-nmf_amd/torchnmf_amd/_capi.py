@@ -43,6 +43,17 @@ class Step(C.Structure):
                 ('l1', C.c_float), ('l2', C.c_float)]
 
 
+class GemmDesc(C.Structure):
+    """struct nmfmu_gemm_desc"""
+    _fields_ = [('a_hi', C.c_void_p), ('a_lo', C.c_void_p), ('b_hi', C.c_void_p), ('b_lo', C.c_void_p),
+                ('m_pad', C.c_int32), ('n_pad', C.c_int32), ('k_pad', C.c_int32), ('precision', C.c_int32),
+                ('beta', C.c_float), ('x', C.c_void_p), ('gn_hi', C.c_void_p), ('gn_lo', C.c_void_p),
+                ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
+                ('n_valid', C.c_int32)]
+
+
+EPI_RATIO, EPI_F32, EPI_LOSS = 0, 1, 2
+
 # name -> (restype, argtypes); every symbol include/nmfmu.h declares
 SIGNATURES = {
     'nmfmu_abi_version': (C.c_int, []),
@@ -67,6 +78,16 @@ SIGNATURES = {
     'nmfmu_beta_div': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_reconstruct': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p]),
+    'nmfmu_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    'nmfmu_pack2d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64,
+                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_unfold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'nmfmu_rank_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_apply_w': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_conv_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_timer_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'nmfmu_timer_record': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_timer_elapsed_ms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

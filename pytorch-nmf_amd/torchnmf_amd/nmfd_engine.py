@@ -1,0 +1,190 @@
+"""Host-side orchestration of NMFD (1-D convolutive NMF) on one MI355X.
+
+Reference: ``NMFD.reconstruct`` = ``F.conv1d(H, W.flip(2), padding=T-1)`` (nmf.py:776-779) driven by the same
+``fit`` loop (nmf.py:297-409).  With ``Wm = W.view(C, R*T)`` and the Toeplitz unfold
+``Hu[(b,l)][(r,t)] = H[b][r][l-t]`` the reconstruction is ``Wm @ Hu.T`` and both conv-backward passes are GEMMs,
+so one MU iteration is four NT GEMMs (C ABI ``nmfmu_gemm``) with fused epilogues plus small unfold / fold /
+apply kernels:
+
+    W half-step   Gn[c][(b,l)]   = ratio( Wm Hu^T , V )              GEMM + EPI_RATIO
+                  num[c][(r,t)]  = Gn  HuT^T                         GEMM + EPI_F32   -> nmfmu_conv_apply_w
+    H half-step   GnT[(b,l)][c]  = ratio( Hu Wm^T , V^T )            GEMM + EPI_RATIO (transposed problem)
+                  Y[(r,t)][(b,l)] = WmT GnT^T                        GEMM + EPI_F32   -> nmfmu_conv_fold_apply_h
+
+NMFD is not sharded across GPUs ("replicas only").
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _capi
+from .engine import _ptr, mu_gamma
+
+
+def _pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Planes:
+    """bf16 (hi[, lo]) planes of a zero-padded row-major matrix."""
+
+    def __init__(self, rows_pad, cols_pad, x3, dev):
+        self.rows_pad, self.cols_pad = rows_pad, cols_pad
+        self.hi = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev)
+        self.lo = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev) if x3 else None
+
+
+class ConvMU:
+    """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
+
+    def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True):
+        self.lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
+        assert V.dim() == 3 and W.dim() == 3 and H.dim() == 3
+        B, Cc, L = V.shape
+        C_, R, T = W.shape
+        Bh, Rh, Lh = H.shape
+        assert (C_, Rh, Bh) == (Cc, R, B) and Lh == L - T + 1, 'V, W, H shapes are inconsistent'
+        for t_ in (W, H):
+            assert t_.dtype == torch.float32 and t_.is_contiguous()
+        if precision in (None, 'auto'):
+            precision = 'bf16x3'
+        if precision not in _capi.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
+        self.precision_name = precision
+        self.precision = _capi.PRECISIONS[precision]
+        x3 = self.precision == _capi.PREC_BF16X3
+        self.beta = float(beta)
+        self.kl = self.beta == 1.0
+        self.gamma, self.l1, self.l2 = mu_gamma(self.beta), float(l1), float(l2)
+        self.W, self.H = W, H
+        self.B, self.C, self.L, self.R, self.T, self.Lh = B, Cc, L, R, T, Lh
+        dev = V.device
+        self.c_pad, self.bl_pad, self.rp_pad = _pad128(Cc), _pad128(B * L), _pad128(R * T)
+        cp, blp, rpp = self.c_pad, self.bl_pad, self.rp_pad
+
+        # targets: X_w[c][(b,l)] and X_h[(b,l)][c], fp32, zero padded; validation fused into the first gather
+        self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
+        V = V.contiguous()
+        self.x_w = torch.empty(cp * blp, dtype=torch.float32, device=dev)
+        self.x_h = torch.empty(blp * cp, dtype=torch.float32, device=dev)
+        self._pack2d(V, Cc, B * L, 1, L, 0, L, Cc * L, 1, cp, blp, self.x_w, None, self.flags)
+        self._pack2d(V, B * L, Cc, L, Cc * L, 1, 1, L, 0, blp, cp, self.x_h, None, None)
+
+        # operand planes
+        self.wm = _Planes(cp, rpp, x3, dev)     # [c][(r,t)]
+        self.wmt = _Planes(rpp, cp, x3, dev)    # [(r,t)][c]
+        self.hu = _Planes(blp, rpp, x3, dev)    # [(b,l)][(r,t)]
+        self.hut = _Planes(rpp, blp, x3, dev)   # [(r,t)][(b,l)]
+        self.gn = _Planes(cp, blp, x3, dev)     # W half-step ratio, [c][(b,l)]
+        self.gnt = _Planes(blp, cp, x3, dev)    # H half-step ratio, [(b,l)][c]
+        self.gp = None if self.kl else _Planes(cp, blp, x3, dev)
+        self.gpt = None if self.kl else _Planes(blp, cp, x3, dev)
+        self.num_w = torch.empty(cp * rpp, dtype=torch.float32, device=dev)
+        self.den_w = None if self.kl else torch.empty(cp * rpp, dtype=torch.float32, device=dev)
+        self.y = torch.empty(rpp * blp, dtype=torch.float32, device=dev)
+        self.y_den = None if self.kl else torch.empty(rpp * blp, dtype=torch.float32, device=dev)
+        self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
+        self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
+        self.loss_part = torch.empty((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.refresh_images()
+
+    # ------------------------------------------------------------------ helpers
+    def _pack2d(self, src, rows, cols, rin, ros, ris, cin, cos, cis, rows_pad, cols_pad, dst_f32, planes, flags):
+        _capi.check(self.lib.nmfmu_pack2d(src.data_ptr(), rows, cols, rin, ros, ris, cin, cos, cis, rows_pad, cols_pad,
+                                          _ptr(dst_f32), _ptr(planes.hi) if planes else None,
+                                          _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
+
+    def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0):
+        assert a.cols_pad == b.cols_pad
+        d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), a.rows_pad, b.rows_pad, a.cols_pad,
+                           self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
+                           _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
+                           _ptr(out), m_valid, n_valid)
+        _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
+
+    def _pack_w(self):
+        RT = self.R * self.T
+        self._pack2d(self.W, self.C, RT, 1, RT, 0, 1, 1, 0, self.c_pad, self.rp_pad, None, self.wm, None)
+        self._pack2d(self.W, RT, self.C, 1, 1, 0, 1, RT, 0, self.rp_pad, self.c_pad, None, self.wmt, None)
+        _capi.check(self.lib.nmfmu_rank_sums(self.W.data_ptr(), self.C, self.R, self.T, self.sum_w.data_ptr(),
+                                             _stream()), 'nmfmu_rank_sums')
+
+    def _pack_h(self):
+        _capi.check(self.lib.nmfmu_conv_unfold(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
+                                               _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), self.bl_pad,
+                                               self.rp_pad, _stream()), 'nmfmu_conv_unfold')
+        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_h.data_ptr(),
+                                             _stream()), 'nmfmu_rank_sums')
+
+    def refresh_images(self):
+        self._pack_w()
+        self._pack_h()
+
+    # ------------------------------------------------------------------ the fit-loop interface (see nmf.BaseComponent.fit)
+    def target_flags(self):
+        bad, mn = (int(x) for x in self.flags.tolist())
+        return bool(bad), mn == 0
+
+    def w_step(self):
+        """nmf.py:367-378 for the conv1d model."""
+        self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp)
+        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w)
+        if not self.kl:
+            self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
+        _capi.check(self.lib.nmfmu_conv_apply_w(self.W.data_ptr(), self.C, self.R, self.T, self.num_w.data_ptr(),
+                                                _ptr(self.den_w), self.sum_h.data_ptr() if self.kl else None,
+                                                self.rp_pad, self.l1, self.l2, self.gamma, _stream()),
+                    'nmfmu_conv_apply_w')
+        self._pack_w()
+
+    def h_step(self):
+        """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
+        self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt)
+        self._gemm(self.wmt, self.gnt, _capi.EPI_F32, out=self.y)
+        if not self.kl:
+            self._gemm(self.wmt, self.gpt, _capi.EPI_F32, out=self.y_den)
+        _capi.check(self.lib.nmfmu_conv_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
+                                                     self.y.data_ptr(), _ptr(self.y_den),
+                                                     self.sum_w.data_ptr() if self.kl else None, self.bl_pad, self.l1,
+                                                     self.l2, self.gamma, _stream()), 'nmfmu_conv_fold_apply_h')
+        self._pack_h()
+
+    def divergence(self) -> float:
+        """beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401).  One host sync."""
+        self._gemm(self.wm, self.hu, _capi.EPI_LOSS, x=self.x_w, out=self.loss_part, m_valid=self.C,
+                   n_valid=self.B * self.L)
+        return float(self.loss_part.double().sum().item())
+
+
+def reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """``NMFD.reconstruct`` (nmf.py:776-779) on the device: Wm @ Hu^T through the split-bf16 GEMM, fp32 out."""
+    if H.device.type != 'cuda' or W.device.type != 'cuda':
+        raise _capi.NmfmuError('reconstruct: tensors must live on the ROCm device (no CPU fallback)')
+    lib = _capi.load()
+    Hc, Wc = H.detach().float().contiguous(), W.detach().float().contiguous()
+    B, R, Lh = Hc.shape
+    Cc, R2, T = Wc.shape
+    assert R == R2
+    L = Lh + T - 1
+    dev = H.device
+    cp, blp, rpp = _pad128(Cc), _pad128(B * L), _pad128(R * T)
+    wm, hu, hut = _Planes(cp, rpp, True, dev), _Planes(blp, rpp, True, dev), _Planes(rpp, blp, True, dev)
+    RT = R * T
+    _capi.check(lib.nmfmu_pack2d(Wc.data_ptr(), Cc, RT, 1, RT, 0, 1, 1, 0, cp, rpp, None, _ptr(wm.hi), _ptr(wm.lo), None,
+                                 _stream()), 'nmfmu_pack2d')
+    _capi.check(lib.nmfmu_conv_unfold(Hc.data_ptr(), B, R, Lh, T, _ptr(hu.hi), _ptr(hu.lo), _ptr(hut.hi), _ptr(hut.lo),
+                                      blp, rpp, _stream()), 'nmfmu_conv_unfold')
+    out = torch.empty(cp, blp, dtype=torch.float32, device=dev)
+    d = _capi.GemmDesc(_ptr(wm.hi), _ptr(wm.lo), _ptr(hu.hi), _ptr(hu.lo), cp, blp, rpp, _capi.PREC_BF16X3, 2.0, None,
+                       None, None, None, None, out.data_ptr(), 0, 0)
+    _capi.check(lib.nmfmu_gemm(C.byref(d), _capi.EPI_F32, _stream()), 'nmfmu_gemm')
+    return out[:Cc, :B * L].reshape(Cc, B, L).permute(1, 0, 2).contiguous()

@@ -352,3 +352,51 @@ def test_large_slice_property_and_fixed_point(dev):
     eng.h_step()
     torch.cuda.synchronize()
     assert rel_err(W.cpu(), W0) < TOL and rel_err(H.cpu(), H0) < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------
+# NMFD (1-D convolutive NMF): golden vectors from the reference + oracle
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['doc', 'mid', 'batch'])
+@pytest.mark.parametrize('beta', [0.5, 1, 2])
+def test_nmfd_fit_g5_golden(dev, name, beta):
+    from torchnmf_amd.nmf import NMFD
+    g = load_golden('g5_nmfd')
+    V, W0, H0 = t(g[f'{name}_V']), t(g[f'{name}_W0']), t(g[f'{name}_H0'])
+    m = NMFD(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), beta, NO_STOP, 30, precision='bf16x3')
+    assert n == 30
+    ew, eh = rel_err(m.W.data.cpu(), g[f'{name}_b{beta}_W30']), rel_err(m.H.data.cpu(), g[f'{name}_b{beta}_H30'])
+    assert ew < TOL and eh < TOL, (ew, eh)
+
+
+@pytest.mark.parametrize('name', ['doc', 'mid', 'batch'])
+def test_nmfd_regularised_and_reconstruct(dev, name):
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMFD
+    g = load_golden('g5_nmfd')
+    V, W0, H0 = t(g[f'{name}_V']), t(g[f'{name}_W0']), t(g[f'{name}_H0'])
+    m = NMFD(W=W0, H=H0).to(dev)
+    assert rel_err(m().cpu(), O.nmfd_reconstruct(H0, W0)) < 1e-5          # NMFD.reconstruct (nmf.py:776-779)
+    m.fit(V.to(dev), 1, NO_STOP, 10, alpha=0.1, l1_ratio=0.5, precision='bf16x3')
+    assert rel_err(m.W.data.cpu(), g[f'{name}_reg_W10']) < TOL and rel_err(m.H.data.cpu(), g[f'{name}_reg_H10']) < TOL
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16x3', TOL), ('bf16', 2e-2)])
+def test_nmfd_medium_against_oracle(dev, prec, tol):
+    """A spectrogram-like shape (C=257, L=1000, R=8, T=40): 3 iterations + early-stop bookkeeping vs the oracle."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMFD
+    g = torch.Generator().manual_seed(21)
+    B, Cc, L, R, T = 1, 257, 1000, 8, 40
+    V = torch.rand(B, Cc, L, generator=g)
+    if prec == 'bf16':
+        V = V.bfloat16().float()
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    m = NMFD(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), 1, NO_STOP, 3, precision=prec)
+    Wr, Hr, nr, losses, _ = O.fit(V, W0, H0, 1, NO_STOP, 3, kind='nmfd')
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    print(f'nmfd {prec}: relW={ew:.2e} relH={eh:.2e}')
+    assert n == nr and ew < tol and eh < tol
