@@ -49,6 +49,9 @@ def parse():
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
+    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd'],
+                    help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
+    ap.add_argument('--taps', type=int, default=400)
     return ap.parse_args()
 
 
@@ -65,8 +68,75 @@ def cpu_baseline(V, W0, H0, beta, iters):
     return dt, cores
 
 
+def main_nmfd(a):
+    """BASELINE configs[3]: NMFD spectrogram 1025 x 8192, rank 8, T = 400, beta = 1 (replicas only: 1 GPU)."""
+    dev = torch.device('cuda', 0)
+    from torchnmf_amd.nmfd_engine import ConvMU
+    Cc, L, R, T, beta = 1025, 8192, 8, a.taps, a.beta
+    g = torch.Generator(device=dev).manual_seed(1000)
+    V = torch.rand(1, Cc, L, device=dev, generator=g).bfloat16().float()
+    W = torch.randn(Cc, R, T, device=dev, generator=g).abs_()
+    H = torch.randn(1, R, L - T + 1, device=dev, generator=g).abs_()
+    Vc, Wc, Hc = V.cpu(), W.cpu(), H.cpu()
+    eng = ConvMU(V, W, H, beta, precision=a.precision)
+
+    def step():
+        eng.w_step()
+        eng.h_step()
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    flops = (4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T
+    # the dominant kernel (nt_gemm) timed live: 4 launches per iteration, each 2*C*L*R*T algorithmic flops
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(a.steps):
+        eng._gemm(eng.wm, eng.hu, 0, x=eng.x_w, gn=eng.gn, gp=eng.gp)
+    ev[1].record()
+    torch.cuda.synchronize()
+    gemm_ms = ev[0].elapsed_time(ev[1]) / a.steps
+    ach = 2.0 * Cc * L * R * T / (gemm_ms * 1e-3) / 1e12
+    peak = MFMA_BF16_PEAK_TFLOPS
+    cpu = None
+    if a.cpu_iters > 0:
+        from oracle import aten_port
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        torch.set_flush_denormal(True)
+        aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1)
+        t0 = time.perf_counter()
+        aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, a.cpu_iters)
+        dt = (time.perf_counter() - t0) / a.cpu_iters
+        cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+               'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
+               f'NMFD workload, fp32, F.conv1d + two backward passes (oracle/aten_port.py)'}
+    print(json.dumps({
+        'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), NMFD 1x{Cc}x{L} rank-{R} T={T} beta={beta:g}',
+        'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
+        'data': 'synthetic',
+        'config': {'workload': f'NMFD 1x{Cc}x{L} rank={R} T={T} beta={beta:g} (BASELINE configs[3])',
+                   'precision': a.precision, 'parallelism': 'single GPU (replicas only)'},
+        'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': round(ach / peak, 4), 'traffic': None, 'kernel': 'nmfmu::nt_gemm_kernel (EPI_RATIO)',
+                     'avg_launch_ms': round(gemm_ms, 5),
+                     'note': 'bf16x3 issues 3 MFMAs per algorithmic product: hardware MFMA rate is 3x achieved'
+                     if a.precision == 'bf16x3' else ''},
+        'cpu_baseline': cpu}))
+
+
 def main():
     a = parse()
+    if a.workload == 'nmfd':
+        assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'NMFD is not sharded (replicas only)'
+        torch.cuda.set_device(0)
+        return main_nmfd(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -58,3 +58,17 @@ def mu_iterations(V, W0, H0, beta=1, n_iter=1, alpha=0.0, l1_ratio=0.0):
         pos = W.detach().sum(0) if beta == 1 else None
         _update(V, F.linear(H, W.detach()), H, beta, gamma, l1, l2, pos)
     return W.data, H.data
+
+
+def mu_iterations_nmfd(V, W0, H0, beta=1, n_iter=1):
+    """Same loop for NMFD: reconstruction = F.conv1d(H, W.flip(2), padding=T-1) (nmf.py:776-779)."""
+    W = torch.nn.Parameter(W0.clone().float())
+    H = torch.nn.Parameter(H0.clone().float())
+    gamma = gamma_of(beta)
+    pad = W.shape[2] - 1
+    for _ in range(n_iter):
+        pos = H.detach().sum((0, 2), keepdim=True) if beta == 1 else None
+        _update(V, F.conv1d(H.detach(), W.flip(2), padding=pad), W, beta, gamma, 0.0, 0.0, pos)
+        pos = W.detach().sum((0, 2), keepdim=True).squeeze(0) if beta == 1 else None
+        _update(V, F.conv1d(H, W.detach().flip(2), padding=pad), H, beta, gamma, 0.0, 0.0, pos)
+    return W.data, H.data

@@ -126,3 +126,35 @@ def test_aten_port_equals_closed_form(beta):
     Wp, Hp = aten_port.mu_iterations(V, t(g['W0']), t(g['H0']), beta, 10, alpha=0.1, l1_ratio=0.5)
     W, H, _, _, _ = O.fit(V, t(g['W0']), t(g['H0']), beta, NO_STOP, 10, 0.1, 0.5)
     assert rel_err(Wp, W) < 2e-6 and rel_err(Hp, H) < 2e-6
+
+
+def _c_oracle():
+    import ctypes, os, subprocess
+    from conftest import ROOT
+    so = os.path.join(ROOT, 'oracle', 'libmu_oracle_c.so')
+    if not os.path.exists(so):
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True)
+    lib = ctypes.CDLL(so)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.mu_oracle_c_iterate.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.mu_oracle_c_beta_div.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    lib.mu_oracle_c_beta_div.restype = ctypes.c_double
+    return lib, fp
+
+
+@pytest.mark.parametrize('beta', [-1, 0, 0.5, 1, 1.5, 2, 3])
+def test_c_oracle_against_golden(beta):
+    """oracle/mu_oracle_c.c (scalar loops, its own summation order) reproduces the reference's vectors too."""
+    import ctypes
+    lib, fp = _c_oracle()
+    g = load_golden('g1_nmf_small')
+    V = (t(g['V']) + (float(g['v_shift_nonpos_beta']) if beta <= 0 else 0.0)).contiguous()
+    W, H = t(g['W0']).clone().contiguous(), t(g['H0']).clone().contiguous()
+    N, C = V.shape
+    R = W.shape[1]
+    p = lambda x: ctypes.cast(x.data_ptr(), fp)
+    loss0 = lib.mu_oracle_c_beta_div(p(V), p(W), p(H), N, C, R, beta)
+    assert (2 * loss0) ** 0.5 == pytest.approx(float(g[f'b{beta}_a0.1_l0.5_loss_init']), rel=2e-5)
+    lib.mu_oracle_c_iterate(p(V), p(W), p(H), N, C, R, beta, 0.05, 0.05, 50, 1, 1)
+    assert rel_err(W, g[f'b{beta}_a0.1_l0.5_W50']) < 2e-5 and rel_err(H, g[f'b{beta}_a0.1_l0.5_H50']) < 2e-5
