@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "nmfmu_layout.h"
 
 #ifndef NMFMU_PIN_SCHED
@@ -40,6 +42,18 @@
 #endif
 #ifndef NMFMU_ORDER
 #define NMFMU_ORDER 1   // 1: interleave accumulators in both GEMMs
+#endif
+#ifndef NMFMU_PHASED
+#define NMFMU_PHASED 1  // phase-interleaved schedule for the 256-row tile
+#endif
+#ifndef NMFMU_VALU_PER_MFMA
+#define NMFMU_VALU_PER_MFMA 7
+#endif
+#ifndef NMFMU_STAGGER
+#define NMFMU_STAGGER 0  // (measured: no gain on MI355X) rotate each workgroup's tile visiting order (HBM channel de-phasing)
+#endif
+#ifndef NMFMU_XDEPTH
+#define NMFMU_XDEPTH 1  // (2 measured no faster) X tiles prefetched ahead in VGPRs (LDS-DMA staging only)
 #endif
 #ifndef NMFMU_ABLATE
 #define NMFMU_ABLATE 0  // timing experiments only (results are WRONG when non-zero): 1 no elementwise, 2 no barrier/DMA
@@ -119,7 +133,11 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 template <int BETA>
 __device__ __forceinline__ void mu_elem(float s, float x, float beta, float& gn, float& gp) {
   if constexpr (BETA == kKL) {
+#if NMFMU_ABLATE == 6
+    gn = x * s;  // timing experiment: no reciprocal
+#else
     gn = x * __builtin_amdgcn_rcpf(s);
+#endif
     gp = 0.f;
   } else if constexpr (BETA == kEuc) {
     gn = x;
@@ -344,8 +362,13 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
             x1 = __builtin_bit_cast(float, u1);
           } else {
             const uint32_t w = x[g][2 * tt + (d >> 2)][d & 3];
+#if NMFMU_ABLATE == 8
+            x0 = __builtin_bit_cast(float, w);  // timing experiment: no unpack
+            x1 = x0;
+#else
             x0 = bf16_lo(w);
             x1 = bf16_hi(w);
+#endif
           }
           const float s0 = s[g][tt][2 * d], s1 = s[g][tt][2 * d + 1];
           if constexpr (C::LOSS) {
@@ -362,7 +385,11 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #endif
             mu_elem<BETA>(s0, x0, a.beta, n0, p0);
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
+#if NMFMU_ABLATE == 7
+            const uint32_t nh = __builtin_bit_cast(uint32_t, n0) ^ __builtin_bit_cast(uint32_t, n1);  // no cvt_pk
+#else
             const uint32_t nh = pack_bf16(n0, n1);
+#endif
             gnh[g][tt][d] = nh;
             if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
             if constexpr (C::TWO_ACC) {
@@ -438,31 +465,172 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     }
   };
 
-  // ---------------- main loop over the chunk's tiles (double-buffered panel, X one tile ahead)
+  // ---------------- phase-interleaved tile body for the 256-row tile (G = 2, beta == 1, bf16 operands).
+  // One wave per SIMD cannot rely on a sibling wave to cover its VALU stage, so the two 32-row groups are
+  // software-pipelined against each other inside the wave:
+  //     slot 1   GEMM1(g0)                       16 MFMA
+  //     slot 2   GEMM1(g1)  ||  elementwise(g0)  16 MFMA beside ~100 VALU (unpack, rcp, mul, cvt_pk)
+  //     slot 3   GEMM2(g0)  ||  elementwise(g1)
+  //     slot 4   GEMM2(g1)
+  // Slots are fenced with sched_barrier; inside a slot the MFMA / ds_read / VALU interleave is pinned.
+  auto compute_phased = [&](int t, int buf, const u32x4(&x)[G][NQ]) {
+    if constexpr (G == 2 && !X3 && !C::LOSS && !C::TWO_ACC) {
+      const char* sb = smem + buf * C::STAGE_BYTES;
+      constexpr int PF = 4;
+      f32x16 s[2][2];
+      uint32_t gnh[2][2][8];
+      // one elementwise pair (two columns of one row group): the VALU work that rides beside one MFMA
+      auto ew_pair = [&](auto gc, int pair) {
+        constexpr int g = decltype(gc)::value;
+        const int tt = pair >> 3, d = pair & 7;
+        const uint32_t w = x[g][2 * tt + (d >> 2)][d & 3];
+        float n0, n1, p0, p1;
+#if NMFMU_ABLATE == 1
+        gnh[g][tt][d] = __builtin_bit_cast(uint32_t, s[g][tt][2 * d]) ^ w;  // timing experiment: no elementwise
+#else
+        mu_elem<BETA>(s[g][tt][2 * d], bf16_lo(w), a.beta, n0, p0);
+        mu_elem<BETA>(s[g][tt][2 * d + 1], bf16_hi(w), a.beta, n1, p1);
+        gnh[g][tt][d] = pack_bf16(n0, n1);
+#endif
+      };
+      // GEMM1 of group g (16 MFMA, the two S^T tiles alternate); optionally one elementwise pair of group eg per MFMA
+      auto gemm1 = [&](auto gc, auto egc, auto with_ew) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int NSTEP = 2 * KS;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[g][tt][e] = (BETA == kEuc) ? 0.f : kEps;
+        u32x4 ring[PF];
+        auto off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P1HI + off(p));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+          const u32x4 ah = ring[step % PF];
+          s[g][step & 1] = mfma_bf16(ah, qh[g][step >> 1], s[g][step & 1]);
+          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P1HI + off(step + PF));
+          if constexpr (decltype(with_ew)::value) {
+            if (step * 16 / NSTEP != (step + 1) * 16 / NSTEP || NSTEP <= 16) {
+#pragma unroll
+              for (int pr = step * 16 / NSTEP; pr < (step + 1) * 16 / NSTEP; ++pr) ew_pair(egc, pr);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto gemm2 = [&](auto gc, auto egc, auto with_ew) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int NSTEP = RT * 4;
+        u32x4 ring[PF];
+        auto off = [&](int step) {
+          const int rt = step % RT, c = step / RT;
+          return rt * 4096 + b_row + b_off[c >> 1][c & 1];
+        };
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P2HI + off(p));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+          const int rt = step % RT, c = step / RT, tt = c >> 1, m2 = c & 1;
+          const u32x4 bh = ring[step % PF];
+          const u32x4 nh = {gnh[g][tt][4 * m2], gnh[g][tt][4 * m2 + 1], gnh[g][tt][4 * m2 + 2], gnh[g][tt][4 * m2 + 3]};
+          on[g][rt] = mfma_bf16(nh, bh, on[g][rt]);
+          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P2HI + off(step + PF));
+          if constexpr (decltype(with_ew)::value) {
+#pragma unroll
+            for (int pr = step * 16 / NSTEP; pr < (step + 1) * 16 / NSTEP; ++pr) ew_pair(egc, pr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      gemm1(I0{}, I0{}, std::false_type{});      // slot 1
+      gemm1(I1{}, I0{}, std::true_type{});       // slot 2: GEMM1(g1) || elementwise(g0)
+      gemm2(I0{}, I1{}, std::true_type{});       // slot 3: GEMM2(g0) || elementwise(g1)
+      gemm2(I1{}, I0{}, std::false_type{});      // slot 4
+    }
+  };
+  constexpr bool kPhased = NMFMU_PHASED && G == 2 && !X3 && !C::LOSS && !C::TWO_ACC;
+
+  // ---------------- main loop over the chunk's tiles: panel double-buffered in LDS (DMA one tile ahead), X two
+  // tiles ahead in VGPRs.  With LDS-DMA the tile ends with a COUNTED vmcnt and a raw s_barrier: the DMA of tile
+  // t+1 is issued before the X loads of tile t+2, so waiting until only the X loads are outstanding proves the DMA
+  // has landed while 2 tiles of X per wave stay in flight across the barrier (one tile in flight caps a CU at
+  // ~3 TB/s chip-wide by Little's law; the X stream is the kernel's only HBM traffic).
   if (t0 < t1) {
-    u32x4 xc[G][NQ], xn[G][NQ];
-    stage_issue(t0, 0);
-    load_x(t0, xc);
+    u32x4 xc[G][NQ], xn[G][NQ], xf[G][NQ];
+    constexpr bool kDeep = (STAGE == 1) && NMFMU_XDEPTH == 2 && NMFMU_ABLATE == 0;
+    constexpr int kXLoads = G * NQ;  // global_load instructions per X tile and lane
+    // Visit order: workgroup-dependent rotation of the chunk's tiles.  Every workgroup's X region starts on a
+    // 1 MiB-aligned boundary and all workgroups advance in lockstep, so without the rotation all 512 concurrent
+    // streams present identical low address bits to the HBM channel hash at every instant.
+    const int nt = t1 - t0;
+    const int stag = NMFMU_STAGGER ? (int)((blockIdx.x * 2654435761u) >> 8) % nt : 0;
+    auto tile_at = [&](int i) {
+      int r = i + stag;
+      if (r >= nt) r -= nt;
+      return t0 + r;
+    };
+    stage_issue(tile_at(0), 0);
+    load_x(tile_at(0), xc);
+    if (kDeep && nt > 1) load_x(tile_at(1), xn);
     stage_commit(0);
     __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const int buf = (t - t0) & 1;
-      const bool more = t + 1 < t1;
+    for (int i = 0; i < nt; ++i) {
+      const int t = tile_at(i);
+      const int buf = i & 1;
+      const bool more = i + 1 < nt;
 #if NMFMU_ABLATE == 2
-      if (more) load_x(t + 1, xn);
+      if (more) load_x(tile_at(i + 1), xn);
       compute(t, 0, xc);
 #elif NMFMU_ABLATE == 3
-      if (more) stage_issue(t + 1, buf ^ 1);
+      if (more) stage_issue(tile_at(i + 1), buf ^ 1);
       compute(t, buf, xc);
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
       continue;
-#else
+#elif NMFMU_ABLATE == 9   // keep the X traffic, drop the dependency: loads stay alive but compute uses the first tile's registers
       if (more) {
-        stage_issue(t + 1, buf ^ 1);
-        load_x(t + 1, xn);
+        stage_issue(tile_at(i + 1), buf ^ 1);
+        load_x(tile_at(i + 1), xn);
       }
       compute(t, buf, xc);
+      if (more) stage_commit(buf ^ 1);
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(xn[g][q]));
+      continue;
+#else
+      if constexpr (kDeep) {
+        const bool far = i + 2 < nt;
+        if (more) stage_issue(tile_at(i + 1), buf ^ 1);
+        if (far) load_x(tile_at(i + 2), xf);
+        if constexpr (kPhased) compute_phased(t, buf, xc);
+        else compute(t, buf, xc);
+        // vmcnt(kXLoads) when a far tile was issued (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+        if (far) __builtin_amdgcn_s_waitcnt((kXLoads & 15) | (7 << 4) | (15 << 8) | ((kXLoads >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            xc[g][q] = xn[g][q];
+            xn[g][q] = xf[g][q];
+          }
+        continue;
+      }
+      if (more) {
+        stage_issue(tile_at(i + 1), buf ^ 1);
+        load_x(tile_at(i + 1), xn);
+      }
+      if constexpr (kPhased) compute_phased(t, buf, xc);
+      else compute(t, buf, xc);
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
 #endif
