@@ -190,8 +190,9 @@ int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t ro
 int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, void* hu_hi, void* hu_lo, void* hut_hi,
                       void* hut_lo, int bl_pad, int rp_pad, void* stream);
 
-/* out[r] = sum over outer o and inner i of src[o][r][i]: the closed-form beta == 1 denominators (nmf.py:122-131). */
-int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* out, void* stream);
+/* out[r] = sum over outer o and inner i of src[o][r][i]: the closed-form beta == 1 denominators (nmf.py:122-131).
+ * part: rank * 128 floats of scratch (deterministic two-stage sum). */
+int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* part, float* out, void* stream);
 
 /* nmf.py:78-92 for W (channels, rank, taps) in place; num/den fp32 [c_pad][rp_pad]; kl_den[rank] or den. */
 int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* num, const float* den,

@@ -132,16 +132,27 @@ __global__ void __launch_bounds__(256) conv_unfold_kernel(const float* __restric
   }
 }
 
-// out[r] = sum_{o, i} src[(o * R + r) * inner + i]   (one workgroup per r, fixed order)
-__global__ void __launch_bounds__(256) rank_sums_kernel(const float* __restrict__ src, int outer, int R, int inner,
-                                                        float* __restrict__ out) {
+// out[r] = sum_{o, i} src[(o * R + r) * inner + i].  Two stages, fixed order (deterministic): grid (R, kRankChunks)
+// partial sums over contiguous `inner` runs, then one small block per r.
+constexpr int kRankChunks = 128;
+
+__global__ void __launch_bounds__(256) rank_sums_partial_kernel(const float* __restrict__ src, int outer, int R, int inner,
+                                                                float* __restrict__ part) {
   __shared__ float red[256];
-  const int r = blockIdx.x;
+  const int r = blockIdx.x, ch = blockIdx.y;
   float s = 0.f;
-  const int64_t n = (int64_t)outer * inner;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t o = i / inner, ii = i % inner;
-    s += src[((size_t)o * R + r) * inner + ii];
+  for (int o = ch; o < outer; o += kRankChunks) {          // one (o, r) run = `inner` contiguous floats
+    const float* p = src + ((size_t)o * R + r) * inner;
+    for (int i = threadIdx.x; i < inner; i += 256) s += p[i];
+  }
+  if (outer < kRankChunks) {                                // few long runs (H: outer = batch): split the run instead
+    s = 0.f;
+    for (int o = 0; o < outer; ++o) {
+      const float* p = src + ((size_t)o * R + r) * inner;
+      const int per = (inner + kRankChunks - 1) / kRankChunks;
+      const int lo = ch * per, hi = min(inner, lo + per);
+      for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -149,7 +160,18 @@ __global__ void __launch_bounds__(256) rank_sums_kernel(const float* __restrict_
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[r] = red[0];
+  if (threadIdx.x == 0) part[r * kRankChunks + ch] = red[0];
+}
+
+__global__ void __launch_bounds__(128) rank_sums_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+  __shared__ float red[kRankChunks];
+  red[threadIdx.x] = part[blockIdx.x * kRankChunks + threadIdx.x];
+  __syncthreads();
+  for (int o = kRankChunks / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 __device__ __forceinline__ float mu_update(float f, float neg, float pos, bool closed_form, float l1, float l2,
@@ -178,23 +200,33 @@ __global__ void __launch_bounds__(256) conv_apply_w_kernel(float* __restrict__ W
 }
 
 // H (B, R, Lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)], Y fp32 [rp_pad][bl_pad].
+// Block = 64 consecutive j x 4 tap groups (coalesced 256-byte reads along j); the four partial sums are combined
+// through LDS in a fixed order.
 __global__ void __launch_bounds__(256) conv_fold_apply_h_kernel(float* __restrict__ H, int B, int R, int Lh, int T,
                                                                 const float* __restrict__ ynum,
                                                                 const float* __restrict__ yden,
                                                                 const float* __restrict__ kl_den, int bl_pad, float l1,
                                                                 float l2, float gamma) {
+  __shared__ float red[2][4][64];
   const int L = Lh + T - 1;
-  const int64_t n = (int64_t)B * R * Lh;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int jx = (int)(i % Lh), r = (int)((i / Lh) % R), b = (int)(i / ((int64_t)Lh * R));
+  const int jl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int jblocks = (Lh + 63) / 64;
+  const int jb = blockIdx.x % jblocks, r = (blockIdx.x / jblocks) % R, b = blockIdx.x / (jblocks * R);
+  const int jx = jb * 64 + jl;
+  float neg = 0.f, pos = 0.f;
+  if (jx < Lh) {
     const size_t base = (size_t)r * T * bl_pad + (size_t)b * L + jx;
-    float neg = 0.f, pos = 0.f;
-    for (int t = 0; t < T; ++t) neg += ynum[base + (size_t)t * bl_pad + t];
-    if (kl_den) {
-      pos = kl_den[r];
-    } else {
-      for (int t = 0; t < T; ++t) pos += yden[base + (size_t)t * bl_pad + t];
-    }
+    for (int t = tg; t < T; t += 4) neg += ynum[base + (size_t)t * bl_pad + t];
+    if (!kl_den)
+      for (int t = tg; t < T; t += 4) pos += yden[base + (size_t)t * bl_pad + t];
+  }
+  red[0][tg][jl] = neg;
+  red[1][tg][jl] = pos;
+  __syncthreads();
+  if (tg == 0 && jx < Lh) {
+    neg = (red[0][0][jl] + red[0][1][jl]) + (red[0][2][jl] + red[0][3][jl]);
+    pos = kl_den ? kl_den[r] : (red[1][0][jl] + red[1][1][jl]) + (red[1][2][jl] + red[1][3][jl]);
+    const size_t i = ((size_t)b * R + r) * Lh + jx;
     H[i] = mu_update(H[i], neg, pos, kl_den != nullptr, l1, l2, gamma);
   }
 }
@@ -269,9 +301,11 @@ int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, voi
   return (int)hipGetLastError();
 }
 
-int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* out, void* stream) {
-  if (!src || !out || outer <= 0 || rank <= 0 || inner <= 0) return NMFMU_ERR_ARG;
-  hipLaunchKernelGGL(rank_sums_kernel, dim3(rank), dim3(256), 0, S(stream), src, outer, rank, inner, out);
+int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* part, float* out, void* stream) {
+  if (!src || !out || !part || outer <= 0 || rank <= 0 || inner <= 0) return NMFMU_ERR_ARG;
+  hipLaunchKernelGGL(rank_sums_partial_kernel, dim3(rank, kRankChunks), dim3(256), 0, S(stream), src, outer, rank, inner,
+                     part);
+  hipLaunchKernelGGL(rank_sums_final_kernel, dim3(rank), dim3(kRankChunks), 0, S(stream), part, out);
   return (int)hipGetLastError();
 }
 
@@ -287,8 +321,8 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
 int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
                             const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream) {
   if (!h || !y_num || (!y_den && !kl_den) || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
-  const int64_t n = (int64_t)batch * rank * lh;
-  hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+  const int grid = batch * rank * ((lh + 63) / 64);
+  hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
                      y_num, y_den, kl_den, bl_pad, l1, l2, gamma);
   return (int)hipGetLastError();
 }

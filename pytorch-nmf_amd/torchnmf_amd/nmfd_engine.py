@@ -93,6 +93,7 @@ class ConvMU:
         self.y_den = None if self.kl else torch.empty(rpp * blp, dtype=torch.float32, device=dev)
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
+        self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
         self.loss_part = torch.empty((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self.refresh_images()
@@ -115,15 +116,15 @@ class ConvMU:
         RT = self.R * self.T
         self._pack2d(self.W, self.C, RT, 1, RT, 0, 1, 1, 0, self.c_pad, self.rp_pad, None, self.wm, None)
         self._pack2d(self.W, RT, self.C, 1, 1, 0, 1, RT, 0, self.rp_pad, self.c_pad, None, self.wmt, None)
-        _capi.check(self.lib.nmfmu_rank_sums(self.W.data_ptr(), self.C, self.R, self.T, self.sum_w.data_ptr(),
-                                             _stream()), 'nmfmu_rank_sums')
+        _capi.check(self.lib.nmfmu_rank_sums(self.W.data_ptr(), self.C, self.R, self.T, self.sum_part.data_ptr(),
+                                             self.sum_w.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
     def _pack_h(self):
         _capi.check(self.lib.nmfmu_conv_unfold(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
                                                _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), self.bl_pad,
                                                self.rp_pad, _stream()), 'nmfmu_conv_unfold')
-        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_h.data_ptr(),
-                                             _stream()), 'nmfmu_rank_sums')
+        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_part.data_ptr(),
+                                             self.sum_h.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
     def refresh_images(self):
         self._pack_w()
