@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
     ap.add_argument('--taps', type=int, default=400)
+    ap.add_argument('--force-dist', action='store_true', help='run the sharded (all-reduce) path even at world size 1')
     return ap.parse_args()
 
 
@@ -144,7 +145,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     group = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)   # RCCL
@@ -247,14 +248,14 @@ def main():
             'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)', 'data': 'synthetic',
             'config': {'workload': f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
                                    f'H replicated, 1 all-reduce/iter' if world > 1 else
-                                   f'NMF {N}x{C} rank={R} beta={beta:g} (BASELINE configs[1])',
+                                   f'NMF {N}x{C} rank={R} beta={beta:g}' + (' (BASELINE configs[1])' if (N, C, R, beta) == (4096, 65536, 128, 1.0) else ''),
                        'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
                        'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -400,3 +400,32 @@ def test_nmfd_medium_against_oracle(dev, prec, tol):
     ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
     print(f'nmfd {prec}: relW={ew:.2e} relH={eh:.2e}')
     assert n == nr and ew < tol and eh < tol
+
+
+# ----------------------------------------------------------------------------------------------------------
+# column-sharded path on the real backend (RCCL, world_size 1: the same kernels and collectives as N > 1)
+# ----------------------------------------------------------------------------------------------------------
+def test_sharded_path_world1_rccl(dev):
+    import os
+    import socket
+    import torch.distributed as dist
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        g = load_golden('g1_nmf_small')
+        V, W0, H0 = t(g['V']), t(g['W0']), t(g['H0'])
+        for beta, alpha in ((1, 0.0), (2, 0.1), (0.5, 0.0)):
+            m = NMF(W=W0, H=H0).to(dev)
+            n = m.fit(V.to(dev), beta, 1e-4, 60, alpha=alpha, l1_ratio=0.5, precision='bf16x3',
+                      process_group=dist.group.WORLD)
+            Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 60, alpha, 0.5)
+            assert n == nr
+            assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+    finally:
+        dist.destroy_process_group()
