@@ -220,6 +220,9 @@ def main():
                 'avg_launch_ms': round(avg_ms, 5),
                 'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
                 'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
+                'note': 'W-step launches carry the MU apply (nmf.py:78-92) in their epilogue when the contraction is '
+                        'not split; H-step launches are the bare MFMA main loop + slab stores',
+                'achieved_main_loop_only': round(flops_per_launch / (sum(spans['h']) / len(spans['h']) * 1e-3) / 1e12, 2),
                 'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_bytes_per_launch': int(bytes_per_launch)}}

@@ -117,6 +117,12 @@ int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precisio
  */
 int nmfmu_mu_partial(const nmfmu_step* st, void* stream);
 
+/* nmfmu_mu_step: one complete single-device half-step = nmfmu_mu_partial + nmfmu_mu_apply.  When the contraction is
+ * not split (nsplit == 1) and beta == 1 the apply runs inside the fused kernel's epilogue (no slab round trip).
+ * kl_den: column sums of the panel (beta == 1), else ignored.  phase: 0 = everything, 1 = only the fused kernel,
+ * 2 = only what follows it (lets a caller bracket the dominant kernel with events). */
+int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream);
+
 /* nmfmu_slab_reduce: num_out = sum_s slab_num[s] (and den_out likewise unless NULL).  Used by the column-sharded
  * multi-GPU path so that one all-reduce carries [owner.rows_pad x r_pad] floats. */
 int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream);

@@ -24,6 +24,7 @@ struct ApplyArgs {
 int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
                   int k_pad, uint32_t* flags, int G, hipStream_t s);
 int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s);
+int launch_colsum_finalize(const float* part, int nblk, int r_pad, float* out, hipStream_t s);
 int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, hipStream_t s);
 int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s);
 int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int kind, double* part, double* out,

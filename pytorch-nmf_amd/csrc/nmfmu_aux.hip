@@ -248,6 +248,11 @@ int launch_apply_r(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   return launch_apply_rr<R_PAD, 64>(a, x3, pack_only, s);
 }
 
+int launch_colsum_finalize(const float* part, int nblk, int r_pad, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(r_pad / 32), dim3(256), 0, s, part, nblk, r_pad, out);
+  return (int)hipGetLastError();
+}
+
 int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   switch (r_pad) {
     case 32: return launch_apply_r<32>(a, x3, pack_only, s);

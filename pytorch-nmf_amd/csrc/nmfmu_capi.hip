@@ -16,7 +16,8 @@ namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s) {
+int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
+                   const float* fuse_kl_den = nullptr) {
   if (!st || !st->xp || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
@@ -43,6 +44,17 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   a.nsplit = st->nsplit;
   a.tiles_per_split = (a.ktiles + st->nsplit - 1) / st->nsplit;
   a.beta = st->beta;
+  a.fuse_apply = 0;
+  if (fuse_kl_den) {  // beta == 1, nsplit == 1: apply in the epilogue
+    a.fuse_apply = 1;
+    a.rank = st->rank;
+    a.f = st->owner.f;
+    a.kl_den = fuse_kl_den;
+    a.o1_hi = static_cast<uint16_t*>(st->owner.p1_hi), a.o1_lo = static_cast<uint16_t*>(st->owner.p1_lo);
+    a.o2_hi = static_cast<uint16_t*>(st->owner.p2_hi), a.o2_lo = static_cast<uint16_t*>(st->owner.p2_lo);
+    a.colsum_part = st->owner.colsum_part;
+    a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
+  }
   if (mode == kModeMU) {
     if (!a.slab_num || !a.p2_hi || (x3 && !a.p2_lo)) return NMFMU_ERR_ARG;
     if (kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
@@ -143,6 +155,26 @@ int nmfmu_mu_partial(const nmfmu_step* st, void* stream) {
   if (!st) return NMFMU_ERR_ARG;
   if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
   return fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream));
+}
+
+int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream) {
+  if (!st || phase < 0 || phase > 2) return NMFMU_ERR_ARG;
+  if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
+  if (kl && !kl_den) return NMFMU_ERR_ARG;
+  const bool fuse = kl && st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum && st->owner.colsum_part;
+  int e = 0;
+  if (phase != 2) {  // the fused kernel (with nmf.py:78-92 in its epilogue when the workgroup owns whole rows)
+    e = fuse ? fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream), kl_den)
+             : nmfmu_mu_partial(st, stream);
+    if (e) return e;
+  }
+  if (phase != 1) {  // what is left: the column-sum finalize, or the whole apply
+    e = fuse ? launch_colsum_finalize(st->owner.colsum_part, st->owner.rows_pad / st->block_rows, st->r_pad,
+                                      st->owner.colsum, S(stream))
+             : nmfmu_mu_apply(st, nullptr, nullptr, 0, kl ? kl_den : nullptr, stream);
+  }
+  return e;
 }
 
 int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream) {

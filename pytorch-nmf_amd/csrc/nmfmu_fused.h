@@ -86,6 +86,17 @@ struct FusedArgs {
   int M, K;               // logical sizes (loss masking only)
   int M_pad, ktiles, nsplit, tiles_per_split;
   float beta;
+  // fused apply (beta == 1, nsplit == 1): the epilogue performs nmf.py:78-92 and re-emits the owner's images
+  int fuse_apply;
+  int rank;               // logical rank (row pitch of f)
+  float* f;               // owner fp32 master [M][rank]
+  const float* kl_den;    // [R_PAD] column sums of the panel
+  uint16_t* o1_hi;        // owner images to refresh (same buffers a1_* were read from)
+  uint16_t* o1_lo;
+  uint16_t* o2_hi;
+  uint16_t* o2_lo;
+  float* colsum_part;     // [M_pad / BM][R_PAD]
+  float l1, l2, gamma;
 };
 
 // G = 32-row groups per wave: G = 1 -> 128-row workgroup tile, 2 waves/SIMD; G = 2 -> 256-row tile, every LDS
@@ -652,17 +663,117 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     if (tid == 0) a.loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   } else {
     // accumulator register e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column 32*rt + j
+    bool fused_done = false;
+    if constexpr (BETA == kKL) {
+      if (a.fuse_apply) {
+        // ---- nmf.py:78-92 in the epilogue (the workgroup owns complete rows: nsplit == 1).  The new factor values
+        // replace the accumulators, go to the fp32 master, to the transposed image (8-byte pieces straight from
+        // registers) and, through a wave-private LDS tile, to the row-major image (16-byte pieces).
+        fused_done = true;
+        constexpr int LDT = R_PAD;                     // wave tile [32][R_PAD] fp32 = 128*R_PAD bytes per wave
+        float* tile = reinterpret_cast<float*>(smem) + wave * (32 * LDT);
+        float den[RT], csum[RT];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const size_t slab = ((size_t)ks * a.M_pad + (size_t)mb * BM + wave * (32 * G) + 32 * g) * R_PAD;
+        for (int rt = 0; rt < RT; ++rt) {
+          den[rt] = a.kl_den[rt * 32 + j];
+          csum[rt] = 0.f;
+        }
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
+        for (int g = 0; g < G; ++g) {
+          const int mrow0 = mb * BM + wave * (32 * G) + 32 * g;  // first owner row of this group
+          // all master loads first (independent, fully pipelined), then the dependent compute + stores
+          float fold[RT][16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * hl;
-          const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
-          a.slab_num[idx] = on[g][rt][e];
-          if constexpr (C::TWO_ACC) a.slab_den[idx] = op[g][rt][e];
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = rt * 32 + j;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+              fold[rt][e] = (row < a.M && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = rt * 32 + j;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+              float fv = fold[rt][e];
+              if (row < a.M && r < a.rank) {
+                const float neg = fmaxf(on[g][rt][e], 0.f) + kEps;
+                float pos = den[rt];
+                if (a.l1 > 0.f) pos += a.l1;
+                if (a.l2 > 0.f) pos += a.l2 * fv;
+                float mult = neg / pos;
+                if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+                fv *= mult;
+                a.f[(size_t)row * a.rank + r] = fv;
+              }
+              on[g][rt][e] = fv;
+              csum[rt] += fv;
+              tile[((e & 3) + 8 * (e >> 2) + 4 * hl) * LDT + r] = fv;
+            }
+            // transposed image: 4 consecutive owner rows of column r = 8 bytes
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const float v0 = on[g][rt][4 * q4], v1 = on[g][rt][4 * q4 + 1], v2 = on[g][rt][4 * q4 + 2],
+                          v3 = on[g][rt][4 * q4 + 3];
+              const uint32_t h0 = pack_bf16(v0, v1), h1 = pack_bf16(v2, v3);
+              const int64_t off = p2_offset(mrow0 + 8 * q4 + 4 * hl, r, R_PAD);
+              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.o2_hi) + off) = make_uint2(h0, h1);
+              if constexpr (X3) {
+                const uint32_t l0 = pack_bf16(v0 - bf16_lo(h0), v1 - bf16_hi(h0));
+                const uint32_t l1 = pack_bf16(v2 - bf16_lo(h1), v3 - bf16_hi(h1));
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.o2_lo) + off) = make_uint2(l0, l1);
+              }
+            }
+          }
+          __syncthreads();
+          // row-major image from the LDS tile: 32 rows x R_PAD/8 sixteen-byte slots per wave
+          constexpr int SP = R_PAD / 8;
+#pragma unroll
+          for (int i = 0; i < (32 * SP) / 64; ++i) {
+            const int chunk = i * 64 + lane, rl = chunk / SP, slot = chunk % SP;
+            const float* src = tile + rl * LDT + slot * 8;
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x0 = src[2 * q], x1 = src[2 * q + 1];
+              const uint32_t h = pack_bf16(x0, x1);
+              hi[q] = h;
+              lo[q] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
+            }
+            const int64_t off = p1_offset(mrow0 + rl, slot * 8, R_PAD);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + off) = hi;
+            if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_lo) + off) = lo;
+          }
+          __syncthreads();
+        }
+        // partial column sums of this workgroup's rows: lane halves, then the four waves (fixed order)
+        float* red = reinterpret_cast<float*>(smem);  // [4][R_PAD]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float tot = csum[rt] + __shfl_xor(csum[rt], 32, 64);
+          if (hl == 0) red[wave * R_PAD + rt * 32 + j] = tot;
+        }
+        __syncthreads();
+        for (int r = tid; r < R_PAD; r += 256)
+          a.colsum_part[(size_t)mb * R_PAD + r] = (red[r] + red[R_PAD + r]) + (red[2 * R_PAD + r] + red[3 * R_PAD + r]);
+      }
+    }
+    if (!fused_done) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const size_t slab = ((size_t)ks * a.M_pad + (size_t)mb * BM + wave * (32 * G) + 32 * g) * R_PAD;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * hl;
+            const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
+            a.slab_num[idx] = on[g][rt][e];
+            if constexpr (C::TWO_ACC) a.slab_den[idx] = op[g][rt][e];
+          }
         }
       }
     }

@@ -76,6 +76,9 @@ class HipBackend:
     def mu_partial(self, st: 'StepBuf'):
         _capi.check(self.lib.nmfmu_mu_partial(C.byref(st.struct), self.stream()), 'nmfmu_mu_partial')
 
+    def mu_step(self, st: 'StepBuf', kl_den, phase=0):
+        _capi.check(self.lib.nmfmu_mu_step(C.byref(st.struct), _ptr(kl_den), phase, self.stream()), 'nmfmu_mu_step')
+
     def slab_reduce(self, st, num_out, den_out):
         _capi.check(self.lib.nmfmu_slab_reduce(C.byref(st.struct), _ptr(num_out), _ptr(den_out), self.stream()),
                     'nmfmu_slab_reduce')
@@ -252,6 +255,19 @@ class DenseMU:
         bad, mn = (int(x) for x in fl.tolist())
         return bool(bad), mn == 0
 
+    def _local_step(self, st, kl_den, tag):
+        """A complete single-device half-step (nmfmu_mu_step); with a timer attached the fused kernel is bracketed."""
+        if not hasattr(self.be, 'mu_step'):          # stand-in test backend
+            self.be.mu_partial(st)
+            self.be.mu_apply(st, None, None, 0, kl_den)
+        elif self.timer is None:
+            self.be.mu_step(st, kl_den, 0)
+        else:
+            self.timer.mark(tag + '<')
+            self.be.mu_step(st, kl_den, 1)
+            self.timer.mark(tag + '>')
+            self.be.mu_step(st, kl_den, 2)
+
     def _partial(self, st, tag):
         if self.timer is None:
             self.be.mu_partial(st)
@@ -262,17 +278,15 @@ class DenseMU:
 
     def w_step(self):
         """nmf.py:367-378.  Local even when sharded: W rows belong to this rank's columns."""
-        st = self.step_w
-        self._partial(st, 'w')
-        self.be.mu_apply(st, None, None, 0, self.fH.colsum if self.kl else None)
+        self._local_step(self.step_w, self.fH.colsum if self.kl else None, 'w')
 
     def h_step(self):
         """nmf.py:380-391, with the freshly updated W."""
         st = self.step_h
-        self._partial(st, 'h')
         if self.group is None:
-            self.be.mu_apply(st, None, None, 0, self.fW.colsum if self.kl else None)
+            self._local_step(st, self.fW.colsum if self.kl else None, 'h')
             return
+        self._partial(st, 'h')
         import torch.distributed as dist
         num = self.xbuf[:st.plane]
         tail = self.xbuf[st.plane:]
