@@ -398,6 +398,8 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
 #if NMFMU_ABLATE == 7
             const uint32_t nh = __builtin_bit_cast(uint32_t, n0) ^ __builtin_bit_cast(uint32_t, n1);  // no cvt_pk
+#elif NMFMU_ABLATE == 10   // truncating pack: one v_perm_b32 instead of v_cvt_pk_bf16_f32
+            const uint32_t nh = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, n1), __builtin_bit_cast(uint32_t, n0), 0x07060302u);
 #else
             const uint32_t nh = pack_bf16(n0, n1);
 #endif
