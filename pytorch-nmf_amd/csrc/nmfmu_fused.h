@@ -44,7 +44,7 @@
 #define NMFMU_ORDER 1   // 1: interleave accumulators in both GEMMs
 #endif
 #ifndef NMFMU_PHASED
-#define NMFMU_PHASED 1  // phase-interleaved schedule for the 256-row tile
+#define NMFMU_PHASED 0  // 1: phase-interleaved schedule for the 256-row tile (measured slower than the shared-read body)
 #endif
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
@@ -680,8 +680,8 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
           den[rt] = a.kl_den[rt * 32 + j];
           csum[rt] = 0.f;
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
+        auto apply_group = [&](auto gc) {
+          constexpr int g = decltype(gc)::value;
           const int mrow0 = mb * BM + wave * (32 * G) + 32 * g;  // first owner row of this group
           // all master loads first (independent, fully pipelined), then the dependent compute + stores
           float fold[RT][16];
@@ -711,15 +711,15 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
                 fv *= mult;
                 a.f[(size_t)row * a.rank + r] = fv;
               }
-              on[g][rt][e] = fv;
+              fold[rt][e] = fv;   // (not written back into the accumulator array: that forced G = 2 into scratch)
               csum[rt] += fv;
               tile[((e & 3) + 8 * (e >> 2) + 4 * hl) * LDT + r] = fv;
             }
             // transposed image: 4 consecutive owner rows of column r = 8 bytes
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-              const float v0 = on[g][rt][4 * q4], v1 = on[g][rt][4 * q4 + 1], v2 = on[g][rt][4 * q4 + 2],
-                          v3 = on[g][rt][4 * q4 + 3];
+              const float v0 = fold[rt][4 * q4], v1 = fold[rt][4 * q4 + 1], v2 = fold[rt][4 * q4 + 2],
+                          v3 = fold[rt][4 * q4 + 3];
               const uint32_t h0 = pack_bf16(v0, v1), h1 = pack_bf16(v2, v3);
               const int64_t off = p2_offset(mrow0 + 8 * q4 + 4 * hl, r, R_PAD);
               *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.o2_hi) + off) = make_uint2(h0, h1);
@@ -750,7 +750,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
             if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_lo) + off) = lo;
           }
           __syncthreads();
-        }
+        };
+        apply_group(std::integral_constant<int, 0>{});
+        if constexpr (G == 2) apply_group(std::integral_constant<int, 1>{});
         // partial column sums of this workgroup's rows: lane halves, then the four waves (fixed order)
         float* red = reinterpret_cast<float*>(smem);  // [4][R_PAD]
 #pragma unroll

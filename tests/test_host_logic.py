@@ -162,3 +162,22 @@ def test_fit_loop_validation_and_verbose(cpu_engine, capsys):
         m.fit(V)
     with pytest.raises(ValueError):
         m.fit(torch.rand(20, 30), precision='fp64')
+
+
+def test_fused_kernels_do_not_spill_to_scratch(tmp_path):
+    """Guard: every instantiation of the rank-128 fused kernel must keep its accumulators in registers
+    (a dynamically indexed register array silently moves to scratch memory and runs ~6x slower)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', 'nmfmu_inst_r128.hip')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Rpass-analysis=kernel-resource-usage',
+                        '-c', src, '-o', str(tmp_path / 'x.o')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = r.stderr.split('Function Name: ')[1:]
+    assert len(blocks) >= 32
+    for b in blocks:
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b)
+        assert m and int(m.group(1)) == 0, b.split('\n')[0]
