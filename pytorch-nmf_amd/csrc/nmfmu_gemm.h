@@ -108,28 +108,45 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     const int buf = kt & 1;
     if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
     const char* sb = smem + buf * C::STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
+    u32x4 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+    auto load_frags = [&](int ks, int fb) {
       const int so = ((2 * ks + hl) << 4) ^ swz;
-      u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = ld16(sb + a_rowoff + i * 4096 + so);
-        bh[i] = ld16(sb + C::NPL * C::TILE + b_rowoff + i * 4096 + so);
+        ah[fb][i] = ld16(sb + a_rowoff + i * 4096 + so);
+        bh[fb][i] = ld16(sb + C::NPL * C::TILE + b_rowoff + i * 4096 + so);
         if constexpr (X3) {
-          al[i] = ld16(sb + C::TILE + a_rowoff + i * 4096 + so);
-          bl[i] = ld16(sb + 3 * C::TILE + b_rowoff + i * 4096 + so);
+          al[fb][i] = ld16(sb + C::TILE + a_rowoff + i * 4096 + so);
+          bl[fb][i] = ld16(sb + 3 * C::TILE + b_rowoff + i * 4096 + so);
         }
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int fb = ks & 1;
+      if (ks + 1 < 4) load_frags(ks + 1, fb ^ 1);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           if constexpr (X3) {
-            acc[mi][ni] = mfma_bf16(al[mi], bh[ni], acc[mi][ni]);
-            acc[mi][ni] = mfma_bf16(ah[mi], bl[ni], acc[mi][ni]);
+            acc[mi][ni] = mfma_bf16(al[fb][mi], bh[fb][ni], acc[mi][ni]);
+            acc[mi][ni] = mfma_bf16(ah[fb][mi], bl[fb][ni], acc[mi][ni]);
           }
-          acc[mi][ni] = mfma_bf16(ah[mi], bh[ni], acc[mi][ni]);
+          acc[mi][ni] = mfma_bf16(ah[fb][mi], bh[fb][ni], acc[mi][ni]);
+        }
+    }
+    {
+      constexpr int RD = 4 * C::NPL, MF = X3 ? 3 : 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+          if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
         }
     }
     __syncthreads();

@@ -99,22 +99,28 @@ __global__ void __launch_bounds__(256) conv_unfold_kernel(const float* __restric
     const int64_t k = tr ? i - n_hu : i;
     float v[8];
     size_t o;
-    if (!tr) {  // row (b,l), 8 consecutive (r,t)
+    if (!tr) {  // row (b,l), 8 consecutive (r,t): one division, then (r,t) advances incrementally
       const int row = (int)(k / (rp_pad / 8)), c0 = (int)(k % (rp_pad / 8)) * 8;
       const int b = row / L, l = row % L;
+      int r = c0 / T, t = c0 - r * T;
+      const bool rowok = row < B * L;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int rp = c0 + e, r = rp / T, t = rp % T, jx = l - t;
-        v[e] = (row < B * L && rp < R * T && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+        const int jx = l - t;
+        v[e] = (rowok && r < R && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+        if (++t == T) t = 0, ++r;
       }
       o = (size_t)row * rp_pad + c0;
     } else {    // row (r,t), 8 consecutive (b,l)
       const int row = (int)(k / (bl_pad / 8)), c0 = (int)(k % (bl_pad / 8)) * 8;
       const int r = row / T, t = row % T;
+      int b = c0 / L, l = c0 - b * L;
+      const bool rowok = row < R * T;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int col = c0 + e, b = col / L, l = col % L, jx = l - t;
-        v[e] = (row < R * T && col < B * L && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+        const int jx = l - t;
+        v[e] = (rowok && b < B && jx >= 0 && jx < Lh) ? H[((size_t)b * R + r) * Lh + jx] : 0.f;
+        if (++l == L) l = 0, ++b;
       }
       o = (size_t)row * bl_pad + c0;
     }
