@@ -49,6 +49,9 @@
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
 #endif
+#ifndef NMFMU_DMA_ASM
+#define NMFMU_DMA_ASM 1  // issue the LDS-DMA from inline asm (keeps hipcc's counted lgkmcnt waits)
+#endif
 #ifndef NMFMU_STAGGER
 #define NMFMU_STAGGER 0  // (measured: no gain on MI355X) rotate each workgroup's tile visiting order (HBM channel de-phasing)
 #endif
@@ -281,8 +284,22 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       for (int p = 0; p < C::PASSES; ++p) {
         if constexpr (STAGE == 1) {
           char* dst = smem + buf * C::STAGE_BYTES + im * IMG + p * 4096 + wave * 1024;  // wave-uniform base
+#if NMFMU_DMA_ASM
+          // Issued from inline asm on purpose: while hipcc knows an LDS-DMA is in flight it turns every LDS wait
+          // into lgkmcnt(0), which serialises the operand prefetch rings.  Completion is waited for explicitly
+          // (vmcnt(0) before the tile's barrier, see the main loop).
+          const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+              (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst));
+          unsigned keep;
+          asm volatile(
+              "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+              : "=&s"(keep)
+              : "v"(src + p * 4096), "s"(lds_addr)
+              : "memory");
+#else
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 4096),
                                            (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+#endif
         } else {
           st[im * C::PASSES + p] = ld16(src + p * 4096);
         }
@@ -591,6 +608,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     load_x(tile_at(0), xc);
     if (kDeep && nt > 1) load_x(tile_at(1), xn);
     stage_commit(0);
+#if NMFMU_DMA_ASM
+    if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+#endif
     __syncthreads();
     for (int i = 0; i < nt; ++i) {
       const int t = tile_at(i);
@@ -645,6 +665,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       if constexpr (kPhased) compute_phased(t, buf, xc);
       else compute(t, buf, xc);
       if (more) stage_commit(buf ^ 1);
+#if NMFMU_DMA_ASM
+      if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0): the asm DMA landed
+#endif
       __syncthreads();
 #endif
 #pragma unroll
