@@ -49,6 +49,15 @@
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
 #endif
+#ifndef NMFMU_X_NT
+#define NMFMU_X_NT 1  // non-temporal loads for the X stream (read once; keeps the factor panel resident in L2)
+#endif
+#ifndef NMFMU_G2C
+#define NMFMU_G2C 0  // 1: chunk-fused tile body for the 256-row tile (8.1 instr/MFMA but measured slower: 0.19 vs 0.17 ms)
+#endif
+#ifndef NMFMU_XSINGLE
+#define NMFMU_XSINGLE 1  // one X register buffer, refilled mid-tile after its last use (0: double buffer)
+#endif
 #ifndef NMFMU_DMA_ASM
 #define NMFMU_DMA_ASM 1  // issue the LDS-DMA from inline asm (keeps hipcc's counted lgkmcnt waits)
 #endif
@@ -264,7 +273,13 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) x[g][q] = ld16(p + (g * NQ + q) * 1024);
+      for (int q = 0; q < NQ; ++q) {
+#if NMFMU_X_NT
+        x[g][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (g * NQ + q) * 1024));
+#else
+        x[g][q] = ld16(p + (g * NQ + q) * 1024);
+#endif
+      }
   };
 
   // ---- panel staging: every image tile is one contiguous, pre-swizzled block in HBM
@@ -276,6 +291,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     if constexpr (X3) img_src[C::NPL + 1] = reinterpret_cast<const char*>(a.p2_lo);
   }
   u32x4 st[STAGE == 0 ? C::NIMG * C::PASSES : 1];
+  const unsigned lds_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+  const unsigned wave_lds = (unsigned)wave * 1024u;
   auto stage_issue = [&](int t, int buf) {
 #pragma unroll
     for (int im = 0; im < C::NIMG; ++im) {
@@ -287,15 +305,14 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #if NMFMU_DMA_ASM
           // Issued from inline asm on purpose: while hipcc knows an LDS-DMA is in flight it turns every LDS wait
           // into lgkmcnt(0), which serialises the operand prefetch rings.  Completion is waited for explicitly
-          // (vmcnt(0) before the tile's barrier, see the main loop).
-          const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
-              (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst));
-          unsigned keep;
-          asm volatile(
-              "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-              : "=&s"(keep)
-              : "v"(src + p * 4096), "s"(lds_addr)
-              : "memory");
+          // (vmcnt(0) before the tile's barrier, see the main loop).  M0 = LDS byte address of the wave's 1 KiB
+          // piece (integer arithmetic on the workgroup's LDS base; M0 is clobbered, nothing else uses it here).
+          (void)dst;
+          const unsigned lds_addr = lds_base + (unsigned)(buf * C::STAGE_BYTES + im * IMG + p * 4096) + wave_lds;
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       :
+                       : "v"(src + p * 4096), "s"(lds_addr)
+                       : "memory", "m0");
 #else
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 4096),
                                            (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
@@ -316,18 +333,18 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     }
   };
 
-  auto compute = [&](int t, int buf, const u32x4(&x)[G][NQ]) {
+  f32x16 epsv;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) epsv[e] = (BETA == kEuc) ? 0.f : kEps;
+
+  auto compute = [&](int t, int buf, u32x4(&x)[G][NQ], int t_next) {
     const char* sb = smem + buf * C::STAGE_BYTES;
     // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank.
     // The panel operands are fetched through a PF-deep register ring so that PF-1 ds_read_b128 are always in
     // flight behind the MFMA that is issuing (hipcc otherwise emits read -> lgkmcnt(0) -> mfma, one at a time).
+    // The accumulators are seeded with eps through the C operand of each chain's first MFMA (seed tile `epsv`,
+    // loop invariant) instead of being re-initialised with 16 moves per tile.
     f32x16 s[G][2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[g][tt][e] = (BETA == kEuc) ? 0.f : kEps;
     {
       constexpr int NSTEP = 2 * KS;
       constexpr int PF = NSTEP < 4 ? NSTEP : 4;
@@ -356,10 +373,12 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if constexpr (X3) {
-            s[g][tt] = mfma_bf16(al, qh[g][kk], s[g][tt]);
+            s[g][tt] = mfma_bf16(al, qh[g][kk], kk == 0 ? epsv : s[g][tt]);
             s[g][tt] = mfma_bf16(ah, ql[g][kk], s[g][tt]);
+            s[g][tt] = mfma_bf16(ah, qh[g][kk], s[g][tt]);
+          } else {
+            s[g][tt] = mfma_bf16(ah, qh[g][kk], kk == 0 ? epsv : s[g][tt]);
           }
-          s[g][tt] = mfma_bf16(ah, qh[g][kk], s[g][tt]);
         }
       }
 #if NMFMU_PIN_SCHED
@@ -431,6 +450,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         }
       }
     }
+    // X's registers are dead from here on: fetch the next tile into them now (single X buffer; the loads have the
+    // whole GEMM2 + barrier + next GEMM1 to land).
+    if (NMFMU_XSINGLE && t_next >= 0) load_x(t_next, x);
     // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
     if constexpr (!C::LOSS) {
       constexpr int NSTEP = RT * 4;
@@ -494,6 +516,76 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #endif
     }
   };
+
+  // ---------------- chunk-fused tile body for the 256-row tile (G = 2, beta == 1, bf16 operands).
+  // The SIMDs are instruction-issue bound (a second wave per SIMD adds no throughput), so this body minimises
+  // instructions per MFMA: every LDS operand read feeds two MFMAs (both row groups), and the elementwise stage is
+  // fused into GEMM2 one 8-column chunk at a time, so only 8 packed-P registers are live (S, Q, X stay in VGPRs
+  // with no AGPR shuffling).  Chunk c = (tt, m2) consumes exactly X chunk q = 2*tt + m2 of each lane.
+  auto compute_g2c = [&](int t, int buf, u32x4(&x)[G][NQ], int t_next) {
+    if constexpr (G == 2 && !X3 && !C::LOSS && !C::TWO_ACC) {
+      const char* sb = smem + buf * C::STAGE_BYTES;
+      constexpr int PF = 4;
+      f32x16 s[2][2];
+      {
+        constexpr int NSTEP = 2 * KS;
+        u32x4 ring[PF];
+        auto off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P1HI + off(p));
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+          const int tt = step & 1, kk = step >> 1;
+          const u32x4 ah = ring[step % PF];
+          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P1HI + off(step + PF));
+          s[0][tt] = mfma_bf16(ah, qh[0][kk], kk == 0 ? epsv : s[0][tt]);
+          s[1][tt] = mfma_bf16(ah, qh[1][kk], kk == 0 ? epsv : s[1][tt]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        u32x4 ring[PF];
+        auto off = [&](int step) {  // step -> (chunk c, rank tile rt)
+          const int rt = step % RT, c = step / RT;
+          return rt * 4096 + b_row + b_off[c >> 1][c & 1];
+        };
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P2HI + off(p));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int tt = c >> 1, m2 = c & 1;
+          u32x4 pk[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const uint32_t w = x[g][2 * tt + m2][d];
+              float n0, n1, p0, p1;
+              mu_elem<BETA>(s[g][tt][8 * m2 + 2 * d], bf16_lo(w), a.beta, n0, p0);
+              mu_elem<BETA>(s[g][tt][8 * m2 + 2 * d + 1], bf16_hi(w), a.beta, n1, p1);
+              pk[g][d] = pack_bf16(n0, n1);
+            }
+          }
+          if (c == 3 && t_next >= 0) load_x(t_next, x);   // X is dead: refill for the next tile
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int step = c * RT + rt;
+            const u32x4 bh = ring[step % PF];
+            if (step + PF < 4 * RT) ring[step % PF] = ld16(sb + C::P2HI + off(step + PF));
+            on[0][rt] = mfma_bf16(pk[0], bh, on[0][rt]);
+            on[1][rt] = mfma_bf16(pk[1], bh, on[1][rt]);
+          }
+        }
+      }
+    }
+  };
+  constexpr bool kG2C = NMFMU_G2C && G == 2 && !X3 && !C::LOSS && !C::TWO_ACC;
 
   // ---------------- phase-interleaved tile body for the 256-row tile (G = 2, beta == 1, bf16 operands).
   // One wave per SIMD cannot rely on a sibling wave to cover its VALU stage, so the two 32-row groups are
@@ -618,10 +710,10 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       const bool more = i + 1 < nt;
 #if NMFMU_ABLATE == 2
       if (more) load_x(tile_at(i + 1), xn);
-      compute(t, 0, xc);
+      compute(t, 0, xc, -1);
 #elif NMFMU_ABLATE == 3
       if (more) stage_issue(tile_at(i + 1), buf ^ 1);
-      compute(t, buf, xc);
+      compute(t, buf, xc, -1);
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
       continue;
@@ -630,7 +722,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         stage_issue(tile_at(i + 1), buf ^ 1);
         load_x(tile_at(i + 1), xn);
       }
-      compute(t, buf, xc);
+      compute(t, buf, xc, -1);
       if (more) stage_commit(buf ^ 1);
       __syncthreads();
 #pragma unroll
@@ -644,7 +736,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         if (more) stage_issue(tile_at(i + 1), buf ^ 1);
         if (far) load_x(tile_at(i + 2), xf);
         if constexpr (kPhased) compute_phased(t, buf, xc);
-        else compute(t, buf, xc);
+        else compute(t, buf, xc, -1);
         // vmcnt(kXLoads) when a far tile was issued (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
         if (far) __builtin_amdgcn_s_waitcnt((kXLoads & 15) | (7 << 4) | (15 << 8) | ((kXLoads >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
@@ -658,12 +750,23 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
           }
         continue;
       }
+      if constexpr (NMFMU_XSINGLE && !kPhased) {
+        if (more) stage_issue(tile_at(i + 1), buf ^ 1);
+        if constexpr (kG2C) compute_g2c(t, buf, xc, more ? tile_at(i + 1) : -1);
+        else compute(t, buf, xc, more ? tile_at(i + 1) : -1);   // loads X of the next tile into xc after its last use
+        if (more) stage_commit(buf ^ 1);
+#if NMFMU_DMA_ASM
+        if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+#endif
+        __syncthreads();
+        continue;
+      }
       if (more) {
         stage_issue(tile_at(i + 1), buf ^ 1);
         load_x(tile_at(i + 1), xn);
       }
       if constexpr (kPhased) compute_phased(t, buf, xc);
-      else compute(t, buf, xc);
+      else compute(t, buf, xc, -1);
       if (more) stage_commit(buf ^ 1);
 #if NMFMU_DMA_ASM
       if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0): the asm DMA landed
