@@ -49,6 +49,9 @@
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
 #endif
+#ifndef NMFMU_SETPRIO
+#define NMFMU_SETPRIO 0  // raise wave priority during the MFMA phases
+#endif
 #ifndef NMFMU_X_NT
 #define NMFMU_X_NT 1  // non-temporal loads for the X stream (read once; keeps the factor panel resident in L2)
 #endif
@@ -345,6 +348,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     // The accumulators are seeded with eps through the C operand of each chain's first MFMA (seed tile `epsv`,
     // loop invariant) instead of being re-initialised with 16 moves per tile.
     f32x16 s[G][2];
+#if NMFMU_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     {
       constexpr int NSTEP = 2 * KS;
       constexpr int PF = NSTEP < 4 ? NSTEP : 4;
@@ -391,6 +397,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       }
 #endif
     }
+#if NMFMU_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---------------- elementwise: Gn / Gp (or the loss terms), packed to bf16 A operands
     uint32_t gnh[G][2][8], gnl[G][X3 ? 2 : 1][8], gph[G][C::TWO_ACC ? 2 : 1][8], gpl[G][(C::TWO_ACC && X3) ? 2 : 1][8];
 #pragma unroll
@@ -455,6 +464,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
     if (NMFMU_XSINGLE && t_next >= 0) load_x(t_next, x);
     // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
     if constexpr (!C::LOSS) {
+#if NMFMU_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
       constexpr int NSTEP = RT * 4;
       constexpr int PF = 4;
       u32x4 ring_h[PF];
@@ -513,6 +525,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         __builtin_amdgcn_sched_group_barrier(0x008, G * (X3 ? 3 : 1) * (C::TWO_ACC ? 2 : 1), 1);
         if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
       }
+#endif
+#if NMFMU_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
 #endif
     }
   };

@@ -429,3 +429,34 @@ def test_sharded_path_world1_rccl(dev):
             assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# wide ranks (padded rank 256, the configs[4] kernel family) and unsupported combinations
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rank', [200, 256])
+@pytest.mark.parametrize('beta', [1, 2])
+def test_rank_above_128_bf16(dev, rank, beta):
+    from oracle import mu_oracle as O
+    g = torch.Generator().manual_seed(rank)
+    N, C = 300, 700
+    V = torch.rand(N, C, generator=g).bfloat16().float()
+    W0 = torch.randn(C, rank, generator=g).abs()
+    H0 = torch.randn(N, rank, generator=g).abs()
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, beta, 'bf16', 1)
+    gam = O.gamma_of(beta)
+    Wr = O.nmf_w_step(V, W0, H0, beta, gam)
+    Hr = O.nmf_h_step(V, Wr, H0, beta, gam)
+    assert rel_err(W1, Wr) < 5e-3 and rel_err(H1, Hr) < 5e-3, (rel_err(W1, Wr), rel_err(H1, Hr))
+    assert l1 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, beta)), rel=5e-3)
+
+
+def test_unsupported_combinations_raise(dev):
+    from torchnmf_amd.nmf import NMF
+    V = torch.rand(64, 80)
+    m = NMF(V.shape, 200).to(dev)
+    with pytest.raises(NotImplementedError):
+        m.fit(V.to(dev), precision='bf16x3')      # split precision needs padded rank <= 128
+    assert m.fit(V.to(dev), max_iter=3) == 3       # 'auto' falls back to bf16 for wide ranks
+    with pytest.raises(NotImplementedError):
+        NMF(V.shape, 300).to(dev).fit(V.to(dev))   # rank > 256
