@@ -49,6 +49,12 @@
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
 #endif
+#ifndef NMFMU_RCP_PAIR
+#define NMFMU_RCP_PAIR 0  // 1: beta == 1 with one v_rcp_f32 per two columns (measured 2 % slower)
+#endif
+#ifndef NMFMU_PIPE3
+#define NMFMU_PIPE3 0  // (measured slower: 1 WG/CU, no gain from the deeper pipeline) 3-slot LDS ring + X two tiles ahead, counted vmcnt across raw barriers (LDS-DMA staging only)
+#endif
 #ifndef NMFMU_SETPRIO
 #define NMFMU_SETPRIO 0  // raise wave priority during the MFMA phases
 #endif
@@ -131,7 +137,9 @@ struct FusedCfg {
   static constexpr int P2HI = NPL * IMG;
   static constexpr int P2LO = NPL * IMG + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  // three LDS slots (panel DMA two tiles ahead) wherever they fit 160 KiB, else the classic double buffer
+  static constexpr bool PIPE3 = NMFMU_PIPE3 && (3 * STAGE_BYTES <= 160 * 1024);
+  static constexpr int LDS_BYTES = (PIPE3 ? 3 : 2) * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
@@ -432,6 +440,15 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
             const bool rowok = m0 + 32 * g < a.M;
             lacc += (rowok && k0 < a.K) ? loss_elem<BETA>(s0, x0, a.beta) : 0.f;
             lacc += (rowok && k0 + 1 < a.K) ? loss_elem<BETA>(s1, x1, a.beta) : 0.f;
+          } else if constexpr (NMFMU_RCP_PAIR && BETA == kKL) {
+            // one reciprocal per PAIR of columns: r = 1/(s0*s1), 1/s0 = s1*r, 1/s1 = s0*r (v_rcp_f32 is the slow
+            // transcendental of this stage; the extra multiplies are full rate).  s >= eps = 2^-23, so the product
+            // neither underflows nor (for s < 1e19) overflows; error ~3 ulp.
+            const float r = __builtin_amdgcn_rcpf(s0 * s1);
+            const float n0 = (x0 * s1) * r, n1 = (x1 * s0) * r;
+            const uint32_t nh = pack_bf16(n0, n1);
+            gnh[g][tt][d] = nh;
+            if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
           } else {
             float n0, n1, p0, p1;
 #if NMFMU_ABLATE == 1
@@ -697,6 +714,64 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
   // t+1 is issued before the X loads of tile t+2, so waiting until only the X loads are outstanding proves the DMA
   // has landed while 2 tiles of X per wave stay in flight across the barrier (one tile in flight caps a CU at
   // ~3 TB/s chip-wide by Little's law; the X stream is the kernel's only HBM traffic).
+  // ---------------- pipelined main loop (LDS-DMA staging): three LDS slots, panel DMA and X loads issued TWO
+  // tiles ahead, and every tile ends with a counted s_waitcnt vmcnt(N) + raw s_barrier, so the next-but-one tile's
+  // traffic stays in flight across the barrier instead of being drained (the drain-per-tile structure is what
+  // cdna_hip_programming.md section 5 measures at ~40 % of the pipelined one).  Both the DMA and the X loads are
+  // issued from inline asm: hipcc must not see them, or it inserts its own vmcnt(0) drains.  The loop is unrolled
+  // by three so that X register sets and LDS slots are static.
+  constexpr bool kPipe3 = C::PIPE3 && STAGE == 1 && NMFMU_ABLATE == 0;
+  if constexpr (kPipe3) {
+    if (t0 < t1) {
+      const int nt = t1 - t0;
+      constexpr int kPerTile = C::NIMG * C::PASSES + G * NQ;   // VMEM instructions issued per prefetched tile
+      static_assert(kPerTile < 64, "vmcnt field");
+      auto load_x_asm = [&](int t, u32x4(&x)[G][NQ]) {
+        const char* p = xbase + (size_t)t * (4 * G * NQ * 1024);
+#pragma unroll
+        for (int i = 0; i < G * NQ; ++i) {
+          const char* pi = p + (i >> 2) * 4096;
+          if ((i & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
+          if ((i & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
+          if ((i & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
+          if ((i & 3) == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
+        }
+      };
+      auto prefetch = [&](int i, int slot, u32x4(&x)[G][NQ]) {   // tile i of this chunk -> LDS slot + registers
+        stage_issue(t0 + i, slot);
+        load_x_asm(t0 + i, x);
+      };
+      auto tile_end = [&](bool two_in_flight) {
+        // allow exactly the newest prefetched tile to stay in flight; everything older (the next tile) has landed
+        if (two_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerTile) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);   // nothing (e.g. the next tile's unpack of X) may move above the wait
+      };
+      u32x4 x0[G][NQ], x1[G][NQ], x2[G][NQ];
+      prefetch(0, 0, x0);
+      if (nt > 1) prefetch(1, 1, x1);
+      tile_end(nt > 1);
+      auto body = [&](int i, int slot, u32x4(&xcur)[G][NQ], u32x4(&xfar)[G][NQ]) {
+        const bool far = i + 2 < nt;
+        if (far) prefetch(i + 2, slot == 0 ? 2 : slot - 1, xfar);   // (slot + 2) % 3
+        // xcur was filled by asm loads two tiles ago and waited for at the end of the previous tile; make it
+        // opaque here so that no use can be scheduled above this point
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(xcur[g][q]));
+        compute(t0 + i, slot, xcur, -1);
+        tile_end(far);
+      };
+      for (int i = 0; i < nt; i += 3) {
+        body(i, 0, x0, x2);
+        if (i + 1 < nt) body(i + 1, 1, x1, x0);
+        if (i + 2 < nt) body(i + 2, 2, x2, x1);
+      }
+    }
+  }
+  if constexpr (!kPipe3)
   if (t0 < t1) {
     u32x4 xc[G][NQ], xn[G][NQ], xf[G][NQ];
     constexpr bool kDeep = (STAGE == 1) && NMFMU_XDEPTH == 2 && NMFMU_ABLATE == 0;
