@@ -49,6 +49,12 @@
 #ifndef NMFMU_VALU_PER_MFMA
 #define NMFMU_VALU_PER_MFMA 7
 #endif
+#ifndef NMFMU_SP_FENCE
+#define NMFMU_SP_FENCE 1
+#endif
+#ifndef NMFMU_SP
+#define NMFMU_SP 0  // cross-tile software pipelining: elementwise(t) beside GEMM1(t+1); measured SLOWER
+#endif
 #ifndef NMFMU_RCP_PAIR
 #define NMFMU_RCP_PAIR 0  // 1: beta == 1 with one v_rcp_f32 per two columns (measured 2 % slower)
 #endif
@@ -139,11 +145,15 @@ struct FusedCfg {
   static constexpr int STAGE_BYTES = NIMG * IMG;
   // three LDS slots (panel DMA two tiles ahead) wherever they fit 160 KiB, else the classic double buffer
   static constexpr bool PIPE3 = NMFMU_PIPE3 && (3 * STAGE_BYTES <= 160 * 1024);
-  static constexpr int LDS_BYTES = (PIPE3 ? 3 : 2) * STAGE_BYTES;
+  // software-pipelined path: 3-slot rings for P1, P2 and the X tile (bf16, 128 rows x 64 columns)
+  static constexpr int XTILE = 128 * kBK * 2;
+  static constexpr bool SP = NMFMU_SP && R_PAD <= 128 && G == 1 && BETA == kKL && !X3 && !LOSS;
+  static constexpr int LDS_BYTES = SP ? 3 * (2 * IMG + XTILE) : (PIPE3 ? 3 : 2) * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
-  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1) ? 1 : 2;
+  // the software-pipelined beta == 1 kernel keeps two S tiles live: it gets the whole register file (one wave per SIMD)
+  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1 || SP) ? 1 : 2;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -714,13 +724,167 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
   // t+1 is issued before the X loads of tile t+2, so waiting until only the X loads are outstanding proves the DMA
   // has landed while 2 tiles of X per wave stay in flight across the barrier (one tile in flight caps a CU at
   // ~3 TB/s chip-wide by Little's law; the X stream is the kernel's only HBM traffic).
+  // ---------------- software-pipelined main loop (beta == 1, bf16 operands, 128-row tile, LDS-DMA staging).
+  // Microbenchmarks on MI355X (tools/ubench) show that (a) a second wave per SIMD adds almost nothing, (b) bit-ops,
+  // moves, v_rcp, v_cvt_pk and ds_read_b128 co-issue with MFMAs nearly for free while fp32 mul/fma cost ~2.5 cycles
+  // and v_pk_mul_f32 ~24, and (c) the serial GEMM1 -> elementwise -> GEMM2 phases of one tile simply ADD.  So the
+  // elementwise stage of tile t is issued BESIDE the (independent) GEMM1 of tile t+1:
+  //     phase A   16 MFMA of GEMM1(t+1) into s_next   ||   per MFMA: unpack, 2 rcp, 2 mul, 1 cvt_pk of tile t
+  //     phase B   16 MFMA of GEMM2(t)
+  // S ping-pongs through a x2-unrolled loop; the GEMM1 operand image of a tile is DMA'd one tile earlier than its
+  // GEMM2 image (P1(t+2) and P2(t+1) are issued at the top of tile t; same two LDS stages as before).
+  constexpr bool kSP = NMFMU_SP && R_PAD <= 128 && G == 1 && BETA == kKL && !X3 && !C::LOSS && STAGE == 1 && NMFMU_ABLATE == 0;
+  if constexpr (kSP) {
+    // LDS: P1 ring [3][IMG] | P2 ring [3][IMG] | X ring [3][XTILE].  Everything arrives by LDS-DMA issued from inline
+    // asm (hipcc must not see it), TWO tiles ahead; each tile ends with ONE counted vmcnt + raw s_barrier that lets
+    // exactly this tile's prefetches stay in flight.  Invariant at the start of tile i: P1(i+1), P2(i), X(i) have
+    // landed; P1(i+2), P2(i+1), X(i+1) may be in flight; tile i issues P1(i+3), P2(i+2), X(i+2).
+    if (t0 < t1) {
+      const int nt = t1 - t0;
+      constexpr int PF = 4;
+      constexpr int XT = C::XTILE;
+      constexpr unsigned P1_BASE = 0, P2_BASE = 3 * IMG, X_BASE = 6 * IMG;
+      constexpr int NP = C::PASSES;          // DMA instructions per panel image tile and thread
+      constexpr int NX = XT / 4096;          // DMA instructions per X tile and thread (4)
+      const char* xtile0 = reinterpret_cast<const char*>(a.xp) + (size_t)mb * a.ktiles * XT + tid * 16;
+      auto dma = [&](const char* src, unsigned lds_off, int n) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (p < n) {
+            const unsigned lds_addr = lds_base + lds_off + (unsigned)(p * 4096) + wave_lds;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :
+                         : "v"(src + p * 4096), "s"(lds_addr)
+                         : "memory", "m0");
+          }
+        }
+      };
+      static_assert(NP <= 4 && NX <= 4, "dma helper issues at most 4 pieces");
+      auto issue_p1 = [&](int i, unsigned slot) { dma(img_src[0] + (size_t)(t0 + i) * IMG + tid * 16, P1_BASE + slot * IMG, NP); };
+      auto issue_p2 = [&](int i, unsigned slot) { dma(img_src[1] + (size_t)(t0 + i) * IMG + tid * 16, P2_BASE + slot * IMG, NP); };
+      auto issue_x = [&](int i, unsigned slot) { dma(xtile0 + (size_t)(t0 + i) * XT, X_BASE + slot * XT, NX); };
+      auto a_off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
+      auto b_offs = [&](int step) {
+        const int rt = step % RT, c = step / RT;
+        return rt * 4096 + b_row + b_off[c >> 1][c & 1];
+      };
+      // counted end-of-tile wait: n = DMA instructions this tile issued (they may stay in flight)
+      auto tile_end = [&](int n) {
+        if (n == 2 * NP + NX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + NX) : "memory");
+        else if (n == NP + NX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      uint32_t gn[2][8];
+      f32x16 sA[2], sB[2];
+      // ---- prologue
+      issue_p1(0, 0);
+      issue_p2(0, 0);
+      issue_x(0, 0);
+      if (nt > 1) issue_p1(1, 1);
+      int second = 0;
+      if (nt > 2) { issue_p1(2, 2); second += NP; }
+      if (nt > 1) { issue_p2(1, 1); issue_x(1, 1); second += NP + NX; }
+      tile_end(second);                       // the first group (tile 0's data and P1(1)) has landed
+      {
+        const char* sb = smem + P1_BASE;
+        u32x4 ring[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + a_off(p));
+#pragma unroll
+        for (int step = 0; step < 2 * KS; ++step) {
+          const u32x4 ah = ring[step % PF];
+          if (step + PF < 2 * KS) ring[step % PF] = ld16(sb + a_off(step + PF));
+          sA[step & 1] = mfma_bf16(ah, qh[0][step >> 1], (step >> 1) == 0 ? epsv : sA[step & 1]);
+        }
+      }
+      __builtin_amdgcn_s_barrier();           // all waves are done with P1 slot 0 before tile 0 re-fills it
+      // ---- one tile.  Ring slots advance with period 3 (runtime scalars), S ping-pongs with period 2 (static).
+      unsigned sl_cur = 0;                    // slot of tile i: i % 3
+      auto tile_body = [&](int i, auto nextc, f32x16(&sc)[2], f32x16(&sn)[2]) {
+        constexpr bool has_next = decltype(nextc)::value;
+        const unsigned s0 = sl_cur, s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;   // i, i+1, i+2 (mod 3)
+        int issued = 0;
+        if (i + 3 < nt) { issue_p1(i + 3, s0); issued += NP; }                                // slot of P1(i): free
+        if (i + 2 < nt) { issue_p2(i + 2, s2); issue_x(i + 2, s2); issued += NP + NX; }       // slots of tile i-1: free
+        // X(i): this lane's four 16-byte chunks, straight from the LDS ring
+        u32x4 x[NQ];
+        {
+          const char* xs = smem + X_BASE + s0 * XT + wave * 4096 + lane * 16;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) x[q] = ld16(xs + q * 1024);
+        }
+        // ---- phase A: GEMM1(i+1) beside the elementwise stage of tile i
+        {
+          const char* sb = smem + P1_BASE + s1 * IMG;
+          u32x4 ring[PF];
+          if constexpr (has_next) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + a_off(p));
+          }
+#pragma unroll
+          for (int step = 0; step < 16; ++step) {
+            if constexpr (has_next) {
+#pragma unroll
+              for (int u = step * (2 * KS) / 16; u < (step + 1) * (2 * KS) / 16; ++u) {
+                const u32x4 ah = ring[u % PF];
+                if (u + PF < 2 * KS) ring[u % PF] = ld16(sb + a_off(u + PF));
+                sn[u & 1] = mfma_bf16(ah, qh[0][u >> 1], (u >> 1) == 0 ? epsv : sn[u & 1]);
+              }
+            }
+            const int tt = step >> 3, d = step & 7;
+            const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
+            const float n0 = bf16_lo(w) * __builtin_amdgcn_rcpf(sc[tt][2 * d]);
+            const float n1 = bf16_hi(w) * __builtin_amdgcn_rcpf(sc[tt][2 * d + 1]);
+            gn[tt][d] = pack_bf16(n0, n1);
+#if NMFMU_SP_FENCE
+            __builtin_amdgcn_sched_barrier(0);   // keep the ring depth and the per-step interleave as written
+#endif
+          }
+        }
+        // ---- phase B: GEMM2(i)
+        {
+          const char* sb = smem + P2_BASE + s0 * IMG;
+          u32x4 ring[PF];
+#pragma unroll
+          for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + b_offs(p));
+#pragma unroll
+          for (int step = 0; step < 4 * RT; ++step) {
+            const int rt = step % RT, c = step / RT, tt = c >> 1, m2 = c & 1;
+            const u32x4 bh = ring[step % PF];
+            if (step + PF < 4 * RT) ring[step % PF] = ld16(sb + b_offs(step + PF));
+            const u32x4 nh = {gn[tt][4 * m2], gn[tt][4 * m2 + 1], gn[tt][4 * m2 + 2], gn[tt][4 * m2 + 3]};
+            on[0][rt] = mfma_bf16(nh, bh, on[0][rt]);
+#if NMFMU_SP_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        }
+        tile_end(issued);
+        sl_cur = s1;
+      };
+      int i = 0;
+      for (; i + 2 < nt; i += 2) {   // both tiles of the pair have a successor
+        tile_body(i, std::true_type{}, sA, sB);
+        tile_body(i + 1, std::true_type{}, sB, sA);
+      }
+      if (i == nt - 1) {
+        tile_body(i, std::false_type{}, sA, sB);
+      } else {                       // i == nt - 2
+        tile_body(i, std::true_type{}, sA, sB);
+        tile_body(i + 1, std::false_type{}, sB, sA);
+      }
+      __syncthreads();               // LDS is reused by the epilogue
+    }
+  }
   // ---------------- pipelined main loop (LDS-DMA staging): three LDS slots, panel DMA and X loads issued TWO
   // tiles ahead, and every tile ends with a counted s_waitcnt vmcnt(N) + raw s_barrier, so the next-but-one tile's
   // traffic stays in flight across the barrier instead of being drained (the drain-per-tile structure is what
   // cdna_hip_programming.md section 5 measures at ~40 % of the pipelined one).  Both the DMA and the X loads are
   // issued from inline asm: hipcc must not see them, or it inserts its own vmcnt(0) drains.  The loop is unrolled
   // by three so that X register sets and LDS slots are static.
-  constexpr bool kPipe3 = C::PIPE3 && STAGE == 1 && NMFMU_ABLATE == 0;
+  constexpr bool kPipe3 = C::PIPE3 && STAGE == 1 && NMFMU_ABLATE == 0 && !kSP;
   if constexpr (kPipe3) {
     if (t0 < t1) {
       const int nt = t1 - t0;
@@ -771,7 +935,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
       }
     }
   }
-  if constexpr (!kPipe3)
+  if constexpr (!kPipe3 && !kSP)
   if (t0 < t1) {
     u32x4 xc[G][NQ], xn[G][NQ], xf[G][NQ];
     constexpr bool kDeep = (STAGE == 1) && NMFMU_XDEPTH == 2 && NMFMU_ABLATE == 0;
