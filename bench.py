@@ -49,24 +49,63 @@ def parse():
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
-    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd'],
+    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
     ap.add_argument('--taps', type=int, default=400)
+    ap.add_argument('--materialise', action='store_true',
+                    help="betamu: the closure returns m() (reconstruction written out, as in the reference's tests) "
+                         "instead of the layer itself")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded (all-reduce) path even at world size 1')
     return ap.parse_args()
 
 
-def cpu_baseline(V, W0, H0, beta, iters):
+def usable_cores():
+    """Host threads this process may actually run on: affinity mask, capped by a cgroup CPU quota if one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def pick_threads(run_probe):
+    """The ATen CPU kernels are far from monotone in thread count on many-core hosts (256 threads were measured ~4x
+    slower than 32 on the MI355X box).  Time a probe with a few thread counts and keep the fastest, so the CPU baseline
+    is the reference at its best on this box, not at its default."""
+    n = usable_cores()
+    cands = sorted({max(1, c) for c in (n, n // 2, n // 4, n // 8, 32, 16) if c <= n} | {min(n, 8)}, reverse=True)
+    best, tried = None, {}
+    for c in cands:
+        torch.set_num_threads(c)
+        run_probe()                      # warm the pool at this size
+        t0 = time.perf_counter()
+        run_probe()
+        tried[c] = round(time.perf_counter() - t0, 4)
+        if best is None or tried[c] < tried[best]:
+            best = c
+    torch.set_num_threads(best)
+    return best, tried
+
+
+def cpu_baseline(V, W0, H0, beta, iters, betamu=False):
     """Time the reference's op sequence on the host cores (bounded sample of the same workload)."""
     from oracle import aten_port
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     torch.set_flush_denormal(True)   # the reference's own advice (README.md:101-102)
-    aten_port.mu_iterations(V, W0, H0, beta, 1)          # warm-up (page-in, thread pool)
+    cs = min(V.shape[1], 8192)       # probe = one MU iteration on a column slice of the same workload
+    Vs, Ws = V[:, :cs].contiguous(), W0[:cs].contiguous()
+    run = aten_port.betamu_iterations if betamu else aten_port.mu_iterations
+    cores, tried = pick_threads(lambda: run(Vs, Ws, H0, beta, 1))
+    run(V, W0, H0, beta, 1)          # warm-up (page-in, thread pool)
     t0 = time.perf_counter()
-    aten_port.mu_iterations(V, W0, H0, beta, iters)
+    run(V, W0, H0, beta, iters)
     dt = (time.perf_counter() - t0) / iters
-    return dt, cores
+    return dt, cores, tried
 
 
 def main_nmfd(a):
@@ -106,15 +145,14 @@ def main_nmfd(a):
     cpu = None
     if a.cpu_iters > 0:
         from oracle import aten_port
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         torch.set_flush_denormal(True)
+        cores, tried = pick_threads(lambda: aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1))
         aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1)
         t0 = time.perf_counter()
         aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, a.cpu_iters)
         dt = (time.perf_counter() - t0) / a.cpu_iters
         cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
-               'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
+               'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
                f'NMFD workload, fp32, F.conv1d + two backward passes (oracle/aten_port.py)'}
     print(json.dumps({
         'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), NMFD 1x{Cc}x{L} rank-{R} T={T} beta={beta:g}',
@@ -165,14 +203,32 @@ def main():
     H = torch.randn(N, R, device=dev, generator=gh).abs_()             # replicated
     W0c, H0c = (W.cpu(), H.cpu()) if (rank == 0 and world == 1 and a.cpu_iters > 0) else (None, None)
 
-    eng = DenseMU(V, W, H, beta, precision=a.precision, stage=a.stage, group=group, block_rows=a.block_rows)
     Vc = V.cpu() if W0c is not None else None
-    del V
-    torch.cuda.synchronize()
+    betamu = a.workload == 'betamu'
+    if betamu:
+        # trainer.BetaMu.step(closure) on one NMF layer; one step = W update + H update
+        assert world == 1 and group is None, 'BetaMu runs on one GPU'
+        from torchnmf_amd.nmf import NMF
+        from torchnmf_amd.trainer import BetaMu
+        layer = NMF(W=W.cpu(), H=H.cpu()).to(dev)
+        trainer = BetaMu(layer.parameters(), beta, precision=a.precision)
 
-    def step():
-        eng.w_step()
-        eng.h_step()
+        def closure():
+            trainer.zero_grad()
+            return V, (layer() if a.materialise else layer)
+
+        def step():
+            trainer.step(closure)
+        step()
+        eng = next(iter(trainer._engines.values()))[0]
+    else:
+        eng = DenseMU(V, W, H, beta, precision=a.precision, stage=a.stage, group=group, block_rows=a.block_rows)
+        del V
+
+        def step():
+            eng.w_step()
+            eng.h_step()
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -235,8 +291,9 @@ def main():
 
     cpu = None
     if Vc is not None:
-        dt, cores = cpu_baseline(Vc, W0c, H0c, beta, a.cpu_iters)
+        dt, cores, tried = cpu_baseline(Vc, W0c, H0c, beta, a.cpu_iters, betamu)
         cpu = {'value': round(flops_per_iter_gpu / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+               'host_cores': usable_cores(), 'thread_probe_s': tried,
                'iters_per_s': round(1.0 / dt, 4), 's_per_iter': round(dt, 4),
                'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same {N}x{C} rank-{R} beta={beta:g} '
                          f'workload, fp32, reference op sequence (oracle/aten_port.py), loss evaluation excluded'}
@@ -251,12 +308,16 @@ def main():
             'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)', 'data': 'synthetic',
             'config': {'workload': f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
                                    f'H replicated, 1 all-reduce/iter' if world > 1 else
+                                   ('trainer.BetaMu.step on ' if betamu else '') +
                                    f'NMF {N}x{C} rank={R} beta={beta:g}' + (' (BASELINE configs[1])' if (N, C, R, beta) == (4096, 65536, 128, 1.0) else ''),
                        'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
                        'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows},
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if betamu:
+            out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \
+                'returns the layer (deferred reconstruction)'
         print(json.dumps(out))
     if group is not None:
         import torch.distributed as dist

@@ -135,6 +135,17 @@ int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void
 int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                    void* stream);
 
+/* nmfmu_trainer_apply: the update of trainer.BetaMu.step (trainer.py:93-112) for one parameter, fed by the same
+ * partial sums as nmfmu_mu_apply (the closure's WH.backward(output_neg) / WH.backward(output_pos) of trainer.py:93-97
+ * are exactly the numerator / denominator contractions of nmfmu_mu_partial):
+ *   neg = relu(sum num slabs);  pos = relu(sum den slabs)   [beta == 1: pos = kl_den[r], the ones-backward]
+ *   grad = pos - neg                                          (p.grad of trainer.py:98; grad may be NULL)
+ *   pos += l1;  pos += l2 * f;  pos += ortho * (sum_r f[row][r] - f);  pos += eps;  neg += eps
+ *   f *= (neg / pos) ** gamma
+ * l1 / l2 / gamma come from *st.  Refreshes owner's bf16 images and column sums like nmfmu_mu_apply. */
+int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                        float ortho, float* grad, void* stream);
+
 /* ---- loss -----------------------------------------------------------------------------------------------------
  * nmfmu_loss: beta_div(owner panel^T, X) of metrics.py:60-96 without materialising the reconstruction
  * (replaces nmf.py:360-361 and 400-401).  loss_part: nmfmu_loss_part_count() floats of scratch; *out (device

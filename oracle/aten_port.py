@@ -72,3 +72,40 @@ def mu_iterations_nmfd(V, W0, H0, beta=1, n_iter=1):
         pos = W.detach().sum((0, 2), keepdim=True).squeeze(0) if beta == 1 else None
         _update(V, F.conv1d(H, W.detach().flip(2), padding=pad), H, beta, gamma, 0.0, 0.0, pos)
     return W.data, H.data
+
+
+def betamu_iterations(V, W0, H0, beta=1, n_iter=1, l1=0.0, l2=0.0, ortho=0.0):
+    """``trainer.BetaMu.step`` on one NMF layer with the reference's op sequence (trainer.py:72-112): the closure's
+    F.linear per parameter, two backward passes (the second with ones for beta == 1), clone/relu_, penalties, eps."""
+    W = torch.nn.Parameter(W0.clone().float())
+    H = torch.nn.Parameter(H0.clone().float())
+    gamma = gamma_of(beta)
+    for _ in range(n_iter):
+        for p, other in ((W, H), (H, W)):
+            other.requires_grad_(False)
+            p.requires_grad_(True)
+            p.grad = None
+            WH = F.linear(H, W)
+            gneg, gpos = _grad_outputs(V, WH.detach(), beta)
+            if gpos is None:
+                gpos = torch.ones_like(WH)
+            WH.backward(gneg, retain_graph=True)
+            neg = torch.clone(p.grad).relu_()
+            p.grad.zero_()
+            WH.backward(gpos)
+            pos = torch.clone(p.grad).relu_()
+            p.grad.add_(-neg)
+            with torch.no_grad():
+                if l1 > 0:
+                    pos.add_(l1)
+                if l2 > 0:
+                    pos.add_(p, alpha=l2)
+                if ortho > 0:
+                    pos.add_(p.sum(1, keepdim=True) - p, alpha=ortho)
+                pos.add_(EPS)
+                neg.add_(EPS)
+                mult = neg.div_(pos)
+                if gamma != 1:
+                    mult.pow_(gamma)
+                p.mul_(mult)
+    return W.data, H.data

@@ -134,6 +134,49 @@ def nmf_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
 
 
 # --------------------------------------------------------------------------
+# trainer.BetaMu on one NMF layer (trainer.py:35-121)
+# --------------------------------------------------------------------------
+def betamu_terms(V: torch.Tensor, S: torch.Tensor, beta: float):
+    """(output_neg, output_pos) of trainer.py:75-91: as nmf.py:61-74 except that beta == 1 back-propagates ones."""
+    gn, gp = mu_terms(V, S, beta)
+    return gn, (torch.ones_like(S) if gp is None else gp)
+
+
+def betamu_update(theta, neg_raw, pos_raw, gamma, l1=0.0, l2=0.0, ortho=0.0):
+    """trainer.py:93-112 for one parameter.  Returns (new theta, p.grad)."""
+    neg = neg_raw.relu()                      # trainer.py:94
+    pos = pos_raw.relu()                      # trainer.py:97
+    grad = pos - neg                          # trainer.py:98
+    if l1 > 0:
+        pos = pos + l1                        # trainer.py:100-101
+    if l2 > 0:
+        pos = pos + l2 * theta                # trainer.py:102-103
+    if ortho > 0:
+        pos = pos + ortho * (theta.sum(1, keepdim=True) - theta)   # trainer.py:105-106
+    pos = pos + EPS                           # trainer.py:108
+    neg = neg + EPS                           # trainer.py:109
+    mult = neg / pos
+    if gamma != 1:
+        mult = mult.pow(gamma)
+    return theta * mult, grad
+
+
+def betamu_step(V, W, H, beta, l1=0.0, l2=0.0, ortho=0.0, params=('W', 'H')):
+    """One ``BetaMu.step`` over ``params`` (in that order; the closure is re-evaluated per parameter, trainer.py:72).
+    Returns (W, H, {name: grad})."""
+    gamma = gamma_of(beta)
+    grads = {}
+    for name in params:
+        S = nmf_reconstruct(H, W)
+        gn, gp = betamu_terms(V, S, beta)
+        if name == 'W':
+            W, grads['W'] = betamu_update(W, gn.t() @ H, gp.t() @ H, gamma, l1, l2, ortho)
+        else:
+            H, grads['H'] = betamu_update(H, gn @ W, gp @ W, gamma, l1, l2, ortho)
+    return W, H, grads
+
+
+# --------------------------------------------------------------------------
 # NMFD:  V (B,C,L) ~ sum_t W[:,:,t] H[:,:,l-t]    (nmf.py:706-713, 776-779)
 #        W (C,R,T), H (B,R,L-T+1)
 # --------------------------------------------------------------------------

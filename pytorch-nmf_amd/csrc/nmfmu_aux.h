@@ -19,6 +19,11 @@ struct ApplyArgs {
   float* colsum;        // [R_PAD]
   int rows, rank, rows_pad;
   float l1, l2, gamma;
+  // trainer.BetaMu semantics (trainer.py:93-112) instead of fit's (nmf.py:78-92): eps added after the penalties,
+  // orthogonality penalty, and grad[row][r] = relu(den) - relu(num) written out (p.grad of trainer.py:98)
+  int trainer;
+  float ortho;
+  float* grad;          // [rows][rank] or nullptr
 };
 
 int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,

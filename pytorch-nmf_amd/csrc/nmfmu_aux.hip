@@ -100,6 +100,25 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   const size_t plane = (size_t)a.rows_pad * R_PAD;
   constexpr int R4 = R_PAD / 4;
 
+  // trainer mode with an orthogonality penalty needs p.sum(1) of the OLD factor (trainer.py:105-106): stage the old
+  // rows in the tile first, reduce each row in a fixed order
+  float* rowsum = tile + ROWS * LDT;  // [ROWS]
+  if constexpr (!PACK_ONLY) {
+    if (a.trainer && a.ortho > 0.f) {
+      for (int idx = tid; idx < ROWS * R_PAD; idx += 256) {
+        const int rl = idx / R_PAD, r = idx - rl * R_PAD;
+        const int row = row0 + rl;
+        tile[rl * LDT + r] = (row < a.rows && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
+      }
+      __syncthreads();
+      for (int rl = tid; rl < ROWS; rl += 256) {
+        float s = 0.f;
+        for (int r = 0; r < a.rank; ++r) s += tile[rl * LDT + r];
+        rowsum[rl] = s;
+      }
+      __syncthreads();
+    }
+  }
   for (int idx = tid; idx < ROWS * R4; idx += 256) {
     const int rl = idx / R4, r = (idx - rl * R4) * 4;
     const int row = row0 + rl;
@@ -117,7 +136,8 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
         }
         float neg[4] = {n4.x, n4.y, n4.z, n4.w};
         float pos[4];
-        if (a.kl_den) {  // closed form, no relu / eps (nmf.py:80 branch skipped)
+        const float den_eps = a.trainer ? 0.f : kEps;  // the trainer adds eps after the penalties (trainer.py:108)
+        if (a.kl_den) {  // closed form, no relu / eps (nmf.py:80 branch skipped; trainer.py:84 ones-backward)
           const float4 d4 = *reinterpret_cast<const float4*>(a.kl_den + r);
           pos[0] = d4.x, pos[1] = d4.y, pos[2] = d4.z, pos[3] = d4.w;
         } else {
@@ -126,16 +146,22 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
             const float4 v = *reinterpret_cast<const float4*>(a.den + s * plane + e);
             d4.x += v.x, d4.y += v.y, d4.z += v.z, d4.w += v.w;
           }
-          pos[0] = fmaxf(d4.x, 0.f) + kEps, pos[1] = fmaxf(d4.y, 0.f) + kEps;  // nmf.py:83
-          pos[2] = fmaxf(d4.z, 0.f) + kEps, pos[3] = fmaxf(d4.w, 0.f) + kEps;
+          pos[0] = fmaxf(d4.x, 0.f) + den_eps, pos[1] = fmaxf(d4.y, 0.f) + den_eps;  // nmf.py:83
+          pos[2] = fmaxf(d4.z, 0.f) + den_eps, pos[3] = fmaxf(d4.w, 0.f) + den_eps;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i < nv) {
-            const float ng = fmaxf(neg[i], 0.f) + kEps;  // nmf.py:78
+            const float ngr = fmaxf(neg[i], 0.f);
+            const float ng = ngr + kEps;        // nmf.py:78, trainer.py:109
             float ps = pos[i];
-            if (a.l1 > 0.f) ps += a.l1;         // nmf.py:85-86
-            if (a.l2 > 0.f) ps += a.l2 * f[i];  // nmf.py:87-88
+            if (a.trainer && a.grad) a.grad[(size_t)row * a.rank + r + i] = ps - ngr;  // trainer.py:98
+            if (a.l1 > 0.f) ps += a.l1;         // nmf.py:85-86, trainer.py:100-101
+            if (a.l2 > 0.f) ps += a.l2 * f[i];  // nmf.py:87-88, trainer.py:102-103
+            if (a.trainer) {
+              if (a.ortho > 0.f) ps += a.ortho * (rowsum[rl] - f[i]);  // trainer.py:105-106
+              ps += kEps;                                              // trainer.py:108
+            }
             float mult = ng / ps;
             if (a.gamma != 1.f) mult = powf(mult, a.gamma);
             f[i] *= mult;
@@ -219,7 +245,7 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
 template <int R_PAD, int ROWS>
 int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   const int grid = a.rows_pad / ROWS;
-  const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float);
+  const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float) + ROWS * sizeof(float);  // tile + row sums
 #define L(X, P)                                                                                                      \
   {                                                                                                                  \
     auto k = apply_kernel<R_PAD, X, P, ROWS>;                                                                        \

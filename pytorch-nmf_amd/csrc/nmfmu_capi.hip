@@ -189,8 +189,8 @@ int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void
   return e;
 }
 
-int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
-                   void* stream) {
+static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                        int trainer, float ortho, float* grad, void* stream) {
   if (!st || !st->owner.f) return NMFMU_ERR_ARG;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   ApplyArgs a{};
@@ -205,8 +205,20 @@ int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int
   a.colsum_part = st->owner.colsum_part, a.colsum = st->owner.colsum;
   a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
   a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
+  a.trainer = trainer, a.ortho = ortho, a.grad = grad;
   if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
+}
+
+int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                   void* stream) {
+  return apply_common(st, num, den, nslab, kl_den, 0, 0.f, nullptr, stream);
+}
+
+int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                        float ortho, float* grad, void* stream) {
+  if (!(ortho >= 0.f)) return NMFMU_ERR_ARG;
+  return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream);
 }
 
 int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit) {

@@ -74,6 +74,8 @@ SIGNATURES = {
     'nmfmu_mu_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_mu_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_trainer_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                      C.c_void_p, C.c_void_p]),
     'nmfmu_loss_part_count': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_loss': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_beta_div': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -87,6 +87,10 @@ class HipBackend:
         _capi.check(self.lib.nmfmu_mu_apply(C.byref(st.struct), _ptr(num), _ptr(den), nslab, _ptr(kl_den),
                                             self.stream()), 'nmfmu_mu_apply')
 
+    def trainer_apply(self, st, kl_den, ortho, grad):
+        _capi.check(self.lib.nmfmu_trainer_apply(C.byref(st.struct), None, None, 0, _ptr(kl_den), float(ortho),
+                                                 _ptr(grad), self.stream()), 'nmfmu_trainer_apply')
+
     def loss(self, st, loss_part, out):
         _capi.check(self.lib.nmfmu_loss(C.byref(st.struct), _ptr(loss_part), _ptr(out), self.stream()), 'nmfmu_loss')
 
@@ -300,6 +304,17 @@ class DenseMU:
             self.be.mu_apply(st, num, None, 1, tail)
         else:
             self.be.mu_apply(st, num, tail, 1, None)
+
+    def trainer_step(self, which: str, ortho: float = 0.0, grad: Optional[torch.Tensor] = None):
+        """One parameter update of ``trainer.BetaMu.step`` (trainer.py:72-112): the two backward contractions are the
+        fused kernel's numerator / denominator slabs; ``grad`` (same shape as the factor) receives ``p.grad``."""
+        if self.group is not None:
+            raise NotImplementedError('BetaMu on a column-sharded layer is not implemented')
+        st = self.step_w if which == 'W' else self.step_h
+        assert st is not None
+        other = self.fH if which == 'W' else self.fW
+        self._partial(st, which.lower())
+        self.be.trainer_apply(st, other.colsum if self.kl else None, ortho, grad)
 
     def divergence(self) -> float:
         """beta_div(H W^T, V) (nmf.py:360-361 / 400-401), summed over shards.  One host sync."""

@@ -84,7 +84,10 @@ class BaseComponent(nn.Module):
         W = self.W if W is None else W
         assert H is not None
         assert W is not None
-        return self.reconstruct(H, W)
+        out = self.reconstruct(H, W)
+        # provenance for trainer.BetaMu's single-layer path: which layer, and which factors, produced this tensor
+        out._nmf_source = (self, H, W)
+        return out
 
     @staticmethod
     def reconstruct(H: Tensor, W: Tensor) -> Tensor:

@@ -83,5 +83,19 @@ class OracleBackend:
         st.owner.f.copy_(new)
         self.pack_factor(st.owner, rank, st.r_pad, 0)
 
+    def trainer_apply(self, st, kl_den, ortho, grad):
+        rows, rank = st.owner.f.shape
+        neg = st.slab_num.view(st.nsplit, st.owner.rows_pad, st.r_pad).sum(0)[:rows, :rank]
+        if kl_den is not None:
+            pos = kl_den[:rank].clone().expand(rows, rank)
+        else:
+            pos = st.slab_den.view(st.nsplit, st.owner.rows_pad, st.r_pad).sum(0)[:rows, :rank]
+        new, g = O.betamu_update(st.owner.f, neg, pos, float(st.struct.gamma), float(st.struct.l1),
+                                 float(st.struct.l2), float(ortho))
+        st.owner.f.copy_(new)
+        if grad is not None:
+            grad.copy_(g)
+        self.pack_factor(st.owner, rank, st.r_pad, 0)
+
     def loss(self, st, loss_part, out):
         out[0] = float(O.beta_div(st.owner.f @ st.panel.f.t(), st.xp, float(st.struct.beta)))

@@ -460,3 +460,81 @@ def test_unsupported_combinations_raise(dev):
     assert m.fit(V.to(dev), max_iter=3) == 3       # 'auto' falls back to bf16 for wide ranks
     with pytest.raises(NotImplementedError):
         NMF(V.shape, 300).to(dev).fit(V.to(dev))   # rank > 256
+
+
+# ----------------------------------------------------------------------------------------------------------
+# trainer.BetaMu on one NMF layer -- reference outputs in g7_betamu
+# ----------------------------------------------------------------------------------------------------------
+def _g7_cases():
+    return [str(c) for c in load_golden('g7_betamu')['cases']]
+
+
+@pytest.mark.parametrize('case', _g7_cases())
+def test_betamu_g7_golden(dev, case):
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
+    g = load_golden('g7_betamu')
+    b, pen, which = case.split('_')
+    l1, l2, ortho = {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}[pen]
+    m = NMF(W=t(g['W0']), H=t(g['H0'])).to(dev)
+    params = list(m.parameters()) if which == 'both' else [getattr(m, which)]
+    trainer = BetaMu(params, float(b[1:]), l1, l2, ortho, precision='bf16x3')
+    V = t(g['V']).to(dev)
+
+    def closure():
+        trainer.zero_grad()
+        return V, m()          # the reference's closure form (tests/test_trainer.py:66-68)
+    for it in range(1, 6):
+        trainer.step(closure)
+        if it in (1, 5):
+            assert rel_err(m.W.data.cpu(), g[f'{case}_W{it}']) < TOL
+            assert rel_err(m.H.data.cpu(), g[f'{case}_H{it}']) < TOL
+        if it == 1:
+            last = 'H' if which in ('both', 'H') else 'W'
+            # p.grad = pos - neg is a difference of two nearly equal sums near a fixed point: compare on the scale
+            # of its terms (|pos| + |neg|), which is what 1e-4 relative on pos and neg separately amounts to
+            got, want = getattr(m, last).grad.cpu(), t(g[f'{case}_grad{last}1'])
+            assert float((got - want).norm() / want.norm()) < 2e-3
+    assert m.W.requires_grad and m.H.requires_grad
+
+
+@pytest.mark.parametrize('beta', [-1, 0, 0.5, 1, 1.5, 2, 3])
+@pytest.mark.parametrize('attr', ['W', 'H'])
+def test_betamu_grad_is_beta_div_gradient(dev, beta, attr):
+    """tests/test_trainer.py:54-73 of the reference: after one step p.grad equals the gradient of beta_div(m(), V)
+    at the factors the step STARTED from; here the gradient comes from the oracle's closed form."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
+    g = torch.Generator().manual_seed(77)
+    m = NMF((100, 50)).to(dev)                   # rank defaults to K = 50 (nmf.py:685)
+    W0, H0 = m.W.data.cpu().clone(), m.H.data.cpu().clone()
+    V = torch.rand(100, 50, generator=g) + 1e-3
+    trainer = BetaMu([getattr(m, attr)], beta, precision='bf16x3')
+    Vd = V.to(dev)
+
+    def closure():
+        trainer.zero_grad()
+        return Vd, m
+    trainer.step(closure)
+    Wn, Hn, grads = O.betamu_step(V, W0, H0, beta, params=(attr,))
+    got = getattr(m, attr).grad.cpu()
+    scale = float(grads[attr].abs().max())
+    assert float((got - grads[attr]).abs().max()) < 1e-4 * max(scale, 1.0) * 50
+    assert rel_err(getattr(m, attr).data.cpu(), Wn if attr == 'W' else Hn) < TOL
+    assert bool(torch.all(getattr(m, attr).data >= 0))
+
+
+def test_betamu_rejects_general_graphs_and_cpu_tensors(dev):
+    from torchnmf_amd import _capi
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
+    m = NMF((30, 20), 4).to(dev)
+    V = torch.rand(30, 20, device=dev)
+    tr = BetaMu(m.parameters())
+    with pytest.raises(NotImplementedError):
+        tr.step(lambda: (V, m() * 2.0))          # arithmetic on the prediction: not a single-layer graph
+    with pytest.raises(_capi.NmfmuError):
+        tr.step(lambda: (V.cpu(), m))            # no CPU fallback
+    tr.step(lambda: (V, m()))
+    assert bool(torch.all(m.W >= 0)) and bool(torch.all(m.H >= 0))

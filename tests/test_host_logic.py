@@ -164,6 +164,65 @@ def test_fit_loop_validation_and_verbose(cpu_engine, capsys):
         m.fit(torch.rand(20, 30), precision='fp64')
 
 
+# ---- trainer.BetaMu host logic on the stand-in backend --------------------------------------------------------
+@pytest.mark.parametrize('case', ['b1_plain_both', 'b0.5_pen_both', 'b2_plain_W', 'b3_plain_H', 'b-1_pen_both'])
+def test_betamu_step_matches_reference(cpu_engine, case):
+    from torchnmf_amd.trainer import BetaMu
+    g = load_golden('g7_betamu')
+    b, pen, which = case.split('_')
+    l1, l2, ortho = {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}[pen]
+    m = NMF(W=t(g['W0']), H=t(g['H0']))
+    params = list(m.parameters()) if which == 'both' else [getattr(m, which)]
+    trainer = BetaMu(params, float(b[1:]), l1, l2, ortho)
+    V = t(g['V'])
+    calls = []
+
+    def closure():
+        trainer.zero_grad()
+        calls.append(1)
+        return V, m            # deferred form: the layer itself (no reconstruction on the host in this test)
+    for it in range(1, 6):
+        trainer.step(closure)
+        if it in (1, 5):
+            assert rel_err(m.W.data, g[f'{case}_W{it}']) < 5e-6 and rel_err(m.H.data, g[f'{case}_H{it}']) < 5e-6
+        if it == 1:
+            last = 'H' if which in ('both', 'H') else 'W'
+            assert rel_err(getattr(m, last).grad, g[f'{case}_grad{last}1']) < 5e-6
+    assert len(calls) == 5 * len(params)                       # closure re-evaluated per parameter (trainer.py:72)
+    assert m.W.requires_grad and m.H.requires_grad             # flags restored (trainer.py:117-119)
+
+
+def test_betamu_argument_checks_and_unsupported_graphs(cpu_engine):
+    from torchnmf_amd.trainer import BetaMu
+    m = NMF((12, 9), 3)
+    for kw in ({'l1_reg': -1}, {'l2_reg': -1}, {'orthogonal': -1}):
+        with pytest.raises(ValueError):
+            BetaMu(m.parameters(), **kw)
+    trainer = BetaMu(m.parameters())
+    V = torch.rand(12, 9)
+    with pytest.raises(NotImplementedError):                   # not the direct output of one layer
+        trainer.step(lambda: (V, torch.rand(12, 9)))
+    from torchnmf_amd.nmf import NMFD
+    d = NMFD((1, 9, 12), 3, 2)
+    with pytest.raises(NotImplementedError):
+        BetaMu(d.parameters()).step(lambda: (torch.rand(1, 9, 12), d))
+    # a parameter that does not feed the prediction is skipped, frozen ones are left alone
+    other = torch.nn.Parameter(torch.rand(3, 3))
+    m2 = NMF(W=torch.rand(9, 3), H=torch.rand(12, 3), trainable_H=False)   # (a shape spec ignores trainable_*)
+    H_before = m2.H.data.clone()
+    tr = BetaMu(list(m2.parameters()) + [other])
+    tr.step(lambda: (V, m2))
+    assert torch.equal(m2.H.data, H_before) and other.grad is None and not m2.H.requires_grad
+    # external in-place edits of a factor between steps are picked up (images refreshed)
+    with torch.no_grad():
+        m2.W.mul_(2.0)
+    W_edit = m2.W.data.clone()
+    tr.step(lambda: (V, m2))
+    from oracle import mu_oracle as O
+    W_ref, _, _ = O.betamu_step(V, W_edit, H_before, 1.0, params=('W',))
+    assert rel_err(m2.W.data, W_ref) < 5e-6
+
+
 def test_fused_kernels_do_not_spill_to_scratch(tmp_path):
     """Guard: every instantiation of the rank-128 fused kernel must keep its accumulators in registers
     (a dynamically indexed register array silently moves to scratch memory and runs ~6x slower)."""

@@ -158,3 +158,43 @@ def test_c_oracle_against_golden(beta):
     assert (2 * loss0) ** 0.5 == pytest.approx(float(g[f'b{beta}_a0.1_l0.5_loss_init']), rel=2e-5)
     lib.mu_oracle_c_iterate(p(V), p(W), p(H), N, C, R, beta, 0.05, 0.05, 50, 1, 1)
     assert rel_err(W, g[f'b{beta}_a0.1_l0.5_W50']) < 2e-5 and rel_err(H, g[f'b{beta}_a0.1_l0.5_H50']) < 2e-5
+
+
+# ---- trainer.BetaMu on one layer --------------------------------------------------
+G7_PEN = {'plain': (0.0, 0.0, 0.0), 'pen': (1e-3, 1e-3, 1e-2)}
+
+
+def g7_cases():
+    return [str(c) for c in load_golden('g7_betamu')['cases']]
+
+
+@pytest.mark.parametrize('case', g7_cases())
+def test_g7_betamu_oracle(case):
+    """oracle.betamu_step restates trainer.py:35-121 for a single NMF layer: pinned on the reference's outputs."""
+    g = load_golden('g7_betamu')
+    b, pen, which = case.split('_')
+    beta = float(b[1:])
+    l1, l2, ortho = G7_PEN[pen]
+    params = ('W', 'H') if which == 'both' else (which,)
+    V, W, H = (torch.from_numpy(g[k]) for k in ('V', 'W0', 'H0'))
+    assert list(g['param_order']) == ['W', 'H']
+    for it in range(1, 6):
+        W, H, grads = O.betamu_step(V, W, H, beta, l1, l2, ortho, params)
+        if it in (1, 5):
+            assert rel_err(W, g[f'{case}_W{it}']) < 2e-6 and rel_err(H, g[f'{case}_H{it}']) < 2e-6
+        if it == 1:
+            for n in params:
+                if f'{case}_grad{n}1' in g:
+                    assert rel_err(grads[n], g[f'{case}_grad{n}1']) < 2e-6
+
+
+@pytest.mark.parametrize('beta', [-1, 0, 0.5, 1, 1.5, 2, 3])
+@pytest.mark.parametrize('pen', ['plain', 'pen'])
+def test_g7_aten_port_is_bit_identical(beta, pen):
+    """The CPU-baseline port of BetaMu (bench.py --workload betamu) reproduces the reference bit for bit."""
+    from oracle import aten_port
+    torch.set_num_threads(1)
+    g = load_golden('g7_betamu')
+    V, W0, H0 = (torch.from_numpy(g[k]) for k in ('V', 'W0', 'H0'))
+    W, H = aten_port.betamu_iterations(V, W0, H0, beta, 5, *G7_PEN[pen])
+    assert np.array_equal(W.numpy(), g[f'b{beta}_{pen}_both_W5']) and np.array_equal(H.numpy(), g[f'b{beta}_{pen}_both_H5'])

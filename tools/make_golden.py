@@ -16,6 +16,7 @@ Sets:
   g4_frozen      trainable_W=False and trainable_H=False
   g5_nmfd        NMFD (1,33,50) r4 T=3 ; (1,65,300) r4 T=12 ; (2,20,64) r3 T=5
   g6_beta_div    metrics.beta_div known answers incl. zeros
+  g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
 import os
 import sys
@@ -176,11 +177,50 @@ def g6():
     np.savez_compressed(os.path.join(OUT, 'g6_beta_div.npz'), **out)
 
 
+def g7():
+    """trainer.BetaMu (trainer.py:35-121) driving a single NMF layer, the closure of tests/test_trainer.py:54-73."""
+    from torchnmf.trainer import BetaMu
+    g = torch.Generator().manual_seed(1007)
+    N, C, R = 48, 40, 6
+    V = bf16_round(torch.rand(N, C, generator=g)) + 2.0 ** -7   # strictly positive (beta <= 0 cases)
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy()}
+    cases = []
+    for beta in [-1, 0, 0.5, 1, 1.5, 2, 3]:
+        for name, (l1, l2, ortho) in {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}.items():
+            for which in ('both', 'W', 'H'):
+                if which != 'both' and name == 'pen':
+                    continue
+                m = torchnmf.nmf.NMF(W=W0.clone(), H=H0.clone())
+                params = list(m.parameters()) if which == 'both' else [getattr(m, which)]
+                trainer = BetaMu(params, beta, l1, l2, ortho)
+
+                def closure():
+                    trainer.zero_grad()
+                    return V, m()
+                key = f'b{beta}_{name}_{which}'
+                for it in range(1, 6):
+                    trainer.step(closure)
+                    if it in (1, 5):
+                        out[f'{key}_W{it}'] = m.W.detach().numpy().copy()
+                        out[f'{key}_H{it}'] = m.H.detach().numpy().copy()
+                    if it == 1:
+                        for pn in ('W', 'H'):
+                            gr = getattr(m, pn).grad
+                            if gr is not None and (which in ('both', pn)):
+                                out[f'{key}_grad{pn}1'] = gr.detach().numpy().copy()
+                cases.append(key)
+    out['cases'] = np.array(cases)
+    out['param_order'] = np.array([n for n, _ in torchnmf.nmf.NMF((4, 3), rank=2).named_parameters()])
+    np.savez_compressed(os.path.join(OUT, 'g7_betamu.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6):
+    for fn in (g1, g2, g3, g4, g5, g6, g7):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
