@@ -370,37 +370,87 @@ int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int k
 
 // ------------------------------------------------------------------------------------------------------------
 // reconstruct: out[m][k] = sum_r A[m][r] B[k][r], fp32 in / fp32 out (NMF.reconstruct, nmf.py:691-693).
-// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one wave per 32x32 output tile, operands straight from global
-// (rank <= 256, both operand rows are contiguous in r).  Not on the fit hot loop.
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  128x128 output tile per workgroup (4 waves, 64x64 = 2x2 MFMA tiles
+// each); the rank axis is staged through LDS 32 columns at a time with coalesced float4 loads (row stride 33 floats:
+// the per-lane operand reads A[row j][r] are then conflict free).  Bound by the N x C fp32 store and the fp32 MFMA
+// rate (1/16 of bf16); it is the materialising forward(), not part of the fit loop.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) reconstruct_kernel(const float* __restrict__ A, int M, const float* __restrict__ B,
-                                                         int K, int R, float* __restrict__ out, int64_t ld) {
-  const int lane = threadIdx.x, j = lane & 31, hl = lane >> 5;
-  const int m = blockIdx.y * 32 + j;  // A-operand row (MFMA row i)
-  const int k = blockIdx.x * 32 + j;  // B-operand column (MFMA col j)
-  f32x16 acc;
+constexpr int kRecBK = 32, kRecLD = kRecBK + 1;
+
+__global__ void __launch_bounds__(256) reconstruct_kernel(const float* __restrict__ A, int M, const float* __restrict__ B,
+                                                          int K, int R, float* __restrict__ out, int64_t ld) {
+  __shared__ float sa[128 * kRecLD], sb[128 * kRecLD];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hl = lane >> 5;
+  const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const float* ap = A + (size_t)min(m, M - 1) * R;
-  const float* bp = B + (size_t)min(k, K - 1) * R;
-  for (int r0 = 0; r0 < R; r0 += 2) {  // wave-uniform trip count; the odd tail feeds zeros
-    const int r = r0 + hl;
-    const float av = r < R ? ap[r] : 0.f;
-    const float bv = r < R ? bp[r] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-  }
-  if (k < K) {
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = blockIdx.y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-      if (row < M) out[(size_t)row * ld + k] = acc[e];
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const bool vec = (R & 3) == 0;   // float4 loads need 16-byte aligned rows
+  for (int r0 = 0; r0 < R; r0 += kRecBK) {
+    // stage A[m0 .. m0+127][r0 .. r0+31] and B likewise (zero fill outside the matrix)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = p * 256 + tid, row = idx >> 3, c4 = (idx & 7) * 4;
+      float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+      const int r = r0 + c4;
+      if (m0 + row < M && r < R) {
+        const float* ap = A + (size_t)(m0 + row) * R + r;
+        if (vec) {
+          const float4 v = *reinterpret_cast<const float4*>(ap);
+          av[0] = v.x, av[1] = v.y, av[2] = v.z, av[3] = v.w;
+        } else {
+          for (int i = 0; i < 4 && r + i < R; ++i) av[i] = ap[i];
+        }
+      }
+      if (k0 + row < K && r < R) {
+        const float* bp = B + (size_t)(k0 + row) * R + r;
+        if (vec) {
+          const float4 v = *reinterpret_cast<const float4*>(bp);
+          bv[0] = v.x, bv[1] = v.y, bv[2] = v.z, bv[3] = v.w;
+        } else {
+          for (int i = 0; i < 4 && r + i < R; ++i) bv[i] = bp[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sa[row * kRecLD + c4 + i] = av[i], sb[row * kRecLD + c4 + i] = bv[i];
     }
+    __syncthreads();
+    const float* pa = sa + (wm * 64 + j) * kRecLD + hl;
+    const float* pb = sb + (wn * 64 + j) * kRecLD + hl;
+#pragma unroll
+    for (int s2 = 0; s2 < kRecBK; s2 += 2) {
+      const float a0 = pa[s2], a1 = pa[32 * kRecLD + s2];
+      const float b0 = pb[s2], b1 = pb[32 * kRecLD + s2];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
   }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int k = k0 + wn * 64 + b * 32 + j;
+      if (k < K) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+          if (row < M) __builtin_nontemporal_store(acc[a][b][e], out + (size_t)row * ld + k);
+        }
+      }
+    }
 }
 
 int launch_reconstruct(const float* A, int M, const float* B, int K, int R, float* out, int64_t ld, hipStream_t s) {
-  dim3 grid((K + 31) / 32, (M + 31) / 32);
-  hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(64), 0, s, A, M, B, K, R, out, ld);
+  dim3 grid((K + 127) / 128, (M + 127) / 128);
+  hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, s, A, M, B, K, R, out, ld);
   return (int)hipGetLastError();
 }
 

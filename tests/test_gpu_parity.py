@@ -294,6 +294,20 @@ def test_forward_shapes(dev):
     assert rel_err(y.cpu(), m.H.data.cpu() @ m.W.data.cpu().t()) < 1e-6
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 1), (33, 130, 7), (128, 128, 32), (300, 257, 33), (513, 1000, 128), (200, 90, 256)])
+def test_reconstruct_shapes(dev, shape):
+    """NMF.reconstruct (nmf.py:691-693): ragged tiles, ranks that are not multiples of 4 / 32, explicit factors."""
+    from torchnmf_amd.nmf import NMF
+    N, C, R = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    H, W = torch.rand(N, R, generator=g), torch.rand(C, R, generator=g)
+    y = NMF.reconstruct(H.to(dev), W.to(dev))
+    assert y.shape == (N, C) and y.is_contiguous()
+    assert rel_err(y.cpu(), (H.double() @ W.double().t()).float()) < 1e-6
+    m = NMF(W=W, H=H).to(dev)
+    assert torch.equal(m(), y) and torch.equal(m(H=H.to(dev) * 2), NMF.reconstruct(H.to(dev) * 2, W.to(dev)))
+
+
 @pytest.mark.parametrize('beta', [-1, 0, 0.5, 1, 1.5, 2, 3])
 @pytest.mark.parametrize('tol', [0, 1e-4])
 @pytest.mark.parametrize('alpha,l1_ratio', [(0, 0), (0.1, 0.5)])
