@@ -15,7 +15,7 @@ __device__ __forceinline__ uint32_t pk(float a, float b) { f32x2 v = {a, b}; bf1
 
 template <int WAVES, bool FENCE, int MEM>
 __global__ void __launch_bounds__(64 * WAVES) model(float* out, const u32x4* xin, int iters, const char* big) {
-  __shared__ __attribute__((aligned(16))) char lds[65536];
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // 64 KiB panel area + X ring (MEM >= 4)
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 8192; i += blockDim.x) ((uint32_t*)lds)[i] = 0x3f803f80u;
   __syncthreads();
@@ -32,13 +32,25 @@ __global__ void __launch_bounds__(64 * WAVES) model(float* out, const u32x4* xin
   auto tile = [&](f32x16(&sc)[2], f32x16(&sn)[2]) {
     if (MEM) {   // 8 LDS-DMA pieces (panel from a small, cache-resident region) + 4 X loads (streamed) per tile
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
+      for (int p = 0; p < (WAVES == 8 ? 4 : 8); ++p) {   // 32 KiB of panel per tile and workgroup
         const unsigned la = __builtin_amdgcn_readfirstlane(32768u + (unsigned)((tilecount & 1) * 8192 + p * 1024 + (wave & 0) ));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(big + (size_t)(p * 4096 + (tilecount & 63) * 32768) + threadIdx.x * 16), "s"(la) : "memory", "m0");
       }
       if (MEM == 2) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) x[qq] = __builtin_nontemporal_load((const u32x4*)(gsrc + (size_t)(tilecount & 63) * 16384 + qq * 1024));
+      }
+      if (MEM >= 4) {   // X through an LDS ring by DMA, D = MEM - 3 tiles ahead; this wave's 4 KiB piece of slot (t + D) % (D + 1)
+        constexpr int D = MEM - 3;
+        const unsigned slot = (unsigned)((tilecount + D) % (D + 1));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const unsigned la = __builtin_amdgcn_readfirstlane(65536u + slot * (WAVES * 4096u) + (unsigned)wave * 4096u + qq * 1024u);
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc + (size_t)(tilecount & 63) * 16384 + qq * 1024), "s"(la) : "memory", "m0");
+        }
+        const unsigned rs = (unsigned)(tilecount % (D + 1));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) x[qq] = *(const u32x4*)(lds + 65536 + rs * (WAVES * 4096) + wave * 4096 + qq * 1024 + lane * 16);
       }
       if (MEM == 3) {   // X two tiles ahead: rotate (moves are free beside MFMAs), load the far set
 #pragma unroll
@@ -78,7 +90,8 @@ __global__ void __launch_bounds__(64 * WAVES) model(float* out, const u32x4* xin
       on[rt] = mf(nh, bh, on[rt]);
       if (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
-    if (MEM == 3) { __builtin_amdgcn_s_waitcnt(4 | (7 << 4) | (15 << 8)); __builtin_amdgcn_s_barrier(); }
+    if (MEM >= 5) { __builtin_amdgcn_s_waitcnt(4 | (7 << 4) | (15 << 8)); __builtin_amdgcn_s_barrier(); }
+    else if (MEM == 3) { __builtin_amdgcn_s_waitcnt(4 | (7 << 4) | (15 << 8)); __builtin_amdgcn_s_barrier(); }
     else if (MEM) { __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)); __syncthreads(); }
   };
   for (int it = 0; it < iters; it += 2) {
@@ -97,10 +110,12 @@ __global__ void __launch_bounds__(64 * WAVES) model(float* out, const u32x4* xin
 template <int WAVES, bool FENCE, int MEM>
 void run(float* out, const u32x4* xin, const char* big) {
   const int iters = 2000, blocks = 256;
-  hipLaunchKernelGGL((model<WAVES, FENCE, MEM>), dim3(blocks), dim3(64 * WAVES), 0, 0, out, xin, iters, big);
+  const size_t ldsb = 65536 + (MEM >= 4 ? (MEM - 2) * WAVES * 4096 : 0);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(model<WAVES, FENCE, MEM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  hipLaunchKernelGGL((model<WAVES, FENCE, MEM>), dim3(blocks), dim3(64 * WAVES), ldsb, 0, out, xin, iters, big);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((model<WAVES, FENCE, MEM>), dim3(blocks), dim3(64 * WAVES), 0, 0, out, xin, iters, big);
+  hipLaunchKernelGGL((model<WAVES, FENCE, MEM>), dim3(blocks), dim3(64 * WAVES), ldsb, 0, out, xin, iters, big);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double mfmas = (double)iters * 32;
@@ -113,6 +128,8 @@ int main() {
   char* big; hipMalloc(&big, (size_t)2100 << 20); hipMemset(big, 0x3f, (size_t)2100 << 20);
   run<4, true, 0>(out, xin, big); run<4, true, 1>(out, xin, big); run<4, true, 2>(out, xin, big);
   run<8, true, 0>(out, xin, big); run<8, true, 1>(out, xin, big); run<8, true, 2>(out, xin, big);
-  run<4, true, 3>(out, xin, big); run<8, true, 3>(out, xin, big); run<4, false, 3>(out, xin, big); run<8, false, 3>(out, xin, big);
+  run<4, true, 3>(out, xin, big); run<8, true, 3>(out, xin, big);
+  run<8, true, 4>(out, xin, big); run<8, true, 5>(out, xin, big); run<8, true, 6>(out, xin, big);
+  run<4, true, 4>(out, xin, big); run<4, true, 5>(out, xin, big); run<4, true, 6>(out, xin, big);
   return 0;
 }
