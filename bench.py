@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--stage', type=int, default=None, help='0 = register staging, 1 = LDS-DMA (default)')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph instead of launching '
+                    'every kernel eagerly (measured no faster on MI355X; fit() does this with TORCHNMF_AMD_GRAPH=1)')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
     ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
@@ -125,10 +127,16 @@ def main_nmfd(a):
         eng.h_step()
     for _ in range(a.warmup):
         step()
+    graph = None
+    if a.graph:
+        os.environ['TORCHNMF_AMD_GRAPH'] = '1'
+        from torchnmf_amd.engine import capture_iteration
+        graph = capture_iteration(step)
+    run = graph.replay if graph is not None else step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        run()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
     flops = (4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T
@@ -161,7 +169,8 @@ def main_nmfd(a):
         'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
         'data': 'synthetic',
         'config': {'workload': f'NMFD 1x{Cc}x{L} rank={R} T={T} beta={beta:g} (BASELINE configs[3])',
-                   'precision': a.precision, 'parallelism': 'single GPU (replicas only)'},
+                   'precision': a.precision, 'parallelism': 'single GPU (replicas only)',
+                   'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(ach / peak, 4), 'traffic': None, 'kernel': 'nmfmu::nt_gemm_kernel (EPI_RATIO)',
                      'avg_launch_ms': round(gemm_ms, 5),
@@ -239,10 +248,16 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    graph = None
+    if a.graph and not betamu:
+        os.environ['TORCHNMF_AMD_GRAPH'] = '1'
+        from torchnmf_amd.engine import capture_iteration
+        graph = capture_iteration(step, group)       # None on the sharded path: the all-reduce stays eager
+    run = graph.replay if graph is not None else step
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        run()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -312,7 +327,8 @@ def main():
                                    f'NMF {N}x{C} rank={R} beta={beta:g}' + (' (BASELINE configs[1])' if (N, C, R, beta) == (4096, 65536, 128, 1.0) else ''),
                        'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
-                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows},
+                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows,
+                       'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if betamu:

@@ -131,6 +131,29 @@ class KernelTimer:
             self.h = C.c_void_p()
 
 
+def capture_iteration(fn, group=None):
+    """Capture ``fn`` (one MU iteration: a fixed sequence of launches on fixed buffers) into a hipGraph and return
+    the ``torch.cuda.CUDAGraph``.  Opt-in (TORCHNMF_AMD_GRAPH=1): measured on MI355X / ROCm 7 the replay is no
+    faster than eager launches -- 2 439 vs 2 502 it/s at BASELINE configs[1], 39.9k vs 42.7k it/s at configs[0],
+    1 714 vs 1 715 it/s for NMFD configs[3] -- because the gaps between the dependent kernels of an iteration are
+    device-side dispatch latency, not host launch cost (the host is ~3x ahead of the device at configs[1]).
+    Must be called after ``fn`` has run once eagerly (kernel attributes are set on first launch).  Returns None
+    when graphs are not enabled, on the sharded path (the all-reduce stays eager) or if capture fails."""
+    import os
+    import warnings
+    if group is not None or os.environ.get('TORCHNMF_AMD_GRAPH', '0') != '1' or not torch.cuda.is_available():
+        return None
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+    except Exception as e:  # pragma: no cover - depends on the runtime
+        warnings.warn(f'torchnmf_amd: hipGraph capture failed ({e}); running launches eagerly')
+        torch.cuda.synchronize()
+        return None
+
+
 class FactorBuf:
     """Device state of one factor: the fp32 master (the nn.Parameter's storage) plus its bf16 images."""
 
@@ -232,6 +255,7 @@ class DenseMU:
             self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, br, self.beta,
                                   gamma, l1, l2, need_den=not self.kl)
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
+        self.graphable = isinstance(self.be, HipBackend) and group is None   # an iteration can be replayed as a hipGraph
         self.refresh_images()
         self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)

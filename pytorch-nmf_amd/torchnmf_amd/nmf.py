@@ -148,11 +148,22 @@ class BaseComponent(nn.Module):
             pbar = tqdm(total=max_iter)
         n_iter = -1
         try:
-            for n_iter in range(max_iter):
+            def iteration():
                 if W.requires_grad:
                     eng.w_step()
                 if H.requires_grad:
                     eng.h_step()
+            graph = None
+            for n_iter in range(max_iter):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    iteration()
+                    if n_iter == 0 and max_iter > 2 and getattr(eng, 'graphable', False):
+                        # the launches of an iteration never change: optionally replay them as one hipGraph
+                        # (TORCHNMF_AMD_GRAPH=1; see capture_iteration for why it is not the default)
+                        from .engine import capture_iteration
+                        graph = capture_iteration(iteration, process_group)
                 if n_iter % 10 == 9:
                     loss = (2.0 * eng.divergence()) ** 0.5
                     if pbar is not None:

@@ -96,6 +96,7 @@ class ConvMU:
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
         self.loss_part = torch.empty((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.graphable = True   # fixed launches on fixed buffers: fit() replays an iteration as one hipGraph
         self.refresh_images()
 
     # ------------------------------------------------------------------ helpers

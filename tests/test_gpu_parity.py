@@ -552,3 +552,28 @@ def test_betamu_rejects_general_graphs_and_cpu_tensors(dev):
         tr.step(lambda: (V.cpu(), m))            # no CPU fallback
     tr.step(lambda: (V, m()))
     assert bool(torch.all(m.W >= 0)) and bool(torch.all(m.H >= 0))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# hipGraph replay of the iteration (fit() captures after its first iteration)
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['nmf', 'nmfd'])
+def test_graph_replay_is_bit_identical_to_eager_launches(dev, kind, monkeypatch):
+    from torchnmf_amd.nmf import NMF, NMFD
+    g = torch.Generator().manual_seed(5)
+    if kind == 'nmf':
+        V = torch.rand(300, 500, generator=g)
+        make = lambda: NMF(W=W0.clone(), H=H0.clone()).to(dev)
+        W0, H0 = torch.rand(500, 24, generator=g), torch.rand(300, 24, generator=g)
+    else:
+        V = torch.rand(1, 40, 200, generator=g)
+        W0, H0 = torch.rand(40, 5, 6, generator=g), torch.rand(1, 5, 195, generator=g)
+        make = lambda: NMFD(W=W0.clone(), H=H0.clone()).to(dev)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_GRAPH', mode)
+        m = make()
+        n = m.fit(V.to(dev), beta=1, tol=NO_STOP, max_iter=25)
+        out[mode] = (n, m.W.data.cpu().clone(), m.H.data.cpu().clone())
+    assert out['1'][0] == out['0'][0] == 25
+    assert torch.equal(out['1'][1], out['0'][1]) and torch.equal(out['1'][2], out['0'][2])
