@@ -327,7 +327,7 @@ def main():
                                    f'NMF {N}x{C} rank={R} beta={beta:g}' + (' (BASELINE configs[1])' if (N, C, R, beta) == (4096, 65536, 128, 1.0) else ''),
                        'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
-                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows': eng.block_rows,
+                       'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows_h': eng.step_h.block_rows, 'block_rows_w': eng.step_w.block_rows,
                        'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
             'roofline': roof, 'cpu_baseline': cpu,
         }

@@ -90,6 +90,8 @@ int nmfmu_beta_kind(float beta);          /* NMFMU_BETA_*                       
 int nmfmu_supported(int r_pad, int precision);
 int nmfmu_block_rows(int r_pad, int precision, float beta); /* 128 or 256: owner rows per workgroup tile          */
 int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu);
+/* tile height for ONE half-step of this shape (128 where the owner axis alone fills the chip, else nmfmu_block_rows) */
+int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu);
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision);
 size_t nmfmu_image_bytes(int rows_pad, int r_pad);            /* one plane of p1 or of p2                          */
 size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit);

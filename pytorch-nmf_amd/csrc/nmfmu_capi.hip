@@ -103,6 +103,10 @@ int nmfmu_block_rows(int r_pad, int precision, float beta) {
   // 128-row tiles (two workgroups per CU, two waves per SIMD) measure faster than the 256-row variant (one wave per
   // SIMD, every LDS operand read shared by two MFMAs) on MI355X today: 0.154 vs 0.179 ms per half-step at
   // 4096x65536 r128.  The 256-row kernels stay built and selectable (block_rows = 256) where has_g2() holds.
+#if NMFMU_SP
+  // the eight-wave software-pipelined kernel works on 256-row tiles (beta == 1, bf16, padded rank 128)
+  if (r_pad == 128 && precision == NMFMU_PREC_BF16 && nmfmu_beta_kind(beta) == NMFMU_BETA_KL) return 256;
+#endif
   (void)r_pad, (void)precision, (void)beta;
   return 128;
 }
@@ -117,6 +121,15 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
   if (ns > 8) ns = (ns + 7) / 8 * 8;           // same-chunk workgroups then share an XCD (block b runs on XCD b % 8)
   ns = std::min(ns, std::max(1, ktiles / 4));  // at least 4 tiles per workgroup to amortise prologue/epilogue
   return std::max(ns, 1);
+}
+
+int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu) {
+  // A half-step whose owner axis alone fills the chip with 128-row workgroups (no contraction split) keeps the
+  // 128-row tile: the MU apply then runs in the epilogue, which measures faster at two workgroups per CU
+  // (0.172 vs 0.178 ms at configs[1]'s W half-step).  Split half-steps take nmfmu_block_rows()'s tile.
+  const int ns128 = nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, 128, num_cu);
+  if (ns128 < 0) return ns128;
+  return ns128 == 1 ? 128 : nmfmu_block_rows(r_pad, precision, beta);
 }
 
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision) {

@@ -53,7 +53,7 @@
 #define NMFMU_SP_FENCE 1
 #endif
 #ifndef NMFMU_SP
-#define NMFMU_SP 0  // cross-tile software pipelining: elementwise(t) beside GEMM1(t+1); measured SLOWER
+#define NMFMU_SP 1  // eight-wave cross-tile software pipelining for beta == 1 / bf16 / rank pad 128 (256-row tiles): +2-6 %
 #endif
 #ifndef NMFMU_RCP_PAIR
 #define NMFMU_RCP_PAIR 0  // 1: beta == 1 with one v_rcp_f32 per two columns (measured 2 % slower)
@@ -131,6 +131,13 @@ struct FusedArgs {
 template <int R_PAD, int BETA, bool X3, int MODE, int G = 1>
 struct FusedCfg {
   static constexpr int BM = 128 * G;
+  // NMFMU_SP: the 256-row instance of the beta == 1 / bf16 / rank-pad-128 MU kernel runs as EIGHT waves of one
+  // 32-row group each (two waves per SIMD, <= 256 VGPRs) with the cross-tile software-pipelined main loop, instead
+  // of four waves of two groups.  Same X packing (wave w' = 2 w + g owns the same rows), same epilogue.
+  static constexpr bool SP = NMFMU_SP && R_PAD == 128 && G == 2 && BETA == kKL && !X3 && MODE == kModeMU;
+  static constexpr int WAVES = SP ? 8 : 4;
+  static constexpr int GW = SP ? 1 : G;      // 32-row groups per wave
+  static constexpr int THREADS = 64 * WAVES;
   static constexpr int KS = R_PAD / 16;      // k-steps of GEMM1 (contraction over rank)
   static constexpr int RT = R_PAD / 32;      // 32-wide rank tiles of GEMM2's output
   static constexpr int ROWB = 2 * R_PAD;     // bytes per P1 row
@@ -146,14 +153,14 @@ struct FusedCfg {
   // three LDS slots (panel DMA two tiles ahead) wherever they fit 160 KiB, else the classic double buffer
   static constexpr bool PIPE3 = NMFMU_PIPE3 && (3 * STAGE_BYTES <= 160 * 1024);
   // software-pipelined path: 3-slot rings for P1, P2 and the X tile (bf16, 128 rows x 64 columns)
-  static constexpr int XTILE = 128 * kBK * 2;
-  static constexpr bool SP = NMFMU_SP && R_PAD <= 128 && G == 1 && BETA == kKL && !X3 && !LOSS;
-  static constexpr int LDS_BYTES = SP ? 3 * (2 * IMG + XTILE) : (PIPE3 ? 3 : 2) * STAGE_BYTES;
+  static constexpr int XTILE = BM * kBK * 2;
+  // pipelined path: two-slot rings for P1 and P2 (one tile of lead), three-slot ring for X (two tiles of lead)
+  static constexpr int LDS_BYTES = SP ? 2 * 2 * IMG + 3 * XTILE : (PIPE3 ? 3 : 2) * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
   // the software-pipelined beta == 1 kernel keeps two S tiles live: it gets the whole register file (one wave per SIMD)
-  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1 || SP) ? 1 : 2;
+  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1) ? 1 : 2;   // (SP: 512 threads, 1 workgroup)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -219,9 +226,11 @@ __device__ __forceinline__ float loss_elem(float s, float x, float beta) {
   }
 }
 
-template <int R_PAD, int BETA, bool X3, int MODE, int STAGE, int G>
-__global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW)) fused_kernel(const FusedArgs a) {
-  using C = FusedCfg<R_PAD, BETA, X3, MODE, G>;
+template <int R_PAD, int BETA, bool X3, int MODE, int STAGE, int GT>
+__global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS), (FusedCfg<R_PAD, BETA, X3, MODE, GT>::MINW))
+    fused_kernel(const FusedArgs a) {
+  using C = FusedCfg<R_PAD, BETA, X3, MODE, GT>;
+  constexpr int G = C::GW;   // 32-row groups per wave
   constexpr int BM = C::BM;
   constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, NQ = C::NQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -733,60 +742,59 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
   //     phase B   16 MFMA of GEMM2(t)
   // S ping-pongs through a x2-unrolled loop; the GEMM1 operand image of a tile is DMA'd one tile earlier than its
   // GEMM2 image (P1(t+2) and P2(t+1) are issued at the top of tile t; same two LDS stages as before).
-  constexpr bool kSP = NMFMU_SP && R_PAD <= 128 && G == 1 && BETA == kKL && !X3 && !C::LOSS && STAGE == 1 && NMFMU_ABLATE == 0;
+  constexpr bool kSP = C::SP;
   if constexpr (kSP) {
-    // LDS: P1 ring [3][IMG] | P2 ring [3][IMG] | X ring [3][XTILE].  Everything arrives by LDS-DMA issued from inline
-    // asm (hipcc must not see it), TWO tiles ahead; each tile ends with ONE counted vmcnt + raw s_barrier that lets
-    // exactly this tile's prefetches stay in flight.  Invariant at the start of tile i: P1(i+1), P2(i), X(i) have
-    // landed; P1(i+2), P2(i+1), X(i+1) may be in flight; tile i issues P1(i+3), P2(i+2), X(i+2).
+    // ---------------- cross-tile software-pipelined main loop, eight waves (two per SIMD).
+    // Tile i's elementwise stage is interleaved step by step with GEMM1 of tile i+1 (the S tile ping-pongs between
+    // two register sets), then GEMM2(i) runs.  LDS: P1 ring [2][IMG] | P2 ring [2][IMG] | X ring [3][XTILE] = 160 KiB.
+    // Everything arrives by LDS-DMA issued from inline asm (hipcc must not see it); every tile ends with ONE counted
+    // vmcnt + raw s_barrier that lets exactly this tile's X prefetch stay in flight.
+    // Invariant at the start of tile i: P1(i+1), P2(i), X(i) have landed, X(i+1) may be in flight;
+    // tile i issues P1(i+2), P2(i+1) (needed by the end of this tile) and then X(i+2).
+    static_assert(G == 1 && NQ == 4 && IMG == 16384, "pipelined path: rank pad 128, bf16");
     if (t0 < t1) {
       const int nt = t1 - t0;
       constexpr int PF = 4;
-      constexpr int XT = C::XTILE;
-      constexpr unsigned P1_BASE = 0, P2_BASE = 3 * IMG, X_BASE = 6 * IMG;
-      constexpr int NP = C::PASSES;          // DMA instructions per panel image tile and thread
-      constexpr int NX = XT / 4096;          // DMA instructions per X tile and thread (4)
+      constexpr int XT = C::XTILE;                  // 32 KiB: 256 rows x 64 columns bf16
+      constexpr int PASS = C::THREADS * 16;         // bytes one DMA instruction of the whole workgroup moves (8 KiB)
+      constexpr int NP = IMG / PASS, NX = XT / PASS;   // 2 and 4 DMA instructions per thread
+      constexpr unsigned P1_BASE = 0, P2_BASE = 2 * IMG, X_BASE = 4 * IMG;
       const char* xtile0 = reinterpret_cast<const char*>(a.xp) + (size_t)mb * a.ktiles * XT + tid * 16;
-      auto dma = [&](const char* src, unsigned lds_off, int n) {
+      auto dma = [&](const char* src, unsigned lds_off, auto nc) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          if (p < n) {
-            const unsigned lds_addr = lds_base + lds_off + (unsigned)(p * 4096) + wave_lds;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :
-                         : "v"(src + p * 4096), "s"(lds_addr)
-                         : "memory", "m0");
-          }
+        for (int p = 0; p < decltype(nc)::value; ++p) {
+          const unsigned lds_addr = lds_base + lds_off + (unsigned)(p * PASS) + wave_lds;
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       :
+                       : "v"(src + p * PASS), "s"(lds_addr)
+                       : "memory", "m0");
         }
       };
-      static_assert(NP <= 4 && NX <= 4, "dma helper issues at most 4 pieces");
-      auto issue_p1 = [&](int i, unsigned slot) { dma(img_src[0] + (size_t)(t0 + i) * IMG + tid * 16, P1_BASE + slot * IMG, NP); };
-      auto issue_p2 = [&](int i, unsigned slot) { dma(img_src[1] + (size_t)(t0 + i) * IMG + tid * 16, P2_BASE + slot * IMG, NP); };
-      auto issue_x = [&](int i, unsigned slot) { dma(xtile0 + (size_t)(t0 + i) * XT, X_BASE + slot * XT, NX); };
+      using NPc = std::integral_constant<int, NP>;
+      using NXc = std::integral_constant<int, NX>;
+      auto issue_p1 = [&](int i, unsigned slot) { dma(img_src[0] + (size_t)(t0 + i) * IMG + tid * 16, P1_BASE + slot * IMG, NPc{}); };
+      auto issue_p2 = [&](int i, unsigned slot) { dma(img_src[1] + (size_t)(t0 + i) * IMG + tid * 16, P2_BASE + slot * IMG, NPc{}); };
+      auto issue_x = [&](int i, unsigned slot) { dma(xtile0 + (size_t)(t0 + i) * XT, X_BASE + slot * XT, NXc{}); };
       auto a_off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
       auto b_offs = [&](int step) {
         const int rt = step % RT, c = step / RT;
         return rt * 4096 + b_row + b_off[c >> 1][c & 1];
       };
-      // counted end-of-tile wait: n = DMA instructions this tile issued (they may stay in flight)
-      auto tile_end = [&](int n) {
-        if (n == 2 * NP + NX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + NX) : "memory");
-        else if (n == NP + NX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NX) : "memory");
+      auto tile_end = [&](bool x_in_flight) {
+        if (x_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
       uint32_t gn[2][8];
       f32x16 sA[2], sB[2];
-      // ---- prologue
+      // ---- prologue: tile 0's data and P1(1); X(1) may stay in flight
       issue_p1(0, 0);
       issue_p2(0, 0);
       issue_x(0, 0);
       if (nt > 1) issue_p1(1, 1);
-      int second = 0;
-      if (nt > 2) { issue_p1(2, 2); second += NP; }
-      if (nt > 1) { issue_p2(1, 1); issue_x(1, 1); second += NP + NX; }
-      tile_end(second);                       // the first group (tile 0's data and P1(1)) has landed
+      if (nt > 1) issue_x(1, 1);
+      tile_end(nt > 1);
       {
         const char* sb = smem + P1_BASE;
         u32x4 ring[PF];
@@ -799,25 +807,26 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
           sA[step & 1] = mfma_bf16(ah, qh[0][step >> 1], (step >> 1) == 0 ? epsv : sA[step & 1]);
         }
       }
-      __builtin_amdgcn_s_barrier();           // all waves are done with P1 slot 0 before tile 0 re-fills it
-      // ---- one tile.  Ring slots advance with period 3 (runtime scalars), S ping-pongs with period 2 (static).
-      unsigned sl_cur = 0;                    // slot of tile i: i % 3
-      auto tile_body = [&](int i, auto nextc, f32x16(&sc)[2], f32x16(&sn)[2]) {
-        constexpr bool has_next = decltype(nextc)::value;
-        const unsigned s0 = sl_cur, s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;   // i, i+1, i+2 (mod 3)
-        int issued = 0;
-        if (i + 3 < nt) { issue_p1(i + 3, s0); issued += NP; }                                // slot of P1(i): free
-        if (i + 2 < nt) { issue_p2(i + 2, s2); issue_x(i + 2, s2); issued += NP + NX; }       // slots of tile i-1: free
-        // X(i): this lane's four 16-byte chunks, straight from the LDS ring
+      __builtin_amdgcn_s_barrier();           // every wave is done with P1 slot 0 before tile 0 re-fills it
+      unsigned xs_cur = 0;                    // X ring slot of tile i (i % 3)
+      auto tile_body = [&](int i, auto parc, auto nextc, f32x16(&sc)[2], f32x16(&sn)[2]) {
+        constexpr int par = decltype(parc)::value;            // i & 1
+        constexpr bool has_next = decltype(nextc)::value;     // tile i+1 exists
+        const unsigned xs1 = xs_cur == 2 ? 0 : xs_cur + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+        const bool xf = i + 2 < nt;
+        if (xf) issue_p1(i + 2, par);           // slot of P1(i): GEMM1(i) ran during tile i-1
+        if (has_next) issue_p2(i + 1, par ^ 1); // slot of P2(i-1)
+        if (xf) issue_x(i + 2, xs2);            // slot of X(i-1)
+        // X(i): this lane's four 16-byte chunks from the ring
         u32x4 x[NQ];
         {
-          const char* xs = smem + X_BASE + s0 * XT + wave * 4096 + lane * 16;
+          const char* xs = smem + X_BASE + xs_cur * XT + wave * 4096 + lane * 16;
 #pragma unroll
           for (int q = 0; q < NQ; ++q) x[q] = ld16(xs + q * 1024);
         }
         // ---- phase A: GEMM1(i+1) beside the elementwise stage of tile i
         {
-          const char* sb = smem + P1_BASE + s1 * IMG;
+          const char* sb = smem + P1_BASE + (par ^ 1) * IMG;
           u32x4 ring[PF];
           if constexpr (has_next) {
 #pragma unroll
@@ -826,12 +835,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #pragma unroll
           for (int step = 0; step < 16; ++step) {
             if constexpr (has_next) {
-#pragma unroll
-              for (int u = step * (2 * KS) / 16; u < (step + 1) * (2 * KS) / 16; ++u) {
-                const u32x4 ah = ring[u % PF];
-                if (u + PF < 2 * KS) ring[u % PF] = ld16(sb + a_off(u + PF));
-                sn[u & 1] = mfma_bf16(ah, qh[0][u >> 1], (u >> 1) == 0 ? epsv : sn[u & 1]);
-              }
+              const u32x4 ah = ring[step % PF];
+              if (step + PF < 2 * KS) ring[step % PF] = ld16(sb + a_off(step + PF));
+              sn[step & 1] = mfma_bf16(ah, qh[0][step >> 1], (step >> 1) == 0 ? epsv : sn[step & 1]);
             }
             const int tt = step >> 3, d = step & 7;
             const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
@@ -845,7 +851,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         }
         // ---- phase B: GEMM2(i)
         {
-          const char* sb = smem + P2_BASE + s0 * IMG;
+          const char* sb = smem + P2_BASE + par * IMG;
           u32x4 ring[PF];
 #pragma unroll
           for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + b_offs(p));
@@ -861,19 +867,21 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
 #endif
           }
         }
-        tile_end(issued);
-        sl_cur = s1;
+        tile_end(xf);
+        xs_cur = xs1;
       };
+      using P0 = std::integral_constant<int, 0>;
+      using P1c = std::integral_constant<int, 1>;
       int i = 0;
       for (; i + 2 < nt; i += 2) {   // both tiles of the pair have a successor
-        tile_body(i, std::true_type{}, sA, sB);
-        tile_body(i + 1, std::true_type{}, sB, sA);
+        tile_body(i, P0{}, std::true_type{}, sA, sB);
+        tile_body(i + 1, P1c{}, std::true_type{}, sB, sA);
       }
       if (i == nt - 1) {
-        tile_body(i, std::false_type{}, sA, sB);
+        tile_body(i, P0{}, std::false_type{}, sA, sB);
       } else {                       // i == nt - 2
-        tile_body(i, std::true_type{}, sA, sB);
-        tile_body(i + 1, std::false_type{}, sB, sA);
+        tile_body(i, P0{}, std::true_type{}, sA, sB);
+        tile_body(i + 1, P1c{}, std::false_type{}, sB, sA);
       }
       __syncthreads();               // LDS is reused by the epilogue
     }
@@ -1133,16 +1141,20 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, X3, MODE, G>::MINW
         };
         apply_group(std::integral_constant<int, 0>{});
         if constexpr (G == 2) apply_group(std::integral_constant<int, 1>{});
-        // partial column sums of this workgroup's rows: lane halves, then the four waves (fixed order)
-        float* red = reinterpret_cast<float*>(smem);  // [4][R_PAD]
+        // partial column sums of this workgroup's rows: lane halves, then the waves (fixed order)
+        float* red = reinterpret_cast<float*>(smem);  // [WAVES][R_PAD]
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const float tot = csum[rt] + __shfl_xor(csum[rt], 32, 64);
           if (hl == 0) red[wave * R_PAD + rt * 32 + j] = tot;
         }
         __syncthreads();
-        for (int r = tid; r < R_PAD; r += 256)
-          a.colsum_part[(size_t)mb * R_PAD + r] = (red[r] + red[R_PAD + r]) + (red[2 * R_PAD + r] + red[3 * R_PAD + r]);
+        for (int r = tid; r < R_PAD; r += C::THREADS) {
+          float tot = (red[r] + red[R_PAD + r]) + (red[2 * R_PAD + r] + red[3 * R_PAD + r]);
+          if constexpr (C::WAVES == 8)
+            tot += (red[4 * R_PAD + r] + red[5 * R_PAD + r]) + (red[6 * R_PAD + r] + red[7 * R_PAD + r]);
+          a.colsum_part[(size_t)mb * R_PAD + r] = tot;
+        }
       }
     }
     if (!fused_done) {
@@ -1182,7 +1194,7 @@ int launch_one(const FusedArgs& a, int grid, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, a);
   return (int)hipGetLastError();
 }
 

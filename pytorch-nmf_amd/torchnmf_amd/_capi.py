@@ -62,6 +62,7 @@ SIGNATURES = {
     'nmfmu_beta_kind': (C.c_int, [C.c_float]),
     'nmfmu_supported': (C.c_int, [C.c_int, C.c_int]),
     'nmfmu_block_rows': (C.c_int, [C.c_int, C.c_int, C.c_float]),
+    'nmfmu_step_block_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     'nmfmu_choose_nsplit': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_xp_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_image_bytes': (C.c_size_t, [C.c_int, C.c_int]),

@@ -50,6 +50,13 @@ class HipBackend:
     def block_rows(self, r_pad: int, precision: int, beta: float) -> int:
         return self.lib.nmfmu_block_rows(r_pad, precision, beta)
 
+    def step_block_rows(self, m_pad: int, k_pad: int, r_pad: int, precision: int, beta: float, device) -> int:
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        br = self.lib.nmfmu_step_block_rows(m_pad, k_pad, r_pad, precision, beta, ncu)
+        if br not in (128, 256):
+            _capi.check(br if br < 0 else _capi.ERR_ARG, 'nmfmu_step_block_rows')
+        return br
+
     def choose_nsplit(self, m_pad: int, k_pad: int, block_rows: int, device) -> int:
         ncu = torch.cuda.get_device_properties(device).multi_processor_count
         return self.lib.nmfmu_choose_nsplit(m_pad, k_pad, block_rows, ncu)
@@ -241,7 +248,14 @@ class DenseMU:
         # validation flags of nmf.py:329-336: [any(!(v >= 0)), min bit pattern]
         self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
         n_pad, c_pad = self.fH.rows_pad, self.fW.rows_pad
-        br = self.be.block_rows(self.r_pad, self.precision, self.beta) if block_rows is None else block_rows
+        # tile height per half-step (the two packed copies of V are independent): the library's choice, or forced
+        def tile_rows(m_pad, k_pad):
+            if block_rows is not None:
+                return block_rows
+            if hasattr(self.be, 'step_block_rows'):
+                return self.be.step_block_rows(m_pad, k_pad, self.r_pad, self.precision, self.beta, dev)
+            return self.be.block_rows(self.r_pad, self.precision, self.beta)
+        br = tile_rows(n_pad, c_pad)
         self.block_rows = br
         # H half-step and loss: owner axis N, contraction over C
         xp_h = self.be.pack_x(V, False, self.precision, br, n_pad, c_pad, self.flags)
@@ -250,9 +264,10 @@ class DenseMU:
                               l1, l2, need_den=not self.kl)
         self.step_w = None
         if update_W:
-            xp_w = self.be.pack_x(V, True, self.precision, br, c_pad, n_pad, None)
-            ns_w = self.be.choose_nsplit(c_pad, n_pad, br, dev)
-            self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, br, self.beta,
+            brw = tile_rows(c_pad, n_pad)
+            xp_w = self.be.pack_x(V, True, self.precision, brw, c_pad, n_pad, None)
+            ns_w = self.be.choose_nsplit(c_pad, n_pad, brw, dev)
+            self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, brw, self.beta,
                                   gamma, l1, l2, need_den=not self.kl)
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
         self.graphable = isinstance(self.be, HipBackend) and group is None   # an iteration can be replayed as a hipGraph

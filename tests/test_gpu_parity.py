@@ -192,6 +192,34 @@ def test_half_steps_bf16(dev, beta, stage, block_rows):
     assert l0 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(H0, W0), V, beta)), rel=2e-3)
 
 
+@pytest.mark.parametrize('cols,nsplit', [(256, 1), (320, 1), (576, 3), (1100, 2), (2300, 8), (4100, 3)])
+@pytest.mark.parametrize('regs', [(0.0, 0.0), (0.05, 0.05)])
+def test_rank128_bf16_kl_tile_variants(dev, cols, nsplit, regs, monkeypatch):
+    """The beta == 1 / bf16 / rank-pad-128 kernel in both workgroup shapes (128-row tiles; 256-row tiles = the
+    eight-wave software-pipelined loop when the library is built with it).  The contraction split is forced so that
+    workgroups get 1, 2, 3, ... tiles (prologue / odd-even tail paths of the pipelined loop), and the W half-step runs
+    both with the apply fused in the epilogue (nsplit 1) and through slabs."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd import engine
+    g = torch.Generator().manual_seed(cols + nsplit)
+    N, C, R = 520, cols, 100
+    V = torch.rand(N, C, generator=g).bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    monkeypatch.setattr(engine.HipBackend, 'choose_nsplit', lambda self, m, k, br, d: min(nsplit, max(1, k // 64)))
+    out = {}
+    for br in (128, 256):
+        out[br] = _one_iter(dev, V, W0, H0, 1, 'bf16', 1, alpha=sum(regs), l1r=0.5, block_rows=br)
+    Wr = O.nmf_w_step(V, W0, H0, 1, 1.0, *regs)
+    Hr = O.nmf_h_step(V, Wr, H0, 1, 1.0, *regs)
+    for br in (128, 256):
+        W1, H1, l0, l1 = out[br]
+        assert rel_err(W1, Wr) < 5e-3 and rel_err(H1, Hr) < 5e-3, (br, rel_err(W1, Wr), rel_err(H1, Hr))
+        assert l0 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(H0, W0), V, 1)), rel=2e-3)
+    # same operands, same products: the two tile shapes differ only in summation order
+    assert rel_err(out[256][0], out[128][0]) < 2e-5 and rel_err(out[256][1], out[128][1]) < 2e-5
+
+
 @pytest.mark.parametrize('shape', [(128, 64, 32), (1, 1, 1), (129, 65, 33), (700, 5000, 128), (3000, 260, 100)])
 def test_shapes_and_ksplit(dev, shape):
     """Ragged and degenerate sizes; 5000 columns forces a contraction split (several slabs per owner block)."""
