@@ -293,6 +293,9 @@ def main():
                 'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
                 'note': 'W-step launches carry the MU apply (nmf.py:78-92) in their epilogue when the contraction is '
                         'not split; H-step launches are the bare MFMA main loop + slab stores',
+                'measured_ceilings': {'mfma_only_random_bf16_tflops': 1910,
+                                      'mfma_beside_independent_hbm_stream_at_256_flop_per_byte_tflops': [1045, 1219],
+                                      'source': 'profiles/r01_ubench.md (tools/ubench/mfma_peak.hip, mfma_hbm.hip)'},
                 'achieved_main_loop_only': round(flops_per_launch / (sum(spans['h']) / len(spans['h']) * 1e-3) / 1e12, 2),
                 'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
