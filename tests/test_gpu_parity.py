@@ -469,6 +469,22 @@ def test_sharded_path_world1_rccl(dev):
             Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 60, alpha, 0.5)
             assert n == nr
             assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+        # the throughput kernels (bf16, rank pad 128: eight-wave pipelined H half-step) on the sharded path:
+        # slab_reduce -> packed buffer -> all_reduce -> apply must reproduce the single-device path
+        from torchnmf_amd.engine import DenseMU
+        gg = torch.Generator().manual_seed(9)
+        Vb = torch.rand(700, 2100, generator=gg).bfloat16().float().to(dev)
+        Wb, Hb = torch.randn(2100, 100, generator=gg).abs(), torch.randn(700, 100, generator=gg).abs()
+        res = []
+        for grp in (None, dist.group.WORLD):
+            W, H = Wb.clone().to(dev), Hb.clone().to(dev)
+            eng = DenseMU(Vb, W, H, 1.0, precision='bf16', group=grp)
+            for _ in range(3):
+                eng.w_step()
+                eng.h_step()
+            res.append((W.cpu(), H.cpu(), eng.divergence()))
+        assert rel_err(res[1][0], res[0][0]) < 1e-6 and rel_err(res[1][1], res[0][1]) < 1e-6
+        assert res[1][2] == pytest.approx(res[0][2], rel=1e-6)
     finally:
         dist.destroy_process_group()
 
