@@ -192,7 +192,26 @@ typedef struct nmfmu_gemm_desc {
   void* gp_lo;
   float* out;       /* F32: [m_pad][n_pad]; LOSS: partials */
   int32_t m_valid, n_valid; /* LOSS: logical extent */
+  /* Implicit conv-unfold operands (nmfmu_conv_tables): instead of materialising the Toeplitz matrix
+   * Hu[(b,l)][(r,t)] = H[b][r][l-t] (T times larger than H), an operand may be fetched chunk by chunk from a
+   * window table that is only 8x H.  ops selects which operand is implicit; its *_hi/*_lo then point to the table. */
+  int32_t ops;              /* NMFMU_OPS_* */
+  int32_t t_batch, t_rank, t_taps, t_lh; /* B, R, T, Lh of H (implicit operands only) */
 } nmfmu_gemm_desc;
+
+#define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
+#define NMFMU_OPS_B_HU 1     /* B = Hu : rows (b,l), k = (r,t)  -- reversed-window table  (W half-step reconstruction) */
+#define NMFMU_OPS_B_HUT 2    /* B = HuT: rows (r,t), k = (b,l)  -- forward-window table   (W numerator)              */
+#define NMFMU_OPS_A_HU 3     /* A = Hu                                                     (H half-step reconstruction) */
+
+/* nmfmu_conv_tables: the two window tables of H (B, R, Lh) for T taps, bf16 (hi[, lo]):
+ *   rev[1 + (b R + r) JJ + jj] = { H[b][r][j], H[b][r][j-1], ..., H[b][r][j-7] }     j = jj - (T-1)
+ *   fwd[1 + (b R + r) JJ + jj] = { H[b][r][j], H[b][r][j+1], ..., H[b][r][j+7] }
+ * with JJ = Lh + 2T - 2 (= L + T - 1), entries outside [0, Lh) zero, chunk 0 all zero.  Requires T % 8 == 0 and
+ * (Lh + T - 1) % 8 == 0; nmfmu_conv_table_bytes() gives the size of ONE plane of ONE table. */
+size_t nmfmu_conv_table_bytes(int batch, int rank, int lh, int taps);
+int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, void* rev_hi, void* rev_lo, void* fwd_hi,
+                      void* fwd_lo, void* stream);
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
 

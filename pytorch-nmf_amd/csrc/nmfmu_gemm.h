@@ -15,6 +15,7 @@
 // ds_read side, which makes every ds_read_b128 conflict free (same analysis as the P2 image of nmfmu_layout.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 #include "nmfmu_fused.h"
@@ -38,7 +39,12 @@ struct GemmArgs {
   float* out;            // EPI_F32: [m_pad][n_pad];  EPI_LOSS: [gridDim.x * gridDim.y] partials
   int m_valid, n_valid;  // loss masking
   float beta;
+  // implicit Toeplitz operand (OPS != kOpsPlanes): the operand's *_hi / *_lo point to a window table
+  int tB, tR, tT, tLh;   // H is (B, R, Lh), T taps
 };
+
+// which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
+enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3 };
 
 template <bool X3>
 struct GemmCfg {
@@ -49,7 +55,7 @@ struct GemmCfg {
   static constexpr int LDS_BYTES = 2 * STAGE;
 };
 
-template <bool X3, int EPI, int BETA>
+template <bool X3, int EPI, int BETA, int OPS>
 __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
   using C = GemmCfg<X3>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -73,21 +79,77 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
       for (int pl = 0; pl < C::NPL; ++pl)
         src[op * C::NPL + pl] = bases[op * 2 + pl] + (size_t)(op == 0 ? bm : bn) * 128 * ldk;
   }
+  const char* tab[2] = {nullptr, nullptr};   // window table planes of the implicit operand
+  if constexpr (OPS != kOpsPlanes) {
+    tab[0] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_hi : a.b_hi);
+    tab[1] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_lo : a.b_lo);
+  }
   const int row_t = tid >> 3;                                   // + 32 * p
   const int sslot = (tid & 7) ^ ((row_t >> 1) & 7);             // (row >> 1) & 7 is the same for every pass (32 | 16)
   const size_t thr_off = (size_t)row_t * ldk + sslot * 16;
 
+  // ---- implicit Toeplitz operand (see nmfmu_conv_tables for the table layout).
+  // Its LDS tile is CHUNK-MAJOR, [8 k-chunks][128 rows] x 16 B, and the DMA lanes run along the rows: chunk
+  // c = p*256 + tid  ->  k-chunk c >> 7, row c & 127.  Consecutive rows of one k-chunk are consecutive table entries,
+  // so a wave instruction reads one contiguous KiB (lanes along k instead touch four cache lines per lane quad and
+  // measured 30 % slower), and the fragment reads (lane j = row) are contiguous too: no swizzle needed.
+  constexpr int TOP = OPS == kOpsAHu ? 0 : 1;                 // which operand is implicit
+  constexpr bool kHuRows = OPS == kOpsBHu || OPS == kOpsAHu;  // rows (b,l), k = (r,t); else rows (r,t), k = (b,l)
+  int trow = -1;      // chunk-index contribution of this thread's row (the same in all four passes), -1 = padding row
+  int tL = 0, tJJ = 0, tT8 = 0;
+  // k position of the thread's chunk in pass p (k-chunk 2p + (wave >> 1) of the k-tile), advanced by one k-tile per
+  // stage_issue call, which come strictly in k order (no integer division in the loop):
+  //   rows-(b,l) operand: k = r T + 8 tc  -> (kq, kr) = (r, tc);   rows-(r,t) operand: k = b L + l0 -> (kq, kr) = (b, l0)
+  int kq[4] = {0, 0, 0, 0}, kr[4] = {0, 0, 0, 0};
+  if constexpr (OPS != kOpsPlanes) {
+    tL = a.tLh + a.tT - 1, tJJ = a.tLh + 2 * a.tT - 2, tT8 = a.tT / 8;
+    const int row = (TOP == 0 ? bm : bn) * 128 + (tid & 127);
+    if constexpr (kHuRows) {   // row = b L + l  ->  (b R) JJ + l + (T - 1)
+      const int b = row / tL, l = row - b * tL;
+      trow = b < a.tB ? b * a.tR * tJJ + l + a.tT - 1 : -1;
+    } else {                   // row = r T + t  ->  r JJ - t + (T - 1)
+      const int r = row / a.tT, t = row - r * a.tT;
+      trow = r < a.tR ? r * tJJ - t + a.tT - 1 : -1;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kc = 2 * p + (tid >> 7);
+      if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
+      else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
+    }
+  }
+  auto toep_index = [&](int p) -> int {   // table chunk of (row, k-chunk p); 0 = the all-zero chunk
+    if (trow < 0) return 0;
+    if constexpr (kHuRows) return kq[p] < a.tR ? 1 + trow + kq[p] * tJJ - 8 * kr[p] : 0;
+    else return kq[p] < a.tB ? 1 + trow + kq[p] * a.tR * tJJ + kr[p] : 0;
+  };
+  auto toep_advance = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (kHuRows) {
+        kr[p] += 8;
+        while (kr[p] >= tT8) kr[p] -= tT8, ++kq[p];
+      } else {
+        kr[p] += 64;
+        while (kr[p] >= tL) kr[p] -= tL, ++kq[p];
+      }
+    }
+  };
+
   auto stage_issue = [&](int kt, int buf) {
 #pragma unroll
     for (int im = 0; im < 2 * C::NPL; ++im) {
+      const bool implicit = OPS != kOpsPlanes && (im / C::NPL) == TOP;
       const char* s0 = src[im] + thr_off + (size_t)kt * (C::BK * 2);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         char* dst = smem + buf * C::STAGE + im * C::TILE + p * 4096 + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (size_t)p * 32 * ldk),
+        const char* g = implicit ? tab[im % C::NPL] + (size_t)toep_index(p) * 16 : s0 + (size_t)p * 32 * ldk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
       }
     }
+    if constexpr (OPS != kOpsPlanes) toep_advance();
   };
 
   f32x16 acc[2][2];
@@ -111,14 +173,17 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
     u32x4 ah[2][2], al[2][2], bh[2][2], bl[2][2];
     auto load_frags = [&](int ks, int fb) {
-      const int so = ((2 * ks + hl) << 4) ^ swz;
+      const int so = ((2 * ks + hl) << 4) ^ swz;          // row-major tile: 128-byte rows, XOR-swizzled 16-byte slots
+      const int co = (2 * ks + hl) * 2048;                // chunk-major tile of the implicit operand
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[fb][i] = ld16(sb + a_rowoff + i * 4096 + so);
-        bh[fb][i] = ld16(sb + C::NPL * C::TILE + b_rowoff + i * 4096 + so);
+        const int ao = (OPS == kOpsAHu) ? co + (wm * 64 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
+        const int bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? co + (wn * 64 + i * 32 + j) * 16 : b_rowoff + i * 4096 + so;
+        ah[fb][i] = ld16(sb + ao);
+        bh[fb][i] = ld16(sb + C::NPL * C::TILE + bo);
         if constexpr (X3) {
-          al[fb][i] = ld16(sb + C::TILE + a_rowoff + i * 4096 + so);
-          bl[fb][i] = ld16(sb + 3 * C::TILE + b_rowoff + i * 4096 + so);
+          al[fb][i] = ld16(sb + C::TILE + ao);
+          bl[fb][i] = ld16(sb + 3 * C::TILE + bo);
         }
       }
     };
@@ -194,10 +259,10 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
   }
 }
 
-template <bool X3, int EPI, int BETA>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3>;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -209,6 +274,6 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_gemm(int x3, int epi, int beta_kind, const GemmArgs& a, hipStream_t s);
+int launch_gemm(int x3, int epi, int beta_kind, int ops, const GemmArgs& a, hipStream_t s);
 
 }  // namespace nmfmu

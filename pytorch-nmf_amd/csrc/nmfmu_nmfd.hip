@@ -16,12 +16,19 @@
 
 namespace nmfmu {
 
-int launch_gemm(int x3, int epi, int beta_kind, const GemmArgs& a, hipStream_t s) {
-#define G1(X, E, B) \
-  if (x3 == (X ? 1 : 0) && epi == E && beta_kind == B) return launch_gemm_one<X, E, B>(a, s);
-#define GB(X, E) G1(X, E, kKL) G1(X, E, kEuc) G1(X, E, kIS) G1(X, E, kGen)
-  GB(false, kEpiRatio) GB(true, kEpiRatio) GB(false, kEpiLoss) GB(true, kEpiLoss)
-  if (epi == kEpiF32) return x3 ? launch_gemm_one<true, kEpiF32, kEuc>(a, s) : launch_gemm_one<false, kEpiF32, kEuc>(a, s);
+int launch_gemm(int x3, int epi, int beta_kind, int ops, const GemmArgs& a, hipStream_t s) {
+  // operand combinations that occur (nmfd_engine.py): RATIO with planes | B = Hu | A = Hu; F32 with planes | B = HuT;
+  // LOSS with planes | B = Hu
+#define G1(X, E, B, O) \
+  if (x3 == (X ? 1 : 0) && epi == E && beta_kind == B && ops == O) return launch_gemm_one<X, E, B, O>(a, s);
+#define GB(X, E, O) G1(X, E, kKL, O) G1(X, E, kEuc, O) G1(X, E, kIS, O) G1(X, E, kGen, O)
+  GB(false, kEpiRatio, kOpsPlanes) GB(true, kEpiRatio, kOpsPlanes) GB(false, kEpiLoss, kOpsPlanes) GB(true, kEpiLoss, kOpsPlanes)
+  GB(false, kEpiRatio, kOpsBHu) GB(true, kEpiRatio, kOpsBHu) GB(false, kEpiRatio, kOpsAHu) GB(true, kEpiRatio, kOpsAHu)
+  GB(false, kEpiLoss, kOpsBHu) GB(true, kEpiLoss, kOpsBHu)
+  if (epi == kEpiF32 && ops == kOpsPlanes)
+    return x3 ? launch_gemm_one<true, kEpiF32, kEuc>(a, s) : launch_gemm_one<false, kEpiF32, kEuc>(a, s);
+  if (epi == kEpiF32 && ops == kOpsBHuT)
+    return x3 ? launch_gemm_one<true, kEpiF32, kEuc, kOpsBHuT>(a, s) : launch_gemm_one<false, kEpiF32, kEuc, kOpsBHuT>(a, s);
 #undef GB
 #undef G1
   return -2;
@@ -85,6 +92,41 @@ __global__ void __launch_bounds__(256) pack2d_kernel(Pack2D p, float* dst_f32, u
       if (bad) atomicOr(&flags[0], 1u);
       atomicMin(&flags[1], mn);
     }
+  }
+}
+
+// Window tables of H for the implicit (never materialised) Toeplitz operands -- layout in include/nmfmu.h
+// (nmfmu_conv_tables).  One thread per chunk; the tables are ~8x H (2 MB at BASELINE configs[3]) where the explicit
+// Hu / HuT matrices are T x H each (2 x 52 MB written and 3 x 52 MB read per iteration).
+__global__ void __launch_bounds__(256) conv_tables_kernel(const float* __restrict__ H, int B, int R, int Lh, int T,
+                                                          u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo) {
+  const int JJ = Lh + 2 * T - 2;
+  const int64_t n = 1 + (int64_t)B * R * JJ;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float vr[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vr[e] = vf[e] = 0.f;
+    if (i > 0) {
+      const int64_t k = i - 1;
+      const int br = (int)(k / JJ), j = (int)(k - (int64_t)br * JJ) - (T - 1);
+      const float* row = H + (size_t)br * Lh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int jr = j - e, jf = j + e;
+        if (jr >= 0 && jr < Lh) vr[e] = row[jr];
+        if (jf >= 0 && jf < Lh) vf[e] = row[jf];
+      }
+    }
+    u32x4 rh, rl, fh, fl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h = pack_bf16(vr[2 * e], vr[2 * e + 1]);
+      rh[e] = h, rl[e] = pack_bf16(vr[2 * e] - bf16_lo(h), vr[2 * e + 1] - bf16_hi(h));
+      h = pack_bf16(vf[2 * e], vf[2 * e + 1]);
+      fh[e] = h, fl[e] = pack_bf16(vf[2 * e] - bf16_lo(h), vf[2 * e + 1] - bf16_hi(h));
+    }
+    rev_hi[i] = rh, fwd_hi[i] = fh;
+    if (rev_lo) rev_lo[i] = rl, fwd_lo[i] = fl;
   }
 }
 
@@ -264,6 +306,14 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   a.out = d->out;
   a.m_valid = d->m_valid, a.n_valid = d->n_valid;
   a.beta = d->beta;
+  if (d->ops < NMFMU_OPS_PLANES || d->ops > NMFMU_OPS_A_HU) return NMFMU_ERR_ARG;
+  if (d->ops != NMFMU_OPS_PLANES) {
+    a.tB = d->t_batch, a.tR = d->t_rank, a.tT = d->t_taps, a.tLh = d->t_lh;
+    if (a.tB <= 0 || a.tR <= 0 || a.tT <= 0 || a.tLh <= 0 || a.tT % 8 || (a.tLh + a.tT - 1) % 8) return NMFMU_ERR_ARG;
+    const int64_t bl = (int64_t)a.tB * (a.tLh + a.tT - 1), rt = (int64_t)a.tR * a.tT;   // logical extents of Hu
+    const int hu_rows = d->ops == NMFMU_OPS_A_HU ? d->m_pad : d->n_pad;
+    if (d->ops == NMFMU_OPS_B_HUT ? (hu_rows < rt || d->k_pad < bl) : (hu_rows < bl || d->k_pad < rt)) return NMFMU_ERR_ARG;
+  }
   if (epilogue == NMFMU_EPI_RATIO) {
     if (!a.x || !a.gn_hi || (x3 && !a.gn_lo)) return NMFMU_ERR_ARG;
     if (kind != NMFMU_BETA_KL && (!a.gp_hi || (x3 && !a.gp_lo))) return NMFMU_ERR_ARG;
@@ -274,7 +324,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else {
     return NMFMU_ERR_ARG;
   }
-  return launch_gemm(x3, epilogue, kind, a, S(stream));
+  return launch_gemm(x3, epilogue, kind, d->ops, a, S(stream));
 }
 
 int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t row_outer_stride, int64_t row_inner_stride,
@@ -304,6 +354,21 @@ int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, voi
   const int64_t n = (int64_t)bl_pad * (rp_pad / 8) * 2;
   hipLaunchKernelGGL(conv_unfold_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
                      (uint16_t*)hu_hi, (uint16_t*)hu_lo, (uint16_t*)hut_hi, (uint16_t*)hut_lo, bl_pad, rp_pad);
+  return (int)hipGetLastError();
+}
+
+size_t nmfmu_conv_table_bytes(int batch, int rank, int lh, int taps) {
+  if (batch <= 0 || rank <= 0 || lh <= 0 || taps <= 0) return 0;
+  return (1 + (size_t)batch * rank * (lh + 2 * (size_t)taps - 2)) * 16;
+}
+
+int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, void* rev_hi, void* rev_lo, void* fwd_hi,
+                      void* fwd_lo, void* stream) {
+  if (!h || !rev_hi || !fwd_hi || batch <= 0 || rank <= 0 || lh <= 0 || taps <= 0) return NMFMU_ERR_ARG;
+  if (taps % 8 || (lh + taps - 1) % 8 || (rev_lo == nullptr) != (fwd_lo == nullptr)) return NMFMU_ERR_ARG;
+  const int64_t n = 1 + (int64_t)batch * rank * (lh + 2 * taps - 2);
+  hipLaunchKernelGGL(conv_tables_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                     (u32x4*)rev_hi, (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo);
   return (int)hipGetLastError();
 }
 

@@ -49,10 +49,12 @@ class GemmDesc(C.Structure):
                 ('m_pad', C.c_int32), ('n_pad', C.c_int32), ('k_pad', C.c_int32), ('precision', C.c_int32),
                 ('beta', C.c_float), ('x', C.c_void_p), ('gn_hi', C.c_void_p), ('gn_lo', C.c_void_p),
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
-                ('n_valid', C.c_int32)]
+                ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
+                ('t_taps', C.c_int32), ('t_lh', C.c_int32)]
 
 
 EPI_RATIO, EPI_F32, EPI_LOSS = 0, 1, 2
+OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/nmfmu.h declares
 SIGNATURES = {
@@ -85,6 +87,9 @@ SIGNATURES = {
     'nmfmu_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
     'nmfmu_pack2d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     'nmfmu_conv_unfold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_rank_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

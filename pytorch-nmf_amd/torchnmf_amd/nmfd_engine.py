@@ -16,6 +16,7 @@ NMFD is not sharded across GPUs ("replicas only").
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -38,6 +39,15 @@ class _Planes:
         self.rows_pad, self.cols_pad = rows_pad, cols_pad
         self.hi = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev)
         self.lo = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev) if x3 else None
+
+
+class _Table:
+    """Window table of H standing in for an (implicit) Toeplitz operand: same interface as _Planes."""
+
+    def __init__(self, rows_pad, cols_pad, nbytes, x3, dev):
+        self.rows_pad, self.cols_pad = rows_pad, cols_pad
+        self.hi = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.lo = torch.empty(nbytes, dtype=torch.uint8, device=dev) if x3 else None
 
 
 class ConvMU:
@@ -81,8 +91,17 @@ class ConvMU:
         # operand planes
         self.wm = _Planes(cp, rpp, x3, dev)     # [c][(r,t)]
         self.wmt = _Planes(rpp, cp, x3, dev)    # [(r,t)][c]
-        self.hu = _Planes(blp, rpp, x3, dev)    # [(b,l)][(r,t)]
-        self.hut = _Planes(rpp, blp, x3, dev)   # [(r,t)][(b,l)]
+        # Hu [(b,l)][(r,t)] = H[b][r][l-t] and its transpose: never materialised when the taps and the frame count are
+        # multiples of 8 -- the GEMMs then fetch those operands chunk-wise from two window tables of H that are 8x H
+        # (nmfmu_conv_tables) instead of T x H; otherwise explicit planes rebuilt every iteration (nmfmu_conv_unfold).
+        self.implicit = T % 8 == 0 and L % 8 == 0 and os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1'
+        if self.implicit:
+            nb = self.lib.nmfmu_conv_table_bytes(B, R, Lh, T)
+            self.hu = _Table(blp, rpp, nb, x3, dev)     # reversed windows: rows (b,l), k = (r,t)
+            self.hut = _Table(rpp, blp, nb, x3, dev)    # forward windows:  rows (r,t), k = (b,l)
+        else:
+            self.hu = _Planes(blp, rpp, x3, dev)    # [(b,l)][(r,t)]
+            self.hut = _Planes(rpp, blp, x3, dev)   # [(r,t)][(b,l)]
         self.gn = _Planes(cp, blp, x3, dev)     # W half-step ratio, [c][(b,l)]
         self.gnt = _Planes(blp, cp, x3, dev)    # H half-step ratio, [(b,l)][c]
         self.gp = None if self.kl else _Planes(cp, blp, x3, dev)
@@ -107,10 +126,14 @@ class ConvMU:
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0):
         assert a.cols_pad == b.cols_pad
+        ops = _capi.OPS_PLANES
+        if self.implicit:
+            ops = (_capi.OPS_A_HU if a is self.hu else _capi.OPS_B_HU if b is self.hu else
+                   _capi.OPS_B_HUT if b is self.hut else _capi.OPS_PLANES)
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), a.rows_pad, b.rows_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
-                           _ptr(out), m_valid, n_valid)
+                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
 
     def _pack_w(self):
@@ -121,11 +144,19 @@ class ConvMU:
                                              self.sum_w.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
     def _pack_h(self):
+        if self.implicit:
+            _capi.check(self.lib.nmfmu_conv_tables(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
+                                                   _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), _stream()),
+                        'nmfmu_conv_tables')
+        else:
+            self._unfold()
+        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_part.data_ptr(),
+                                             self.sum_h.data_ptr(), _stream()), 'nmfmu_rank_sums')
+
+    def _unfold(self):
         _capi.check(self.lib.nmfmu_conv_unfold(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
                                                _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), self.bl_pad,
                                                self.rp_pad, _stream()), 'nmfmu_conv_unfold')
-        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_part.data_ptr(),
-                                             self.sum_h.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
     def refresh_images(self):
         self._pack_w()

@@ -444,6 +444,38 @@ def test_nmfd_medium_against_oracle(dev, prec, tol):
     assert n == nr and ew < tol and eh < tol
 
 
+@pytest.mark.parametrize('shape', [(1, 65, 304, 4, 8), (2, 40, 200, 3, 24), (1, 130, 1000, 5, 40), (3, 33, 96, 2, 16)])
+@pytest.mark.parametrize('beta', [1, 2, 0.5])
+def test_nmfd_implicit_toeplitz_operands(dev, shape, beta, monkeypatch):
+    """Taps and frames that are multiples of 8 take the implicit path (GEMM operands fetched from the 8x window
+    tables of H, nmfmu_conv_tables); it must agree with the explicit-unfold path operand for operand (same bf16
+    products, same k order) and with the oracle.  Shapes cover k tiles that straddle rank boundaries (R*T = 72),
+    batches, the minimum tap count and padding rows / columns on every side."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMFD
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_EXPLICIT', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, precision='bf16x3')
+        assert eng.implicit == (mode == '0')
+        l0 = eng.divergence()
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), l0, eng.divergence())
+    assert rel_err(res['0'][0], res['1'][0]) < 1e-6 and rel_err(res['0'][1], res['1'][1]) < 1e-6
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-6) and res['0'][3] == pytest.approx(res['1'][3], rel=1e-6)
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, kind='nmfd')
+    assert rel_err(res['0'][0], Wr) < TOL and rel_err(res['0'][1], Hr) < TOL
+
+
 # ----------------------------------------------------------------------------------------------------------
 # column-sharded path on the real backend (RCCL, world_size 1: the same kernels and collectives as N > 1)
 # ----------------------------------------------------------------------------------------------------------
