@@ -241,6 +241,15 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
 int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
                             const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream);
 
+/* NMF2D / NMF3D (nmf.py:782-942): the same two steps with ndim = 2 or 3 shift axes (lh[ndim], taps[ndim] outermost
+ * first; ndim = 1 is NMFD).  Flattened, (b,l) has batch * prod(lh + taps - 1) rows and (r,t) rank * prod(taps) columns;
+ * everything else of the NMFD sequence (pack2d, gemm, rank_sums, conv_apply_w with taps = prod(taps)) is shared. */
+int nmfmu_convnd_unfold(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
+                        void* hu_hi, void* hu_lo, void* hut_hi, void* hut_lo, int bl_pad, int rp_pad, void* stream);
+int nmfmu_convnd_fold_apply_h(float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
+                              const float* y_num, const float* y_den, const float* kl_den, int bl_pad, float l1,
+                              float l2, float gamma, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */
 int nmfmu_timer_create(int n_events, void** timer);

@@ -229,11 +229,69 @@ def nmfd_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
 
 
 # --------------------------------------------------------------------------
+# NMF2D / NMF3D (nmf.py:782-942): the same model with 2 / 3 shift axes.  V (B,C,*L), W (C,R,*T), H (B,R,*(L-T+1)),
+#   V[b,c,l] ~ sum_{r,t} W[c,r,t] H[b,r,l-t]      (vector l, t; nmf.py:857-860, 937-940: convNd(H, W.flip, pad=T-1))
+# Written as explicit shifted accumulations over the taps (any number of axes), like the NMFD functions above.
+# --------------------------------------------------------------------------
+def _taps(W):
+    import itertools
+    return itertools.product(*[range(k) for k in W.shape[2:]])
+
+
+def _win(t, lh):
+    """Index tuple selecting the window [t_d, t_d + lh_d) on every shift axis (after the two leading axes)."""
+    return (slice(None), slice(None)) + tuple(slice(td, td + n) for td, n in zip(t, lh))
+
+
+def convnd_reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    lh, ks = H.shape[2:], W.shape[2:]
+    out = torch.zeros(H.shape[0], W.shape[0], *[n + k - 1 for n, k in zip(lh, ks)], dtype=H.dtype)
+    for t in _taps(W):
+        out[_win(t, lh)] += torch.einsum('cr,br...->bc...', W[(slice(None), slice(None)) + t], H)
+    return out
+
+
+def _convnd_grad_w(G, H, W):
+    lh = H.shape[2:]
+    out = torch.zeros_like(W)
+    for t in _taps(W):
+        out[(slice(None), slice(None)) + t] = torch.einsum('bc...,br...->cr', G[_win(t, lh)], H)
+    return out
+
+
+def _convnd_grad_h(G, W, H):
+    lh = H.shape[2:]
+    out = torch.zeros_like(H)
+    for t in _taps(W):
+        out += torch.einsum('cr,bc...->br...', W[(slice(None), slice(None)) + t], G[_win(t, lh)])
+    return out
+
+
+def convnd_w_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    gn, gp = mu_terms(V, convnd_reconstruct(H, W), beta)
+    neg = _convnd_grad_w(gn, H, W)
+    if gp is None:   # nmf.py:122-125: H summed over everything but the rank axis, broadcast over (C, R, *T)
+        pos = H.sum([0] + list(range(2, H.dim())), keepdim=True)
+        return _apply(W, neg, pos, True, gamma, l1, l2)
+    return _apply(W, neg, _convnd_grad_w(gp, H, W), False, gamma, l1, l2)
+
+
+def convnd_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
+    gn, gp = mu_terms(V, convnd_reconstruct(H, W), beta)
+    neg = _convnd_grad_h(gn, W, H)
+    if gp is None:   # nmf.py:128-131
+        pos = W.sum([0] + list(range(2, W.dim())), keepdim=True).squeeze(0)
+        return _apply(H, neg, pos, True, gamma, l1, l2)
+    return _apply(H, neg, _convnd_grad_h(gp, W, H), False, gamma, l1, l2)
+
+
+# --------------------------------------------------------------------------
 # fit driver (nmf.py:297-409, dense branch)
 # --------------------------------------------------------------------------
 _STEPS = {
     'nmf': (nmf_reconstruct, nmf_w_step, nmf_h_step),
     'nmfd': (nmfd_reconstruct, nmfd_w_step, nmfd_h_step),
+    'convnd': (convnd_reconstruct, convnd_w_step, convnd_h_step),
 }
 
 

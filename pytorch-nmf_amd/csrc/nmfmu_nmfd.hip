@@ -279,6 +279,84 @@ __global__ void __launch_bounds__(256) conv_fold_apply_h_kernel(float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// NMF2D / NMF3D (nmf.py:782-942): the same unfold / fold with up to three shift axes.  Axes are stored outermost
+// first and missing leading axes have extent 1, so 1-D .. 3-D share this code.  Used by the explicit-operand path
+// only (these layers are small: the reference's own examples are (33,50) x 3x3 and (64,64,100) x 5x5x20).
+// ------------------------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int lh[3], t[3], l[3];   // H extent, taps, V extent (= lh + t - 1) per shift axis
+  int lh_tot, t_tot, l_tot;
+};
+
+// H index of (l flat, t flat), or -1 when l - t leaves H on some axis
+__device__ __forceinline__ int conv_src(const ConvGeom& g, int lf, int tf) {
+  const int l2 = lf % g.l[2], l01 = lf / g.l[2], l1 = l01 % g.l[1], l0 = l01 / g.l[1];
+  const int t2 = tf % g.t[2], t01 = tf / g.t[2], t1 = t01 % g.t[1], t0 = t01 / g.t[1];
+  const int j0 = l0 - t0, j1 = l1 - t1, j2 = l2 - t2;
+  if (j0 < 0 || j0 >= g.lh[0] || j1 < 0 || j1 >= g.lh[1] || j2 < 0 || j2 >= g.lh[2]) return -1;
+  return (j0 * g.lh[1] + j1) * g.lh[2] + j2;
+}
+
+// Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], bf16 (hi[, lo]) zero padded: one thread per 8 consecutive columns
+__global__ void __launch_bounds__(256) convnd_unfold_kernel(const float* __restrict__ H, int B, int R, ConvGeom g,
+                                                            uint16_t* hu_hi, uint16_t* hu_lo, uint16_t* hut_hi,
+                                                            uint16_t* hut_lo, int bl_pad, int rp_pad) {
+  const int64_t n_hu = (int64_t)bl_pad * (rp_pad / 8), n_hut = (int64_t)rp_pad * (bl_pad / 8);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_hu + n_hut; i += (int64_t)gridDim.x * 256) {
+    const bool tr = i >= n_hu;
+    const int64_t k = tr ? i - n_hu : i;
+    const int cols8 = (tr ? bl_pad : rp_pad) / 8;
+    const int row = (int)(k / cols8), c0 = (int)(k % cols8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int bl = tr ? c0 + e : row, rt = tr ? row : c0 + e;   // (b,l) flat and (r,t) flat of this element
+      const int b = bl / g.l_tot, lf = bl - b * g.l_tot, r = rt / g.t_tot, tf = rt - r * g.t_tot;
+      float x = 0.f;
+      if (b < B && r < R) {
+        const int j = conv_src(g, lf, tf);
+        if (j >= 0) x = H[((size_t)b * R + r) * g.lh_tot + j];
+      }
+      v[e] = x;
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t h = pack_bf16(v[2 * e], v[2 * e + 1]);
+      hi[e] = h;
+      lo[e] = pack_bf16(v[2 * e] - bf16_lo(h), v[2 * e + 1] - bf16_hi(h));
+    }
+    const size_t o = (size_t)row * (tr ? bl_pad : rp_pad) + c0;
+    *reinterpret_cast<u32x4*>((tr ? hut_hi : hu_hi) + o) = hi;
+    if (hu_lo) *reinterpret_cast<u32x4*>((tr ? hut_lo : hu_lo) + o) = lo;
+  }
+}
+
+// H (B, R, *lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j + t)].  One thread per element, taps in a fixed order.
+__global__ void __launch_bounds__(256) convnd_fold_apply_h_kernel(float* __restrict__ H, int B, int R, ConvGeom g,
+                                                                  const float* __restrict__ ynum,
+                                                                  const float* __restrict__ yden,
+                                                                  const float* __restrict__ kl_den, int bl_pad,
+                                                                  float l1, float l2, float gamma) {
+  const int64_t n = (int64_t)B * R * g.lh_tot;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int jf = (int)(i % g.lh_tot), br = (int)(i / g.lh_tot), r = br % R, b = br / R;
+    const int j2 = jf % g.lh[2], j01 = jf / g.lh[2], j1 = j01 % g.lh[1], j0 = j01 / g.lh[1];
+    float neg = 0.f, pos = 0.f;
+    int tf = 0;
+    for (int t0 = 0; t0 < g.t[0]; ++t0)
+      for (int t1 = 0; t1 < g.t[1]; ++t1)
+        for (int t2 = 0; t2 < g.t[2]; ++t2, ++tf) {
+          const int lf = ((j0 + t0) * g.l[1] + (j1 + t1)) * g.l[2] + (j2 + t2);
+          const size_t o = ((size_t)r * g.t_tot + tf) * bl_pad + (size_t)b * g.l_tot + lf;
+          neg += ynum[o];
+          if (!kl_den) pos += yden[o];
+        }
+    H[i] = mu_update(H[i], neg, kl_den ? kl_den[r] : pos, kl_den != nullptr, l1, l2, gamma);
+  }
+}
+
 }  // namespace nmfmu
 
 using namespace nmfmu;
@@ -395,6 +473,47 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
   const int grid = batch * rank * ((lh + 63) / 64);
   hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
                      y_num, y_den, kl_den, bl_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+static int make_geom(int nd, const int32_t* lh, const int32_t* taps, ConvGeom* g) {
+  if (nd < 1 || nd > 3 || !lh || !taps) return NMFMU_ERR_ARG;
+  for (int d = 0; d < 3; ++d) g->lh[d] = g->t[d] = g->l[d] = 1;
+  int64_t lt = 1, tt = 1, ht = 1;
+  for (int d = 0; d < nd; ++d) {
+    const int s = 3 - nd + d;
+    if (lh[d] <= 0 || taps[d] <= 0) return NMFMU_ERR_ARG;
+    g->lh[s] = lh[d], g->t[s] = taps[d], g->l[s] = lh[d] + taps[d] - 1;
+    lt *= g->l[s], tt *= taps[d], ht *= lh[d];
+  }
+  if (lt > INT32_MAX / 4 || tt > INT32_MAX / 4) return NMFMU_ERR_ARG;
+  g->l_tot = (int)lt, g->t_tot = (int)tt, g->lh_tot = (int)ht;
+  return 0;
+}
+
+int nmfmu_convnd_unfold(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
+                        void* hu_hi, void* hu_lo, void* hut_hi, void* hut_lo, int bl_pad, int rp_pad, void* stream) {
+  ConvGeom g;
+  if (!h || !hu_hi || !hut_hi || batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g)) return NMFMU_ERR_ARG;
+  if (bl_pad < (int64_t)batch * g.l_tot || rp_pad < (int64_t)rank * g.t_tot || bl_pad % 8 || rp_pad % 8 ||
+      (hu_lo == nullptr) != (hut_lo == nullptr))
+    return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)bl_pad * (rp_pad / 8) * 2;
+  hipLaunchKernelGGL(convnd_unfold_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, g,
+                     (uint16_t*)hu_hi, (uint16_t*)hu_lo, (uint16_t*)hut_hi, (uint16_t*)hut_lo, bl_pad, rp_pad);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_convnd_fold_apply_h(float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
+                              const float* y_num, const float* y_den, const float* kl_den, int bl_pad, float l1,
+                              float l2, float gamma, void* stream) {
+  ConvGeom g;
+  if (!h || !y_num || (!y_den && !kl_den) || batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g))
+    return NMFMU_ERR_ARG;
+  if (bl_pad < (int64_t)batch * g.l_tot) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * rank * g.lh_tot;
+  hipLaunchKernelGGL(convnd_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, g, y_num,
+                     y_den, kl_den, bl_pad, l1, l2, gamma);
   return (int)hipGetLastError();
 }
 

@@ -87,6 +87,11 @@ SIGNATURES = {
     'nmfmu_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
     'nmfmu_pack2d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_convnd_unfold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'nmfmu_convnd_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_void_p]),
     'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

@@ -239,3 +239,34 @@ class NMFD(BaseComponent):
             raise NotImplementedError('NMFD is not sharded (replicas only): sharding L needs a (T-1)-column halo')
         return ConvMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
                       update_W=self.W.requires_grad, update_H=self.H.requires_grad)
+
+
+def _ntuple(x, n):
+    return tuple(x) if isinstance(x, Iterable) else (x,) * n
+
+
+class NMF2D(NMFD):
+    """2-D convolutive NMF ``V[b,c,l,m] ~ sum W[c,r,i,j] H[b,r,l-i,m-j]`` (reference: nmf.py:782-865).  Same engine
+    as NMFD with two shift axes (explicit unfold / fold kernels, nmfmu_convnd_*)."""
+
+    def __init__(self, Vshape=None, rank: Optional[int] = None, kernel_size=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            kernel_size = _ntuple(kernel_size, 2)
+            batch, channel, K, M = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (channel, rank) + kernel_size
+            kwargs['H'] = (batch, rank, K - kernel_size[0] + 1, M - kernel_size[1] + 1)
+        BaseComponent.__init__(self, rank, **kwargs)
+
+
+class NMF3D(NMFD):
+    """3-D convolutive NMF (reference: nmf.py:868-942); three shift axes."""
+
+    def __init__(self, Vshape=None, rank: Optional[int] = None, kernel_size=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            kernel_size = _ntuple(kernel_size, 3)
+            batch, channel, N, K, M = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (channel, rank) + kernel_size
+            kwargs['H'] = (batch, rank, N - kernel_size[0] + 1, K - kernel_size[1] + 1, M - kernel_size[2] + 1)
+        BaseComponent.__init__(self, rank, **kwargs)

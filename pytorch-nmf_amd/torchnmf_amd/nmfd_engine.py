@@ -57,11 +57,19 @@ class ConvMU:
         self.lib = _capi.load()
         if not torch.cuda.is_available():
             raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
-        assert V.dim() == 3 and W.dim() == 3 and H.dim() == 3
-        B, Cc, L = V.shape
-        C_, R, T = W.shape
-        Bh, Rh, Lh = H.shape
-        assert (C_, Rh, Bh) == (Cc, R, B) and Lh == L - T + 1, 'V, W, H shapes are inconsistent'
+        # NMFD has one shift axis, NMF2D / NMF3D two / three (nmf.py:700-942); flattened they are the same problem
+        nd = V.dim() - 2
+        assert nd in (1, 2, 3) and W.dim() == V.dim() and H.dim() == V.dim()
+        B, Cc = V.shape[:2]
+        C_, R = W.shape[:2]
+        Bh, Rh = H.shape[:2]
+        self.ls, self.ts, self.lhs = tuple(V.shape[2:]), tuple(W.shape[2:]), tuple(H.shape[2:])
+        assert (C_, Rh, Bh) == (Cc, R, B) and all(lh == l - t + 1 for lh, l, t in zip(self.lhs, self.ls, self.ts)), \
+            'V, W, H shapes are inconsistent'
+        L, T, Lh = (int(torch.tensor(x).prod()) for x in (self.ls, self.ts, self.lhs))   # flattened extents
+        self.nd = nd
+        self._lh_arr = (C.c_int32 * nd)(*self.lhs)
+        self._t_arr = (C.c_int32 * nd)(*self.ts)
         for t_ in (W, H):
             assert t_.dtype == torch.float32 and t_.is_contiguous()
         if precision in (None, 'auto'):
@@ -94,7 +102,8 @@ class ConvMU:
         # Hu [(b,l)][(r,t)] = H[b][r][l-t] and its transpose: never materialised when the taps and the frame count are
         # multiples of 8 -- the GEMMs then fetch those operands chunk-wise from two window tables of H that are 8x H
         # (nmfmu_conv_tables) instead of T x H; otherwise explicit planes rebuilt every iteration (nmfmu_conv_unfold).
-        self.implicit = T % 8 == 0 and L % 8 == 0 and os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1'
+        self.implicit = (nd == 1 and T % 8 == 0 and L % 8 == 0 and
+                         os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1')
         if self.implicit:
             nb = self.lib.nmfmu_conv_table_bytes(B, R, Lh, T)
             self.hu = _Table(blp, rpp, nb, x3, dev)     # reversed windows: rows (b,l), k = (r,t)
@@ -154,9 +163,15 @@ class ConvMU:
                                              self.sum_h.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
     def _unfold(self):
-        _capi.check(self.lib.nmfmu_conv_unfold(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
-                                               _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), self.bl_pad,
-                                               self.rp_pad, _stream()), 'nmfmu_conv_unfold')
+        if self.nd == 1:
+            _capi.check(self.lib.nmfmu_conv_unfold(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
+                                                   _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), self.bl_pad,
+                                                   self.rp_pad, _stream()), 'nmfmu_conv_unfold')
+        else:
+            _capi.check(self.lib.nmfmu_convnd_unfold(self.H.data_ptr(), self.B, self.R, self.nd, self._lh_arr,
+                                                     self._t_arr, _ptr(self.hu.hi), _ptr(self.hu.lo), _ptr(self.hut.hi),
+                                                     _ptr(self.hut.lo), self.bl_pad, self.rp_pad, _stream()),
+                        'nmfmu_convnd_unfold')
 
     def refresh_images(self):
         self._pack_w()
@@ -185,10 +200,17 @@ class ConvMU:
         self._gemm(self.wmt, self.gnt, _capi.EPI_F32, out=self.y)
         if not self.kl:
             self._gemm(self.wmt, self.gpt, _capi.EPI_F32, out=self.y_den)
-        _capi.check(self.lib.nmfmu_conv_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
-                                                     self.y.data_ptr(), _ptr(self.y_den),
-                                                     self.sum_w.data_ptr() if self.kl else None, self.bl_pad, self.l1,
-                                                     self.l2, self.gamma, _stream()), 'nmfmu_conv_fold_apply_h')
+        kl_den = self.sum_w.data_ptr() if self.kl else None
+        if self.nd == 1:
+            _capi.check(self.lib.nmfmu_conv_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
+                                                         self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,
+                                                         self.l1, self.l2, self.gamma, _stream()),
+                        'nmfmu_conv_fold_apply_h')
+        else:
+            _capi.check(self.lib.nmfmu_convnd_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.nd, self._lh_arr,
+                                                           self._t_arr, self.y.data_ptr(), _ptr(self.y_den), kl_den,
+                                                           self.bl_pad, self.l1, self.l2, self.gamma, _stream()),
+                        'nmfmu_convnd_fold_apply_h')
         self._pack_h()
 
     def divergence(self) -> float:
@@ -199,25 +221,35 @@ class ConvMU:
 
 
 def reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
-    """``NMFD.reconstruct`` (nmf.py:776-779) on the device: Wm @ Hu^T through the split-bf16 GEMM, fp32 out."""
+    """``NMFD / NMF2D / NMF3D.reconstruct`` (nmf.py:776-779, 857-860, 937-940) on the device: Wm @ Hu^T through the
+    split-bf16 GEMM, fp32 out."""
     if H.device.type != 'cuda' or W.device.type != 'cuda':
         raise _capi.NmfmuError('reconstruct: tensors must live on the ROCm device (no CPU fallback)')
     lib = _capi.load()
     Hc, Wc = H.detach().float().contiguous(), W.detach().float().contiguous()
-    B, R, Lh = Hc.shape
-    Cc, R2, T = Wc.shape
+    nd = Hc.dim() - 2
+    assert nd in (1, 2, 3) and Wc.dim() == Hc.dim()
+    B, R = Hc.shape[:2]
+    Cc, R2 = Wc.shape[:2]
     assert R == R2
-    L = Lh + T - 1
+    lhs, ts = tuple(Hc.shape[2:]), tuple(Wc.shape[2:])
+    ls = tuple(lh + t - 1 for lh, t in zip(lhs, ts))
+    L, T = int(torch.tensor(ls).prod()), int(torch.tensor(ts).prod())
     dev = H.device
     cp, blp, rpp = _pad128(Cc), _pad128(B * L), _pad128(R * T)
     wm, hu, hut = _Planes(cp, rpp, True, dev), _Planes(blp, rpp, True, dev), _Planes(rpp, blp, True, dev)
     RT = R * T
     _capi.check(lib.nmfmu_pack2d(Wc.data_ptr(), Cc, RT, 1, RT, 0, 1, 1, 0, cp, rpp, None, _ptr(wm.hi), _ptr(wm.lo), None,
                                  _stream()), 'nmfmu_pack2d')
-    _capi.check(lib.nmfmu_conv_unfold(Hc.data_ptr(), B, R, Lh, T, _ptr(hu.hi), _ptr(hu.lo), _ptr(hut.hi), _ptr(hut.lo),
-                                      blp, rpp, _stream()), 'nmfmu_conv_unfold')
+    if nd == 1:
+        _capi.check(lib.nmfmu_conv_unfold(Hc.data_ptr(), B, R, lhs[0], T, _ptr(hu.hi), _ptr(hu.lo), _ptr(hut.hi),
+                                          _ptr(hut.lo), blp, rpp, _stream()), 'nmfmu_conv_unfold')
+    else:
+        _capi.check(lib.nmfmu_convnd_unfold(Hc.data_ptr(), B, R, nd, (C.c_int32 * nd)(*lhs), (C.c_int32 * nd)(*ts),
+                                            _ptr(hu.hi), _ptr(hu.lo), _ptr(hut.hi), _ptr(hut.lo), blp, rpp, _stream()),
+                    'nmfmu_convnd_unfold')
     out = torch.empty(cp, blp, dtype=torch.float32, device=dev)
     d = _capi.GemmDesc(_ptr(wm.hi), _ptr(wm.lo), _ptr(hu.hi), _ptr(hu.lo), cp, blp, rpp, _capi.PREC_BF16X3, 2.0, None,
-                       None, None, None, None, out.data_ptr(), 0, 0)
+                       None, None, None, None, out.data_ptr(), 0, 0, _capi.OPS_PLANES, 0, 0, 0, 0)
     _capi.check(lib.nmfmu_gemm(C.byref(d), _capi.EPI_F32, _stream()), 'nmfmu_gemm')
-    return out[:Cc, :B * L].reshape(Cc, B, L).permute(1, 0, 2).contiguous()
+    return out[:Cc, :B * L].reshape(Cc, B, *ls).transpose(0, 1).contiguous()

@@ -476,6 +476,42 @@ def test_nmfd_implicit_toeplitz_operands(dev, shape, beta, monkeypatch):
     assert rel_err(res['0'][0], Wr) < TOL and rel_err(res['0'][1], Hr) < TOL
 
 
+@pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
+@pytest.mark.parametrize('beta', [0.5, 1, 2])
+def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
+    """NMF2D / NMF3D (nmf.py:782-942) against the reference's own outputs (g8_convnd)."""
+    from torchnmf_amd import nmf as anmf
+    g = load_golden('g8_convnd')
+    V, W0, H0 = t(g[f'{name}_V']), t(g[f'{name}_W0']), t(g[f'{name}_H0'])
+    m = getattr(anmf, cls)(W=W0, H=H0).to(dev)
+    assert rel_err(m().cpu(), g[f'{name}_recon']) < 1e-5 and tuple(m().shape) == tuple(V.shape)
+    n = m.fit(V.to(dev), beta, NO_STOP, 20, precision='bf16x3')
+    assert n == 20
+    assert rel_err(m.W.data.cpu(), g[f'{name}_b{beta}_W20']) < TOL and rel_err(m.H.data.cpu(), g[f'{name}_b{beta}_H20']) < TOL
+    if beta == 1:
+        m = getattr(anmf, cls)(W=W0, H=H0).to(dev)
+        m.fit(V.to(dev), 1, NO_STOP, 10, alpha=0.1, l1_ratio=0.5, precision='bf16x3')
+        assert rel_err(m.W.data.cpu(), g[f'{name}_reg_W10']) < TOL and rel_err(m.H.data.cpu(), g[f'{name}_reg_H10']) < TOL
+
+
+def test_nmf2d_nmf3d_constructors_and_docstring_shapes(dev):
+    """The reference docstrings' examples (nmf.py:826-836, 909-918) and its constructor rules."""
+    from torchnmf_amd.nmf import NMF2D, NMF3D
+    V = torch.rand(1, 1, 33, 50)
+    m = NMF2D(V.shape, 16, 3)
+    assert tuple(m.W.shape) == (1, 16, 3, 3) and tuple(m.H.shape) == (1, 16, 31, 48) and m.kernel_size == (3, 3)
+    m = m.to(dev)
+    assert tuple(m().shape) == (1, 1, 33, 50)
+    assert m.fit(V.to(dev), max_iter=15) <= 15 and bool(torch.all(m.W >= 0)) and bool(torch.all(m.H >= 0))
+    V3 = torch.rand(1, 3, 16, 16, 20)
+    m3 = NMF3D(V3.shape, 8, (5, 5, 6))
+    assert tuple(m3.W.shape) == (3, 8, 5, 5, 6) and tuple(m3.H.shape) == (1, 8, 12, 12, 15) and m3.rank == 8
+    m3 = m3.to(dev)
+    assert tuple(m3().shape) == tuple(V3.shape)
+    assert m3.fit(V3.to(dev), beta=2, max_iter=10) <= 10
+    assert NMF2D((1, 2, 7, 9), kernel_size=(2, 3)).rank == 7 and NMF3D((1, 2, 5, 7, 9), kernel_size=2).rank == 7
+
+
 # ----------------------------------------------------------------------------------------------------------
 # column-sharded path on the real backend (RCCL, world_size 1: the same kernels and collectives as N > 1)
 # ----------------------------------------------------------------------------------------------------------

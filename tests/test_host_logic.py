@@ -164,6 +164,21 @@ def test_fit_loop_validation_and_verbose(cpu_engine, capsys):
         m.fit(torch.rand(20, 30), precision='fp64')
 
 
+def test_nmf2d_nmf3d_constructors():
+    """nmf.py:842-855, 922-935: shape inference, rank default (the first shift extent), kernel_size attribute."""
+    from torchnmf_amd.nmf import NMF2D, NMF3D
+    m = NMF2D((1, 1, 33, 50), 16, 3)
+    assert tuple(m.W.shape) == (1, 16, 3, 3) and tuple(m.H.shape) == (1, 16, 31, 48) and m.kernel_size == (3, 3)
+    assert NMF2D((2, 5, 7, 9), kernel_size=(2, 3)).rank == 7
+    m = NMF3D((1, 3, 64, 64, 100), 8, (5, 5, 20))
+    assert tuple(m.W.shape) == (3, 8, 5, 5, 20) and tuple(m.H.shape) == (1, 8, 60, 60, 81) and m.out_channels == 3
+    assert NMF3D((1, 2, 5, 7, 9), kernel_size=2).rank == 7
+    m = NMF2D(W=torch.rand(4, 3, 2, 2), H=torch.rand(1, 3, 5, 6), trainable_W=False)
+    assert m.rank == 3 and not m.W.requires_grad and m.H.requires_grad
+    with pytest.raises(_capi.NmfmuError):          # no CPU fallback
+        m()
+
+
 # ---- trainer.BetaMu host logic on the stand-in backend --------------------------------------------------------
 @pytest.mark.parametrize('case', ['b1_plain_both', 'b0.5_pen_both', 'b2_plain_W', 'b3_plain_H', 'b-1_pen_both'])
 def test_betamu_step_matches_reference(cpu_engine, case):

@@ -198,3 +198,19 @@ def test_g7_aten_port_is_bit_identical(beta, pen):
     V, W0, H0 = (torch.from_numpy(g[k]) for k in ('V', 'W0', 'H0'))
     W, H = aten_port.betamu_iterations(V, W0, H0, beta, 5, *G7_PEN[pen])
     assert np.array_equal(W.numpy(), g[f'b{beta}_{pen}_both_W5']) and np.array_equal(H.numpy(), g[f'b{beta}_{pen}_both_H5'])
+
+
+# ---- NMF2D / NMF3D ------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['2d_a', '2d_b', '3d_a'])
+@pytest.mark.parametrize('beta', [0.5, 1, 2])
+def test_g8_convnd_oracle(name, beta):
+    g = load_golden('g8_convnd')
+    V, W0, H0 = (torch.from_numpy(g[f'{name}_{k}']) for k in ('V', 'W0', 'H0'))
+    assert rel_err(O.convnd_reconstruct(H0, W0), g[f'{name}_recon']) < 2e-6
+    W, H, n, losses, _ = O.fit(V, W0, H0, beta, NO_STOP, 20, kind='convnd')
+    assert n == 20
+    assert rel_err(W, g[f'{name}_b{beta}_W20']) < 1e-5 and rel_err(H, g[f'{name}_b{beta}_H20']) < 1e-5
+    assert np.allclose(losses[1:], g[f'{name}_b{beta}_losses'], rtol=1e-5)
+    if beta == 1:
+        W, H, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 10, 0.1, 0.5, kind='convnd')
+        assert rel_err(W, g[f'{name}_reg_W10']) < 1e-5 and rel_err(H, g[f'{name}_reg_H10']) < 1e-5

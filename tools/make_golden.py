@@ -16,6 +16,7 @@ Sets:
   g4_frozen      trainable_W=False and trainable_H=False
   g5_nmfd        NMFD (1,33,50) r4 T=3 ; (1,65,300) r4 T=12 ; (2,20,64) r3 T=5
   g6_beta_div    metrics.beta_div known answers incl. zeros
+  g8_convnd      NMF2D (1,4,20,18) r3 k=(3,4), (2,3,12,10) r2 k=(2,2); NMF3D (1,3,8,9,10) r2 k=(2,3,2): 20 iterations
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
 import os
@@ -216,11 +217,37 @@ def g7():
     np.savez_compressed(os.path.join(OUT, 'g7_betamu.npz'), **out)
 
 
+def g8():
+    """NMF2D / NMF3D (nmf.py:782-942): the conv2d / conv3d members of the NMFD family."""
+    out = {}
+    cases = {'2d_a': (ref_nmf.NMF2D, (1, 4, 20, 18), 3, (3, 4)), '2d_b': (ref_nmf.NMF2D, (2, 3, 12, 10), 2, (2, 2)),
+             '3d_a': (ref_nmf.NMF3D, (1, 3, 8, 9, 10), 2, (2, 3, 2))}
+    for name, (cls, vshape, R, ks) in cases.items():
+        g = torch.Generator().manual_seed(1008 + len(name) + vshape[-1])
+        V = torch.rand(*vshape, generator=g)
+        B, C = vshape[:2]
+        hshape = (B, R) + tuple(l - k + 1 for l, k in zip(vshape[2:], ks))
+        W0 = torch.randn(C, R, *ks, generator=g).abs()
+        H0 = torch.randn(*hshape, generator=g).abs()
+        out[f'{name}_V'], out[f'{name}_W0'], out[f'{name}_H0'] = V.numpy(), W0.numpy(), H0.numpy()
+        for beta in (0.5, 1, 2):
+            W, H, n, losses = run_ref(cls, V, W0, H0, beta, NO_STOP, 20)
+            out[f'{name}_b{beta}_W20'] = W.numpy()
+            out[f'{name}_b{beta}_H20'] = H.numpy()
+            out[f'{name}_b{beta}_losses'] = np.array(losses, dtype=np.float64)
+            out[f'{name}_b{beta}_loss_init'] = np.float64(loss_of(cls, V, W0, H0, beta))
+        W, H, n, _ = run_ref(cls, V, W0, H0, 1, NO_STOP, 10, alpha=0.1, l1_ratio=0.5)
+        out[f'{name}_reg_W10'], out[f'{name}_reg_H10'] = W.numpy(), H.numpy()
+        m = cls(W=W0.clone(), H=H0.clone())
+        out[f'{name}_recon'] = m().detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'g8_convnd.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
