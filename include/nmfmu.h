@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 1
+#define NMFMU_ABI_VERSION 2 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */

@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32)]
 
 
+ABI_VERSION = 2   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS = 0, 1, 2
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
@@ -125,7 +126,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the header and the library diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.nmfmu_abi_version() != 1:
+        if lib.nmfmu_abi_version() != ABI_VERSION:
             raise NmfmuError('libnmfmu.so ABI version mismatch')
         _lib = lib
     return _lib
