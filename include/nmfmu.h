@@ -236,6 +236,12 @@ int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* par
 int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                        const float* kl_den, int rp_pad, float l1, float l2, float gamma, void* stream);
 
+/* nmfmu_conv_apply_w (when update != 0) fused with the re-packing of W into both GEMM operand layouts:
+ * Wm [c_pad][rp_pad] and WmT [rp_pad][c_pad] bf16 planes (hi[, lo]; padding zero).  update == 0 only packs. */
+int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                            const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
+                            void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
+
 /* Folds y[(r,t)][(b,l)] (fp32 [rp_pad][bl_pad]) along the taps, neg[b][r][j] = sum_t y[(r,t)][(b,j+t)], then
  * nmf.py:78-92 for H (batch, rank, lh) in place. */
 int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,

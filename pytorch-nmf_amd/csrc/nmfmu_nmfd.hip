@@ -247,6 +247,55 @@ __global__ void __launch_bounds__(256) conv_apply_w_kernel(float* __restrict__ W
   }
 }
 
+// conv_apply_w + both operand packings in one pass: a 64 (c) x 64 (k = (r,t)) tile of W is updated in place
+// (nmf.py:78-92), kept in LDS, and re-emitted as bf16 planes in both layouts the GEMMs read -- Wm [c_pad][rp_pad]
+// and WmT [rp_pad][c_pad] (zero in the padding).  Replaces conv_apply_w_kernel + two pack2d_kernel launches
+// (11 + 14 + 14 us and two inter-kernel gaps at BASELINE configs[3]).  update == 0: pack only.
+template <bool X3>
+__global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restrict__ W, int C, int RT, int T,
+                                                                const float* __restrict__ num,
+                                                                const float* __restrict__ den,
+                                                                const float* __restrict__ kl_den, int c_pad, int rp_pad,
+                                                                float l1, float l2, float gamma, int update,
+                                                                uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
+                                                                uint16_t* wmt_lo) {
+  constexpr int LDT = 65;
+  __shared__ float tile[64 * LDT];
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {     // consecutive threads along k: coalesced fp32 traffic
+    const int cl = idx >> 6, kl = idx & 63, c = c0 + cl, kk = k0 + kl;
+    float v = 0.f;
+    if (c < C && kk < RT) {
+      const size_t wi = (size_t)c * RT + kk;
+      v = W[wi];
+      if (update) {
+        const size_t o = (size_t)c * rp_pad + kk;
+        v = mu_update(v, num[o], kl_den ? kl_den[kk / T] : den[o], kl_den != nullptr, l1, l2, gamma);
+        W[wi] = v;
+      }
+    }
+    tile[cl * LDT + kl] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * 64 * 8; idx += 256) {  // 16-byte chunks: 512 of Wm (8 consecutive k), 512 of WmT (8 c)
+    const bool tr = idx >= 512;
+    const int q = idx & 511, row = q >> 3, ch = (q & 7) * 8;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = tr ? tile[(ch + 2 * e) * LDT + row] : tile[row * LDT + ch + 2 * e];
+      const float x1 = tr ? tile[(ch + 2 * e + 1) * LDT + row] : tile[row * LDT + ch + 2 * e + 1];
+      const uint32_t h = pack_bf16(x0, x1);
+      hi[e] = h;
+      lo[e] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
+    }
+    const size_t o = tr ? (size_t)(k0 + row) * c_pad + c0 + ch : (size_t)(c0 + row) * rp_pad + k0 + ch;
+    *reinterpret_cast<u32x4*>((tr ? wmt_hi : wm_hi) + o) = hi;
+    if constexpr (X3) *reinterpret_cast<u32x4*>((tr ? wmt_lo : wm_lo) + o) = lo;
+  }
+}
+
 // H (B, R, Lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)], Y fp32 [rp_pad][bl_pad].
 // Block = 64 consecutive j x 4 tap groups (coalesced 256-byte reads along j); the four partial sums are combined
 // through LDS in a fixed order.
@@ -464,6 +513,25 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
   const int64_t n = (int64_t)channels * rank * taps;
   hipLaunchKernelGGL(conv_apply_w_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                      den, kl_den, rp_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                            const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
+                            void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+  if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
+  if (update && (!num || (!den && !kl_den))) return NMFMU_ERR_ARG;
+  if (c_pad < channels || rp_pad < (int64_t)rank * taps || c_pad % 64 || rp_pad % 64 || (wm_lo == nullptr) != (wmt_lo == nullptr))
+    return NMFMU_ERR_ARG;
+  const dim3 grid(rp_pad / 64, c_pad / 64);
+  if (wm_lo)
+    hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
+                       den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo);
+  else
+    hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
+                       den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
+                       nullptr);
   return (int)hipGetLastError();
 }
 

@@ -93,6 +93,9 @@ SIGNATURES = {
     'nmfmu_convnd_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                             C.c_void_p]),
+    'nmfmu_conv_apply_pack_w': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

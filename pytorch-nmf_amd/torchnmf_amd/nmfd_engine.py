@@ -145,10 +145,13 @@ class ConvMU:
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
 
-    def _pack_w(self):
-        RT = self.R * self.T
-        self._pack2d(self.W, self.C, RT, 1, RT, 0, 1, 1, 0, self.c_pad, self.rp_pad, None, self.wm, None)
-        self._pack2d(self.W, RT, self.C, 1, 1, 0, 1, RT, 0, self.rp_pad, self.c_pad, None, self.wmt, None)
+    def _pack_w(self, update: bool = False):
+        """W -> Wm / WmT planes (one kernel); with ``update`` the MU apply of nmf.py:78-92 runs in the same pass."""
+        _capi.check(self.lib.nmfmu_conv_apply_pack_w(
+            self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None,
+            _ptr(self.den_w) if update else None, self.sum_h.data_ptr() if (update and self.kl) else None, self.c_pad,
+            self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
+            _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w')
         _capi.check(self.lib.nmfmu_rank_sums(self.W.data_ptr(), self.C, self.R, self.T, self.sum_part.data_ptr(),
                                              self.sum_w.data_ptr(), _stream()), 'nmfmu_rank_sums')
 
@@ -188,11 +191,7 @@ class ConvMU:
         self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w)
         if not self.kl:
             self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
-        _capi.check(self.lib.nmfmu_conv_apply_w(self.W.data_ptr(), self.C, self.R, self.T, self.num_w.data_ptr(),
-                                                _ptr(self.den_w), self.sum_h.data_ptr() if self.kl else None,
-                                                self.rp_pad, self.l1, self.l2, self.gamma, _stream()),
-                    'nmfmu_conv_apply_w')
-        self._pack_w()
+        self._pack_w(update=True)
 
     def h_step(self):
         """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
