@@ -40,51 +40,18 @@
 #ifndef NMFMU_PIN_SCHED
 #define NMFMU_PIN_SCHED 1
 #endif
-#ifndef NMFMU_ORDER
-#define NMFMU_ORDER 1   // 1: interleave accumulators in both GEMMs
-#endif
-#ifndef NMFMU_PHASED
-#define NMFMU_PHASED 0  // 1: phase-interleaved schedule for the 256-row tile (measured slower than the shared-read body)
-#endif
-#ifndef NMFMU_VALU_PER_MFMA
-#define NMFMU_VALU_PER_MFMA 7
-#endif
 #ifndef NMFMU_SP_FENCE
 #define NMFMU_SP_FENCE 1
 #endif
 #ifndef NMFMU_SP
 #define NMFMU_SP 1  // eight-wave cross-tile software pipelining for beta == 1 / bf16 / rank pad 128 (256-row tiles): +2-6 %
 #endif
-#ifndef NMFMU_RCP_PAIR
-#define NMFMU_RCP_PAIR 0  // 1: beta == 1 with one v_rcp_f32 per two columns (measured 2 % slower)
-#endif
-#ifndef NMFMU_PIPE3
-#define NMFMU_PIPE3 0  // (measured slower: 1 WG/CU, no gain from the deeper pipeline) 3-slot LDS ring + X two tiles ahead, counted vmcnt across raw barriers (LDS-DMA staging only)
-#endif
-#ifndef NMFMU_SETPRIO
-#define NMFMU_SETPRIO 0  // raise wave priority during the MFMA phases
-#endif
 #ifndef NMFMU_X_NT
 #define NMFMU_X_NT 1  // non-temporal loads for the X stream (read once; keeps the factor panel resident in L2)
-#endif
-#ifndef NMFMU_G2C
-#define NMFMU_G2C 0  // 1: chunk-fused tile body for the 256-row tile (8.1 instr/MFMA but measured slower: 0.19 vs 0.17 ms)
-#endif
-#ifndef NMFMU_XSINGLE
-#define NMFMU_XSINGLE 1  // one X register buffer, refilled mid-tile after its last use (0: double buffer)
 #endif
 #ifndef NMFMU_DMA_ASM
 #define NMFMU_DMA_ASM 1  // issue the LDS-DMA from inline asm (keeps hipcc's counted lgkmcnt waits)
 #endif
-#ifndef NMFMU_STAGGER
-#define NMFMU_STAGGER 0  // (measured: no gain on MI355X) rotate each workgroup's tile visiting order (HBM channel de-phasing)
-#endif
-#ifndef NMFMU_XDEPTH
-#define NMFMU_XDEPTH 1  // (2 measured no faster) X tiles prefetched ahead in VGPRs (LDS-DMA staging only)
-#endif
-#ifndef NMFMU_ABLATE
-#define NMFMU_ABLATE 0  // timing experiments only (results are WRONG when non-zero): 1 no elementwise, 2 no barrier/DMA
-#endif                  // after the first tile, 3 no X loads after the first tile, 4 no GEMM1, 5 no GEMM2
 
 namespace nmfmu {
 
@@ -150,12 +117,10 @@ struct FusedCfg {
   static constexpr int P2HI = NPL * IMG;
   static constexpr int P2LO = NPL * IMG + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  // three LDS slots (panel DMA two tiles ahead) wherever they fit 160 KiB, else the classic double buffer
-  static constexpr bool PIPE3 = NMFMU_PIPE3 && (3 * STAGE_BYTES <= 160 * 1024);
   // software-pipelined path: 3-slot rings for P1, P2 and the X tile (bf16, 128 rows x 64 columns)
   static constexpr int XTILE = BM * kBK * 2;
   // pipelined path: two-slot rings for P1 and P2 (one tile of lead), three-slot ring for X (two tiles of lead)
-  static constexpr int LDS_BYTES = SP ? 2 * 2 * IMG + 3 * XTILE : (PIPE3 ? 3 : 2) * STAGE_BYTES;
+  static constexpr int LDS_BYTES = SP ? 2 * 2 * IMG + 3 * XTILE : 2 * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
@@ -184,11 +149,7 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 template <int BETA>
 __device__ __forceinline__ void mu_elem(float s, float x, float beta, float& gn, float& gp) {
   if constexpr (BETA == kKL) {
-#if NMFMU_ABLATE == 6
-    gn = x * s;  // timing experiment: no reciprocal
-#else
     gn = x * __builtin_amdgcn_rcpf(s);
-#endif
     gp = 0.f;
   } else if constexpr (BETA == kEuc) {
     gn = x;
@@ -375,9 +336,6 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
     // The accumulators are seeded with eps through the C operand of each chain's first MFMA (seed tile `epsv`,
     // loop invariant) instead of being re-initialised with 16 moves per tile.
     f32x16 s[G][2];
-#if NMFMU_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     {
       constexpr int NSTEP = 2 * KS;
       constexpr int PF = NSTEP < 4 ? NSTEP : 4;
@@ -385,7 +343,7 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
       u32x4 ring_l[X3 ? PF : 1];
       // step -> (kk, tt): the two S^T tiles alternate, so consecutive MFMAs never share an accumulator
       auto a_off = [&](int step) {
-        const int tt = NMFMU_ORDER ? (step & 1) : step / KS, kk = NMFMU_ORDER ? (step >> 1) : step % KS;
+        const int tt = step & 1, kk = step >> 1;
         return a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
       };
 #pragma unroll
@@ -394,8 +352,8 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
         if constexpr (X3) ring_l[p] = ld16(sb + C::P1LO + a_off(p));
       }
 #pragma unroll
-      for (int step = 0; step < (NMFMU_ABLATE == 4 ? 2 : NSTEP); ++step) {
-        const int tt = NMFMU_ORDER ? (step & 1) : step / KS, kk = NMFMU_ORDER ? (step >> 1) : step % KS;
+      for (int step = 0; step < NSTEP; ++step) {
+        const int tt = step & 1, kk = step >> 1;
         const u32x4 ah = ring_h[step % PF];
         u32x4 al;
         if constexpr (X3) al = ring_l[step % PF];
@@ -424,9 +382,6 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
       }
 #endif
     }
-#if NMFMU_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // ---------------- elementwise: Gn / Gp (or the loss terms), packed to bf16 A operands
     uint32_t gnh[G][2][8], gnl[G][X3 ? 2 : 1][8], gph[G][C::TWO_ACC ? 2 : 1][8], gpl[G][(C::TWO_ACC && X3) ? 2 : 1][8];
 #pragma unroll
@@ -445,13 +400,8 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
             x1 = __builtin_bit_cast(float, u1);
           } else {
             const uint32_t w = x[g][2 * tt + (d >> 2)][d & 3];
-#if NMFMU_ABLATE == 8
-            x0 = __builtin_bit_cast(float, w);  // timing experiment: no unpack
-            x1 = x0;
-#else
             x0 = bf16_lo(w);
             x1 = bf16_hi(w);
-#endif
           }
           const float s0 = s[g][tt][2 * d], s1 = s[g][tt][2 * d + 1];
           if constexpr (C::LOSS) {
@@ -459,31 +409,11 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
             const bool rowok = m0 + 32 * g < a.M;
             lacc += (rowok && k0 < a.K) ? loss_elem<BETA>(s0, x0, a.beta) : 0.f;
             lacc += (rowok && k0 + 1 < a.K) ? loss_elem<BETA>(s1, x1, a.beta) : 0.f;
-          } else if constexpr (NMFMU_RCP_PAIR && BETA == kKL) {
-            // one reciprocal per PAIR of columns: r = 1/(s0*s1), 1/s0 = s1*r, 1/s1 = s0*r (v_rcp_f32 is the slow
-            // transcendental of this stage; the extra multiplies are full rate).  s >= eps = 2^-23, so the product
-            // neither underflows nor (for s < 1e19) overflows; error ~3 ulp.
-            const float r = __builtin_amdgcn_rcpf(s0 * s1);
-            const float n0 = (x0 * s1) * r, n1 = (x1 * s0) * r;
-            const uint32_t nh = pack_bf16(n0, n1);
-            gnh[g][tt][d] = nh;
-            if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
           } else {
             float n0, n1, p0, p1;
-#if NMFMU_ABLATE == 1
-            n0 = s0, n1 = s1, p0 = x0, p1 = x1;
-            gnh[g][tt][d] = __builtin_bit_cast(uint32_t, s0) ^ x[g][0][d & 3];
-            continue;
-#endif
             mu_elem<BETA>(s0, x0, a.beta, n0, p0);
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
-#if NMFMU_ABLATE == 7
-            const uint32_t nh = __builtin_bit_cast(uint32_t, n0) ^ __builtin_bit_cast(uint32_t, n1);  // no cvt_pk
-#elif NMFMU_ABLATE == 10   // truncating pack: one v_perm_b32 instead of v_cvt_pk_bf16_f32
-            const uint32_t nh = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, n1), __builtin_bit_cast(uint32_t, n0), 0x07060302u);
-#else
             const uint32_t nh = pack_bf16(n0, n1);
-#endif
             gnh[g][tt][d] = nh;
             if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
             if constexpr (C::TWO_ACC) {
@@ -497,20 +427,16 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
     }
     // X's registers are dead from here on: fetch the next tile into them now (single X buffer; the loads have the
     // whole GEMM2 + barrier + next GEMM1 to land).
-    if (NMFMU_XSINGLE && t_next >= 0) load_x(t_next, x);
+    if (t_next >= 0) load_x(t_next, x);
     // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
     if constexpr (!C::LOSS) {
-#if NMFMU_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
       constexpr int NSTEP = RT * 4;
       constexpr int PF = 4;
       u32x4 ring_h[PF];
       u32x4 ring_l[X3 ? PF : 1];
       // step -> ((tt, m2), rt): rank tiles innermost, so consecutive MFMAs cycle through the RT accumulators
       auto b_offs = [&](int step) {
-        const int rt = NMFMU_ORDER ? step % RT : step >> 2;
-        const int c = NMFMU_ORDER ? step / RT : step & 3;
+        const int rt = step % RT, c = step / RT;
         return rt * 4096 + b_row + b_off[c >> 1][c & 1];
       };
 #pragma unroll
@@ -519,9 +445,8 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
         if constexpr (X3) ring_l[p] = ld16(sb + C::P2LO + b_offs(p));
       }
 #pragma unroll
-      for (int step = 0; step < (NMFMU_ABLATE == 5 ? RT : NSTEP); ++step) {
-        const int rt = NMFMU_ORDER ? step % RT : step >> 2;
-        const int c = NMFMU_ORDER ? step / RT : step & 3;
+      for (int step = 0; step < NSTEP; ++step) {
+        const int rt = step % RT, c = step / RT;
         const int tt = c >> 1, m2 = c & 1;
         const u32x4 bh = ring_h[step % PF];
         u32x4 bl;
@@ -562,186 +487,9 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
         if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
       }
 #endif
-#if NMFMU_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
   };
 
-  // ---------------- chunk-fused tile body for the 256-row tile (G = 2, beta == 1, bf16 operands).
-  // The SIMDs are instruction-issue bound (a second wave per SIMD adds no throughput), so this body minimises
-  // instructions per MFMA: every LDS operand read feeds two MFMAs (both row groups), and the elementwise stage is
-  // fused into GEMM2 one 8-column chunk at a time, so only 8 packed-P registers are live (S, Q, X stay in VGPRs
-  // with no AGPR shuffling).  Chunk c = (tt, m2) consumes exactly X chunk q = 2*tt + m2 of each lane.
-  auto compute_g2c = [&](int t, int buf, u32x4(&x)[G][NQ], int t_next) {
-    if constexpr (G == 2 && !X3 && !C::LOSS && !C::TWO_ACC) {
-      const char* sb = smem + buf * C::STAGE_BYTES;
-      constexpr int PF = 4;
-      f32x16 s[2][2];
-      {
-        constexpr int NSTEP = 2 * KS;
-        u32x4 ring[PF];
-        auto off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P1HI + off(p));
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-          const int tt = step & 1, kk = step >> 1;
-          const u32x4 ah = ring[step % PF];
-          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P1HI + off(step + PF));
-          s[0][tt] = mfma_bf16(ah, qh[0][kk], kk == 0 ? epsv : s[0][tt]);
-          s[1][tt] = mfma_bf16(ah, qh[1][kk], kk == 0 ? epsv : s[1][tt]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        u32x4 ring[PF];
-        auto off = [&](int step) {  // step -> (chunk c, rank tile rt)
-          const int rt = step % RT, c = step / RT;
-          return rt * 4096 + b_row + b_off[c >> 1][c & 1];
-        };
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P2HI + off(p));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int tt = c >> 1, m2 = c & 1;
-          u32x4 pk[2];
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              const uint32_t w = x[g][2 * tt + m2][d];
-              float n0, n1, p0, p1;
-              mu_elem<BETA>(s[g][tt][8 * m2 + 2 * d], bf16_lo(w), a.beta, n0, p0);
-              mu_elem<BETA>(s[g][tt][8 * m2 + 2 * d + 1], bf16_hi(w), a.beta, n1, p1);
-              pk[g][d] = pack_bf16(n0, n1);
-            }
-          }
-          if (c == 3 && t_next >= 0) load_x(t_next, x);   // X is dead: refill for the next tile
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const int step = c * RT + rt;
-            const u32x4 bh = ring[step % PF];
-            if (step + PF < 4 * RT) ring[step % PF] = ld16(sb + C::P2HI + off(step + PF));
-            on[0][rt] = mfma_bf16(pk[0], bh, on[0][rt]);
-            on[1][rt] = mfma_bf16(pk[1], bh, on[1][rt]);
-          }
-        }
-      }
-    }
-  };
-  constexpr bool kG2C = NMFMU_G2C && G == 2 && !X3 && !C::LOSS && !C::TWO_ACC;
-
-  // ---------------- phase-interleaved tile body for the 256-row tile (G = 2, beta == 1, bf16 operands).
-  // One wave per SIMD cannot rely on a sibling wave to cover its VALU stage, so the two 32-row groups are
-  // software-pipelined against each other inside the wave:
-  //     slot 1   GEMM1(g0)                       16 MFMA
-  //     slot 2   GEMM1(g1)  ||  elementwise(g0)  16 MFMA beside ~100 VALU (unpack, rcp, mul, cvt_pk)
-  //     slot 3   GEMM2(g0)  ||  elementwise(g1)
-  //     slot 4   GEMM2(g1)
-  // Slots are fenced with sched_barrier; inside a slot the MFMA / ds_read / VALU interleave is pinned.
-  auto compute_phased = [&](int t, int buf, const u32x4(&x)[G][NQ]) {
-    if constexpr (G == 2 && !X3 && !C::LOSS && !C::TWO_ACC) {
-      const char* sb = smem + buf * C::STAGE_BYTES;
-      constexpr int PF = 4;
-      f32x16 s[2][2];
-      uint32_t gnh[2][2][8];
-      // one elementwise pair (two columns of one row group): the VALU work that rides beside one MFMA
-      auto ew_pair = [&](auto gc, int pair) {
-        constexpr int g = decltype(gc)::value;
-        const int tt = pair >> 3, d = pair & 7;
-        const uint32_t w = x[g][2 * tt + (d >> 2)][d & 3];
-        float n0, n1, p0, p1;
-#if NMFMU_ABLATE == 1
-        gnh[g][tt][d] = __builtin_bit_cast(uint32_t, s[g][tt][2 * d]) ^ w;  // timing experiment: no elementwise
-#else
-        mu_elem<BETA>(s[g][tt][2 * d], bf16_lo(w), a.beta, n0, p0);
-        mu_elem<BETA>(s[g][tt][2 * d + 1], bf16_hi(w), a.beta, n1, p1);
-        gnh[g][tt][d] = pack_bf16(n0, n1);
-#endif
-      };
-      // GEMM1 of group g (16 MFMA, the two S^T tiles alternate); optionally one elementwise pair of group eg per MFMA
-      auto gemm1 = [&](auto gc, auto egc, auto with_ew) {
-        constexpr int g = decltype(gc)::value;
-        constexpr int NSTEP = 2 * KS;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[g][tt][e] = (BETA == kEuc) ? 0.f : kEps;
-        u32x4 ring[PF];
-        auto off = [&](int step) { return a_row[step & 1] + (((step >> 1) * 32 + hl * 16) ^ a_sw[step & 1]); };
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P1HI + off(p));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-          const u32x4 ah = ring[step % PF];
-          s[g][step & 1] = mfma_bf16(ah, qh[g][step >> 1], s[g][step & 1]);
-          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P1HI + off(step + PF));
-          if constexpr (decltype(with_ew)::value) {
-            if (step * 16 / NSTEP != (step + 1) * 16 / NSTEP || NSTEP <= 16) {
-#pragma unroll
-              for (int pr = step * 16 / NSTEP; pr < (step + 1) * 16 / NSTEP; ++pr) ew_pair(egc, pr);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      auto gemm2 = [&](auto gc, auto egc, auto with_ew) {
-        constexpr int g = decltype(gc)::value;
-        constexpr int NSTEP = RT * 4;
-        u32x4 ring[PF];
-        auto off = [&](int step) {
-          const int rt = step % RT, c = step / RT;
-          return rt * 4096 + b_row + b_off[c >> 1][c & 1];
-        };
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = ld16(sb + C::P2HI + off(p));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-          const int rt = step % RT, c = step / RT, tt = c >> 1, m2 = c & 1;
-          const u32x4 bh = ring[step % PF];
-          const u32x4 nh = {gnh[g][tt][4 * m2], gnh[g][tt][4 * m2 + 1], gnh[g][tt][4 * m2 + 2], gnh[g][tt][4 * m2 + 3]};
-          on[g][rt] = mfma_bf16(nh, bh, on[g][rt]);
-          if (step + PF < NSTEP) ring[step % PF] = ld16(sb + C::P2HI + off(step + PF));
-          if constexpr (decltype(with_ew)::value) {
-#pragma unroll
-            for (int pr = step * 16 / NSTEP; pr < (step + 1) * 16 / NSTEP; ++pr) ew_pair(egc, pr);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      gemm1(I0{}, I0{}, std::false_type{});      // slot 1
-      gemm1(I1{}, I0{}, std::true_type{});       // slot 2: GEMM1(g1) || elementwise(g0)
-      gemm2(I0{}, I1{}, std::true_type{});       // slot 3: GEMM2(g0) || elementwise(g1)
-      gemm2(I1{}, I0{}, std::false_type{});      // slot 4
-    }
-  };
-  constexpr bool kPhased = NMFMU_PHASED && G == 2 && !X3 && !C::LOSS && !C::TWO_ACC;
-
-  // ---------------- main loop over the chunk's tiles: panel double-buffered in LDS (DMA one tile ahead), X two
-  // tiles ahead in VGPRs.  With LDS-DMA the tile ends with a COUNTED vmcnt and a raw s_barrier: the DMA of tile
-  // t+1 is issued before the X loads of tile t+2, so waiting until only the X loads are outstanding proves the DMA
-  // has landed while 2 tiles of X per wave stay in flight across the barrier (one tile in flight caps a CU at
-  // ~3 TB/s chip-wide by Little's law; the X stream is the kernel's only HBM traffic).
-  // ---------------- software-pipelined main loop (beta == 1, bf16 operands, 128-row tile, LDS-DMA staging).
-  // Microbenchmarks on MI355X (tools/ubench) show that (a) a second wave per SIMD adds almost nothing, (b) bit-ops,
-  // moves, v_rcp, v_cvt_pk and ds_read_b128 co-issue with MFMAs nearly for free while fp32 mul/fma cost ~2.5 cycles
-  // and v_pk_mul_f32 ~24, and (c) the serial GEMM1 -> elementwise -> GEMM2 phases of one tile simply ADD.  So the
-  // elementwise stage of tile t is issued BESIDE the (independent) GEMM1 of tile t+1:
-  //     phase A   16 MFMA of GEMM1(t+1) into s_next   ||   per MFMA: unpack, 2 rcp, 2 mul, 1 cvt_pk of tile t
-  //     phase B   16 MFMA of GEMM2(t)
-  // S ping-pongs through a x2-unrolled loop; the GEMM1 operand image of a tile is DMA'd one tile earlier than its
-  // GEMM2 image (P1(t+2) and P2(t+1) are issued at the top of tile t; same two LDS stages as before).
   constexpr bool kSP = C::SP;
   if constexpr (kSP) {
     // ---------------- cross-tile software-pipelined main loop, eight waves (two per SIMD).
@@ -886,159 +634,25 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
       __syncthreads();               // LDS is reused by the epilogue
     }
   }
-  // ---------------- pipelined main loop (LDS-DMA staging): three LDS slots, panel DMA and X loads issued TWO
-  // tiles ahead, and every tile ends with a counted s_waitcnt vmcnt(N) + raw s_barrier, so the next-but-one tile's
-  // traffic stays in flight across the barrier instead of being drained (the drain-per-tile structure is what
-  // cdna_hip_programming.md section 5 measures at ~40 % of the pipelined one).  Both the DMA and the X loads are
-  // issued from inline asm: hipcc must not see them, or it inserts its own vmcnt(0) drains.  The loop is unrolled
-  // by three so that X register sets and LDS slots are static.
-  constexpr bool kPipe3 = C::PIPE3 && STAGE == 1 && NMFMU_ABLATE == 0 && !kSP;
-  if constexpr (kPipe3) {
-    if (t0 < t1) {
-      const int nt = t1 - t0;
-      constexpr int kPerTile = C::NIMG * C::PASSES + G * NQ;   // VMEM instructions issued per prefetched tile
-      static_assert(kPerTile < 64, "vmcnt field");
-      auto load_x_asm = [&](int t, u32x4(&x)[G][NQ]) {
-        const char* p = xbase + (size_t)t * (4 * G * NQ * 1024);
-#pragma unroll
-        for (int i = 0; i < G * NQ; ++i) {
-          const char* pi = p + (i >> 2) * 4096;
-          if ((i & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
-          if ((i & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
-          if ((i & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
-          if ((i & 3) == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(x[i / NQ][i % NQ]) : "v"(pi) : "memory");
-        }
-      };
-      auto prefetch = [&](int i, int slot, u32x4(&x)[G][NQ]) {   // tile i of this chunk -> LDS slot + registers
-        stage_issue(t0 + i, slot);
-        load_x_asm(t0 + i, x);
-      };
-      auto tile_end = [&](bool two_in_flight) {
-        // allow exactly the newest prefetched tile to stay in flight; everything older (the next tile) has landed
-        if (two_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerTile) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);   // nothing (e.g. the next tile's unpack of X) may move above the wait
-      };
-      u32x4 x0[G][NQ], x1[G][NQ], x2[G][NQ];
-      prefetch(0, 0, x0);
-      if (nt > 1) prefetch(1, 1, x1);
-      tile_end(nt > 1);
-      auto body = [&](int i, int slot, u32x4(&xcur)[G][NQ], u32x4(&xfar)[G][NQ]) {
-        const bool far = i + 2 < nt;
-        if (far) prefetch(i + 2, slot == 0 ? 2 : slot - 1, xfar);   // (slot + 2) % 3
-        // xcur was filled by asm loads two tiles ago and waited for at the end of the previous tile; make it
-        // opaque here so that no use can be scheduled above this point
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(xcur[g][q]));
-        compute(t0 + i, slot, xcur, -1);
-        tile_end(far);
-      };
-      for (int i = 0; i < nt; i += 3) {
-        body(i, 0, x0, x2);
-        if (i + 1 < nt) body(i + 1, 1, x1, x0);
-        if (i + 2 < nt) body(i + 2, 2, x2, x1);
-      }
-    }
-  }
-  if constexpr (!kPipe3 && !kSP)
+  // ---------------- default main loop: LDS double buffer for the panel, X in ONE register buffer that compute()
+  // refills with the next tile right after its last use; one drain + barrier per tile.
+  if constexpr (!kSP)
   if (t0 < t1) {
-    u32x4 xc[G][NQ], xn[G][NQ], xf[G][NQ];
-    constexpr bool kDeep = (STAGE == 1) && NMFMU_XDEPTH == 2 && NMFMU_ABLATE == 0;
-    constexpr int kXLoads = G * NQ;  // global_load instructions per X tile and lane
-    // Visit order: workgroup-dependent rotation of the chunk's tiles.  Every workgroup's X region starts on a
-    // 1 MiB-aligned boundary and all workgroups advance in lockstep, so without the rotation all 512 concurrent
-    // streams present identical low address bits to the HBM channel hash at every instant.
+    u32x4 xc[G][NQ];
     const int nt = t1 - t0;
-    const int stag = NMFMU_STAGGER ? (int)((blockIdx.x * 2654435761u) >> 8) % nt : 0;
-    auto tile_at = [&](int i) {
-      int r = i + stag;
-      if (r >= nt) r -= nt;
-      return t0 + r;
-    };
-    stage_issue(tile_at(0), 0);
-    load_x(tile_at(0), xc);
-    if (kDeep && nt > 1) load_x(tile_at(1), xn);
+    stage_issue(t0, 0);
+    load_x(t0, xc);
     stage_commit(0);
-#if NMFMU_DMA_ASM
-    if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-#endif
+    if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): the asm DMA landed
     __syncthreads();
     for (int i = 0; i < nt; ++i) {
-      const int t = tile_at(i);
-      const int buf = i & 1;
+      const int t = t0 + i, buf = i & 1;
       const bool more = i + 1 < nt;
-#if NMFMU_ABLATE == 2
-      if (more) load_x(tile_at(i + 1), xn);
-      compute(t, 0, xc, -1);
-#elif NMFMU_ABLATE == 3
-      if (more) stage_issue(tile_at(i + 1), buf ^ 1);
-      compute(t, buf, xc, -1);
+      if (more) stage_issue(t + 1, buf ^ 1);
+      compute(t, buf, xc, more ? t + 1 : -1);
       if (more) stage_commit(buf ^ 1);
+      if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
       __syncthreads();
-      continue;
-#elif NMFMU_ABLATE == 9   // keep the X traffic, drop the dependency: loads stay alive but compute uses the first tile's registers
-      if (more) {
-        stage_issue(tile_at(i + 1), buf ^ 1);
-        load_x(tile_at(i + 1), xn);
-      }
-      compute(t, buf, xc, -1);
-      if (more) stage_commit(buf ^ 1);
-      __syncthreads();
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(xn[g][q]));
-      continue;
-#else
-      if constexpr (kDeep) {
-        const bool far = i + 2 < nt;
-        if (more) stage_issue(tile_at(i + 1), buf ^ 1);
-        if (far) load_x(tile_at(i + 2), xf);
-        if constexpr (kPhased) compute_phased(t, buf, xc);
-        else compute(t, buf, xc, -1);
-        // vmcnt(kXLoads) when a far tile was issued (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-        if (far) __builtin_amdgcn_s_waitcnt((kXLoads & 15) | (7 << 4) | (15 << 8) | ((kXLoads >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            xc[g][q] = xn[g][q];
-            xn[g][q] = xf[g][q];
-          }
-        continue;
-      }
-      if constexpr (NMFMU_XSINGLE && !kPhased) {
-        if (more) stage_issue(tile_at(i + 1), buf ^ 1);
-        if constexpr (kG2C) compute_g2c(t, buf, xc, more ? tile_at(i + 1) : -1);
-        else compute(t, buf, xc, more ? tile_at(i + 1) : -1);   // loads X of the next tile into xc after its last use
-        if (more) stage_commit(buf ^ 1);
-#if NMFMU_DMA_ASM
-        if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-#endif
-        __syncthreads();
-        continue;
-      }
-      if (more) {
-        stage_issue(tile_at(i + 1), buf ^ 1);
-        load_x(tile_at(i + 1), xn);
-      }
-      if constexpr (kPhased) compute_phased(t, buf, xc);
-      else compute(t, buf, xc, -1);
-      if (more) stage_commit(buf ^ 1);
-#if NMFMU_DMA_ASM
-      if constexpr (STAGE == 1) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0): the asm DMA landed
-#endif
-      __syncthreads();
-#endif
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) xc[g][q] = xn[g][q];
     }
   }
 
