@@ -51,9 +51,11 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph instead of launching '
                     'every kernel eagerly (measured no faster on MI355X; fit() does this with TORCHNMF_AMD_GRAPH=1)')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
-    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu'],
+    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
     ap.add_argument('--taps', type=int, default=400)
+    ap.add_argument('--kernel2d', type=int, nargs=2, default=[8, 16],
+                    help='nmf2d: kernel size; the target is (1, 64, 256, 512), rank 8 (SURVEY.md 8 row f2: no reference headline)')
     ap.add_argument('--materialise', action='store_true',
                     help="betamu: the closure returns m() (reconstruction written out, as in the reference's tests) "
                          "instead of the layer itself")
@@ -116,9 +118,19 @@ def main_nmfd(a):
     from torchnmf_amd.nmfd_engine import ConvMU
     Cc, L, R, T, beta = 1025, 8192, 8, a.taps, a.beta
     g = torch.Generator(device=dev).manual_seed(1000)
-    V = torch.rand(1, Cc, L, device=dev, generator=g).bfloat16().float()
-    W = torch.randn(Cc, R, T, device=dev, generator=g).abs_()
-    H = torch.randn(1, R, L - T + 1, device=dev, generator=g).abs_()
+    if a.workload == 'nmf2d':       # NMF2D, the next row after NMFD (same engine, two shift axes)
+        Cc, R = 64, 8
+        ls, ks = (256, 512), tuple(a.kernel2d)
+        V = torch.rand(1, Cc, *ls, device=dev, generator=g).bfloat16().float()
+        W = torch.randn(Cc, R, *ks, device=dev, generator=g).abs_()
+        H = torch.randn(1, R, *[l - k + 1 for l, k in zip(ls, ks)], device=dev, generator=g).abs_()
+        L, T = ls[0] * ls[1], ks[0] * ks[1]
+        title = f'NMF2D 1x{Cc}x{ls[0]}x{ls[1]} rank={R} kernel={ks[0]}x{ks[1]}'
+    else:
+        V = torch.rand(1, Cc, L, device=dev, generator=g).bfloat16().float()
+        W = torch.randn(Cc, R, T, device=dev, generator=g).abs_()
+        H = torch.randn(1, R, L - T + 1, device=dev, generator=g).abs_()
+        title = f'NMFD 1x{Cc}x{L} rank={R} T={T}' + (' (BASELINE configs[3])' if T == 400 else '')
     Vc, Wc, Hc = V.cpu(), W.cpu(), H.cpu()
     eng = ConvMU(V, W, H, beta, precision=a.precision)
 
@@ -161,14 +173,14 @@ def main_nmfd(a):
         dt = (time.perf_counter() - t0) / a.cpu_iters
         cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
-               f'NMFD workload, fp32, F.conv1d + two backward passes (oracle/aten_port.py)'}
+               f'workload, fp32, F.conv{2 if a.workload == "nmf2d" else 1}d + two backward passes (oracle/aten_port.py)'}
     print(json.dumps({
-        'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), NMFD 1x{Cc}x{L} rank-{R} T={T} beta={beta:g}',
+        'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), {title} beta={beta:g}',
         'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
         'data': 'synthetic',
-        'config': {'workload': f'NMFD 1x{Cc}x{L} rank={R} T={T} beta={beta:g} (BASELINE configs[3])',
+        'config': {'workload': f'{title} beta={beta:g}',
                    'precision': a.precision, 'parallelism': 'single GPU (replicas only)',
                    'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
@@ -181,8 +193,8 @@ def main_nmfd(a):
 
 def main():
     a = parse()
-    if a.workload == 'nmfd':
-        assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'NMFD is not sharded (replicas only)'
+    if a.workload in ('nmfd', 'nmf2d'):
+        assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'NMFD / NMF2D are not sharded (replicas only)'
         torch.cuda.set_device(0)
         return main_nmfd(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -61,16 +61,21 @@ def mu_iterations(V, W0, H0, beta=1, n_iter=1, alpha=0.0, l1_ratio=0.0):
 
 
 def mu_iterations_nmfd(V, W0, H0, beta=1, n_iter=1):
-    """Same loop for NMFD: reconstruction = F.conv1d(H, W.flip(2), padding=T-1) (nmf.py:776-779)."""
+    """Same loop for NMFD / NMF2D / NMF3D: reconstruction = F.convNd(H, W.flip(shift axes), padding=T-1)
+    (nmf.py:776-779, 857-860, 937-940)."""
     W = torch.nn.Parameter(W0.clone().float())
     H = torch.nn.Parameter(H0.clone().float())
     gamma = gamma_of(beta)
-    pad = W.shape[2] - 1
+    nd = W.dim() - 2
+    conv = (F.conv1d, F.conv2d, F.conv3d)[nd - 1]
+    axes = tuple(range(2, 2 + nd))
+    pad = tuple(k - 1 for k in W.shape[2:])
+    red = (0,) + axes
     for _ in range(n_iter):
-        pos = H.detach().sum((0, 2), keepdim=True) if beta == 1 else None
-        _update(V, F.conv1d(H.detach(), W.flip(2), padding=pad), W, beta, gamma, 0.0, 0.0, pos)
-        pos = W.detach().sum((0, 2), keepdim=True).squeeze(0) if beta == 1 else None
-        _update(V, F.conv1d(H, W.detach().flip(2), padding=pad), H, beta, gamma, 0.0, 0.0, pos)
+        pos = H.detach().sum(red, keepdim=True) if beta == 1 else None
+        _update(V, conv(H.detach(), W.flip(axes), padding=pad), W, beta, gamma, 0.0, 0.0, pos)
+        pos = W.detach().sum(red, keepdim=True).squeeze(0) if beta == 1 else None
+        _update(V, conv(H, W.detach().flip(axes), padding=pad), H, beta, gamma, 0.0, 0.0, pos)
     return W.data, H.data
 
 

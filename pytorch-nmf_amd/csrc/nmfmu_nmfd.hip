@@ -338,16 +338,9 @@ struct ConvGeom {
   int lh_tot, t_tot, l_tot;
 };
 
-// H index of (l flat, t flat), or -1 when l - t leaves H on some axis
-__device__ __forceinline__ int conv_src(const ConvGeom& g, int lf, int tf) {
-  const int l2 = lf % g.l[2], l01 = lf / g.l[2], l1 = l01 % g.l[1], l0 = l01 / g.l[1];
-  const int t2 = tf % g.t[2], t01 = tf / g.t[2], t1 = t01 % g.t[1], t0 = t01 / g.t[1];
-  const int j0 = l0 - t0, j1 = l1 - t1, j2 = l2 - t2;
-  if (j0 < 0 || j0 >= g.lh[0] || j1 < 0 || j1 >= g.lh[1] || j2 < 0 || j2 >= g.lh[2]) return -1;
-  return (j0 * g.lh[1] + j1) * g.lh[2] + j2;
-}
-
-// Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], bf16 (hi[, lo]) zero padded: one thread per 8 consecutive columns
+// Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], bf16 (hi[, lo]) zero padded: one thread per 8 consecutive columns.
+// The row index is decomposed once per thread and the column index once, then advanced with carries (the naive
+// per-element div/mod chain made this kernel ALU-bound at ~2.5 ms for a 256 x 512 frame).
 __global__ void __launch_bounds__(256) convnd_unfold_kernel(const float* __restrict__ H, int B, int R, ConvGeom g,
                                                             uint16_t* hu_hi, uint16_t* hu_lo, uint16_t* hut_hi,
                                                             uint16_t* hut_lo, int bl_pad, int rp_pad) {
@@ -357,17 +350,25 @@ __global__ void __launch_bounds__(256) convnd_unfold_kernel(const float* __restr
     const int64_t k = tr ? i - n_hu : i;
     const int cols8 = (tr ? bl_pad : rp_pad) / 8;
     const int row = (int)(k / cols8), c0 = (int)(k % cols8) * 8;
+    // (b, l0, l1, l2) of the (b,l) index and (r, t0, t1, t2) of the (r,t) index: one is the row, the other starts at c0
+    const int bl0 = tr ? c0 : row, rt0 = tr ? row : c0;
+    int b = bl0 / g.l_tot, lf = bl0 - b * g.l_tot;
+    int l2 = lf % g.l[2], l01 = lf / g.l[2], l1 = l01 % g.l[1], l0 = l01 / g.l[1];
+    int r = rt0 / g.t_tot, tf = rt0 - r * g.t_tot;
+    int t2 = tf % g.t[2], t01 = tf / g.t[2], t1 = t01 % g.t[1], t0 = t01 / g.t[1];
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int bl = tr ? c0 + e : row, rt = tr ? row : c0 + e;   // (b,l) flat and (r,t) flat of this element
-      const int b = bl / g.l_tot, lf = bl - b * g.l_tot, r = rt / g.t_tot, tf = rt - r * g.t_tot;
       float x = 0.f;
-      if (b < B && r < R) {
-        const int j = conv_src(g, lf, tf);
-        if (j >= 0) x = H[((size_t)b * R + r) * g.lh_tot + j];
-      }
+      const int j0 = l0 - t0, j1 = l1 - t1, j2 = l2 - t2;
+      if (b < B && r < R && j0 >= 0 && j0 < g.lh[0] && j1 >= 0 && j1 < g.lh[1] && j2 >= 0 && j2 < g.lh[2])
+        x = H[((size_t)b * R + r) * g.lh_tot + (j0 * g.lh[1] + j1) * g.lh[2] + j2];
       v[e] = x;
+      if (tr) {   // next (b,l)
+        if (++l2 == g.l[2]) { l2 = 0; if (++l1 == g.l[1]) { l1 = 0; if (++l0 == g.l[0]) { l0 = 0; ++b; } } }
+      } else {    // next (r,t)
+        if (++t2 == g.t[2]) { t2 = 0; if (++t1 == g.t[1]) { t1 = 0; if (++t0 == g.t[0]) { t0 = 0; ++r; } } }
+      }
     }
     u32x4 hi, lo;
 #pragma unroll
