@@ -51,11 +51,12 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph instead of launching '
                     'every kernel eagerly (measured no faster on MI355X; fit() does this with TORCHNMF_AMD_GRAPH=1)')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
-    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d'],
+    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d', 'sparse'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
     ap.add_argument('--taps', type=int, default=400)
     ap.add_argument('--kernel2d', type=int, nargs=2, default=[8, 16],
                     help='nmf2d: kernel size; the target is (1, 64, 256, 512), rank 8 (SURVEY.md 8 row f2: no reference headline)')
+    ap.add_argument('--density', type=float, default=0.01, help='sparse: fraction of stored entries of the target')
     ap.add_argument('--materialise', action='store_true',
                     help="betamu: the closure returns m() (reconstruction written out, as in the reference's tests) "
                          "instead of the layer itself")
@@ -78,12 +79,14 @@ def usable_cores():
     return n
 
 
-def pick_threads(run_probe):
+def pick_threads(run_probe, max_cands=None):
     """The ATen CPU kernels are far from monotone in thread count on many-core hosts (256 threads were measured ~4x
     slower than 32 on the MI355X box).  Time a probe with a few thread counts and keep the fastest, so the CPU baseline
     is the reference at its best on this box, not at its default."""
     n = usable_cores()
     cands = sorted({max(1, c) for c in (n, n // 2, n // 4, n // 8, 32, 16) if c <= n} | {min(n, 8)}, reverse=True)
+    if max_cands:
+        cands = cands[:max_cands]            # slow probes (seconds each): only the largest counts
     best, tried = None, {}
     for c in cands:
         torch.set_num_threads(c)
@@ -191,8 +194,90 @@ def main_nmfd(a):
         'cpu_baseline': cpu}))
 
 
+def main_sparse(a):
+    """NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638); no reference headline.
+    Default: 32768 x 32768, 1 % stored entries, rank 64, beta = 1."""
+    dev = torch.device('cuda', 0)
+    from torchnmf_amd.sparse_engine import SparseMU
+    N = a.rows if a.rows != 4096 else 32768
+    Cc = a.cols if a.cols != 65536 else 32768
+    R = a.rank if a.rank != 128 else 64      # (the default of --rank belongs to the dense headline)
+    beta = a.beta
+    g = torch.Generator(device=dev).manual_seed(1000)
+    nnz = int(N * Cc * a.density)
+    flat = torch.randint(0, N * Cc, (nnz,), device=dev, generator=g).unique()
+    idx = torch.stack([flat // Cc, flat % Cc])
+    vals = torch.rand(flat.numel(), device=dev, generator=g) + 1e-3
+    V = torch.sparse_coo_tensor(idx, vals, (N, Cc)).coalesce()
+    nnz = V._nnz()
+    W = torch.randn(Cc, R, device=dev, generator=g).abs_()
+    H = torch.randn(N, R, device=dev, generator=g).abs_()
+    Vc, Wc, Hc = V.cpu(), W.cpu(), H.cpu()
+    eng = SparseMU(V, W, H, beta)
+
+    def step():
+        eng.w_step()
+        eng.h_step()
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    flops = 8.0 * nnz * R if beta == 1 else 4.0 * nnz * R      # per iteration: (dot + axpy) x 2 half-steps (beta 2: axpy only)
+    # dominant kernel (sp_partial_kernel) timed live: one half-step's numerator pass
+    st, csr = eng.step_h, eng.csr_h
+    from torchnmf_amd import _capi
+
+    def partial():
+        _capi.check(eng.lib.nmfmu_sp_partial(csr[0].data_ptr(), csr[1].data_ptr(), csr[2].data_ptr(), st.owner.rows,
+                                             st.owner.f.data_ptr(), st.panel.f.data_ptr(), R, beta, st.slab_num.data_ptr(),
+                                             eng.r_pad, torch.cuda.current_stream().cuda_stream), 'nmfmu_sp_partial')
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    partial()
+    ev[0].record()
+    for _ in range(a.steps):
+        partial()
+    ev[1].record()
+    torch.cuda.synchronize()
+    k_ms = ev[0].elapsed_time(ev[1]) / a.steps
+    bytes_per_launch = nnz * (R * 4 + 8.0) + N * R * 8.0     # one panel row + (column index, value) per entry; owner in/out
+    cpu = None
+    if a.cpu_iters > 0:
+        from oracle import aten_port
+        torch.set_flush_denormal(True)
+        cores, tried = pick_threads(lambda: aten_port.sp_mu_iterations(Vc, Wc, Hc, beta, 1), max_cands=2)
+        t0 = time.perf_counter()
+        aten_port.sp_mu_iterations(Vc, Wc, Hc, beta, a.cpu_iters)
+        dt = (time.perf_counter() - t0) / a.cpu_iters
+        cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+               'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4),
+               'sample': f'{a.cpu_iters} timed MU iterations (+1 probe per thread count) of the same sparse workload, fp32, '
+                         f"the reference's scalar-objective op sequence (oracle/aten_port.py: sp_mu_iterations)"}
+    print(json.dumps({
+        'metric': f'MU GFLOP/s (algorithmic 8*nnz*R per iteration), sparse NMF {N}x{Cc}, {nnz} stored entries, rank-{R} '
+                  f'beta={beta:g}; MU iterations/s alongside',
+        'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'sparse NMF {N}x{Cc} density={nnz / (N * Cc):.4f} rank={R} beta={beta:g} (SURVEY 8 row f3)',
+                   'nnz': nnz, 'parallelism': 'single GPU'},
+        'roofline': {'bound': 'hbm', 'achieved': round(bytes_per_launch / (k_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': round(bytes_per_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     'traffic': None, 'kernel': 'nmfmu::sp_partial_kernel', 'avg_launch_ms': round(k_ms, 5),
+                     'note': 'algorithmic bytes = one panel row (4R B) + index and value (8 B) per stored entry; panel rows '
+                             'are re-read from L2 / MALL when columns repeat, so HBM traffic is below this figure'},
+        'cpu_baseline': cpu}))
+
+
 def main():
     a = parse()
+    if a.workload == 'sparse':
+        assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'the sparse path is not sharded'
+        torch.cuda.set_device(0)
+        return main_sparse(a)
     if a.workload in ('nmfd', 'nmf2d'):
         assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'NMFD / NMF2D are not sharded (replicas only)'
         torch.cuda.set_device(0)

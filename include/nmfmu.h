@@ -194,7 +194,7 @@ typedef struct nmfmu_gemm_desc {
   int32_t m_valid, n_valid; /* LOSS: logical extent */
   /* Implicit conv-unfold operands (nmfmu_conv_tables): instead of materialising the Toeplitz matrix
    * Hu[(b,l)][(r,t)] = H[b][r][l-t] (T times larger than H), an operand may be fetched chunk by chunk from a
-   * window table that is only 8x H.  ops selects which operand is implicit; its *_hi/*_lo then point to the table. */
+   * window table that is only 8x H.  ops selects which operand is implicit; its hi / lo pointers then address the table. */
   int32_t ops;              /* NMFMU_OPS_* */
   int32_t t_batch, t_rank, t_taps, t_lh; /* B, R, T, Lh of H (implicit operands only) */
 } nmfmu_gemm_desc;
@@ -255,6 +255,24 @@ int nmfmu_convnd_unfold(const float* h, int batch, int rank, int ndim, const int
 int nmfmu_convnd_fold_apply_h(float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
                               const float* y_num, const float* y_den, const float* kl_den, int bl_pad, float l1,
                               float l2, float gamma, void* stream);
+
+/* ---- sparse-COO targets (nmf.py:351-398, 602-638), beta in {1, 2} ---------------------------------------------
+ * V is handed over as CSR over the owner axis of the half-step: rowptr[owner_rows + 1], colidx / vals[nnz] (int32
+ * indices; rows of V for the H half-step, rows of V^T for the W half-step).  Factors are the plain fp32 masters.
+ *   nmfmu_sp_partial : num[row][:] = sum over the row's entries of g(v, <owner[row], panel[col]>) * panel[col][:]
+ *                      (g = v / (s + eps) for beta 1, v for beta 2), num is [owner_rows][r_pad], later passed to
+ *                      nmfmu_mu_apply as a single slab together with kl_den (beta 1) or den (beta 2)
+ *   nmfmu_gram       : gram = f^T f (rank x rank);  nmfmu_rowmat : den[row][:] = owner[row] @ gram  (beta 2)
+ *   nmfmu_sp_loss_neg: *out = sum_nnz v log(s + eps) (beta 1) or v s (beta 2), the data-dependent term of the loss
+ *                      the reference tracks on sparse targets; part: (owner_rows + 3) / 4 doubles of scratch
+ * Other beta: NMFMU_ERR_UNSUPPORTED (their positive term is a dense N x C pass in the reference too). */
+int nmfmu_sp_partial(const int32_t* rowptr, const int32_t* colidx, const float* vals, int owner_rows, const float* owner,
+                     const float* panel, int rank, float beta, float* num, int r_pad, void* stream);
+int nmfmu_sp_loss_neg(const int32_t* rowptr, const int32_t* colidx, const float* vals, int owner_rows, const float* owner,
+                      const float* panel, int rank, float beta, double* part, double* out, void* stream);
+size_t nmfmu_gram_part_bytes(int rank);   /* scratch of nmfmu_gram */
+int nmfmu_gram(const float* f, int rows, int rank, float* part, float* gram, void* stream);
+int nmfmu_rowmat(const float* owner, int rows, int rank, const float* gram, float* den, int r_pad, void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */

@@ -114,3 +114,39 @@ def betamu_iterations(V, W0, H0, beta=1, n_iter=1, l1=0.0, l2=0.0, ortho=0.0):
                     mult.pow_(gamma)
                 p.mul_(mult)
     return W.data, H.data
+
+
+def sp_mu_iterations(V, W0, H0, beta=1, n_iter=1):
+    """The reference's sparse-target update with its own op sequence (nmf.py:95-119, 366-391, 602-638): the scalars
+    ``pos`` / ``neg`` built from the stored entries, two backward passes, relu_/add_, div_, mul_.  beta in {1, 2}."""
+    V = V.coalesce()
+    idx, vals = V.indices(), V.values()
+    ii, jj = idx[0], idx[1]
+    W = torch.nn.Parameter(W0.clone().float())
+    H = torch.nn.Parameter(H0.clone().float())
+    gamma = gamma_of(beta)
+
+    def terms(Hx, Wx):
+        if beta == 2:
+            pos = torch.linalg.multi_dot([Hx, Wx.t(), Wx]).view(-1) @ Hx.view(-1) * 0.5
+            neg = (V.t() @ Hx).view(-1) @ Wx.view(-1)
+            return pos, neg
+        s = (Wx[jj] * Hx[ii]).sum(1)
+        return Wx.sum(0) @ Hx.sum(0), vals @ s.add(EPS).log()
+
+    def update(p, pos_out, neg_out, pos):
+        p.grad = None
+        neg_out.backward(retain_graph=pos is None)
+        neg = p.grad.relu_().add_(EPS)
+        if pos is None:
+            p.grad = None
+            pos_out.backward()
+            pos = p.grad.relu_().add_(EPS)
+        p.data.mul_(neg.div_(pos) if gamma == 1 else neg.div_(pos).pow_(gamma))
+
+    for _ in range(n_iter):
+        pos, neg = terms(H.detach(), W)
+        update(W, pos, neg, H.detach().sum(0, keepdim=True) if beta == 1 else None)
+        pos, neg = terms(H, W.detach())
+        update(H, pos, neg, W.detach().sum(0) if beta == 1 else None)
+    return W.data, H.data

@@ -341,6 +341,76 @@ def fit(V: torch.Tensor, W0: torch.Tensor, H0: torch.Tensor, beta: float = 1, to
 
 
 # --------------------------------------------------------------------------
+# sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}.  The reference differentiates the scalars
+#   beta = 1: pos = W.sum(0) . H.sum(0)            neg = sum_nnz v log(WH + eps)          (nmf.py:624-626)
+#   beta = 2: pos = 1/2 <H W^T W, H>               neg = <V^T H, W>                        (nmf.py:616-619)
+# whose gradients are the dense numerator / denominator terms restricted to the stored entries (zeros of V add
+# nothing to a numerator), so the factor updates equal the dense ones (tests/test_nmf_sparse.py:8-37); only the
+# tracked loss  V_norm + pos - neg  (nmf.py:172-181, 357, 397) is a different expression from metrics.beta_div.
+# --------------------------------------------------------------------------
+def sp_terms(idx, vals, W, H, beta):
+    """(pos, neg) of nmf.py:605-638 for stored entries (idx (2, nnz), vals)."""
+    ii, jj = idx[0], idx[1]
+    if beta == 2:
+        pos = ((H @ W.t() @ W).reshape(-1) @ H.reshape(-1)) * 0.5
+        VtH = torch.zeros(W.shape[0], H.shape[1]).index_add_(0, jj, vals[:, None] * H[ii])
+        return pos, VtH.reshape(-1) @ W.reshape(-1)
+    assert beta == 1, 'the sparse oracle covers beta in {1, 2}'
+    s = (W[jj] * H[ii]).sum(1)
+    return W.sum(0) @ H.sum(0), vals @ (s + EPS).log()
+
+
+def sp_v_norm(vals, beta):
+    """nmf.py:172-181."""
+    if beta == 2:
+        return vals @ vals * 0.5
+    return vals @ vals.log() - vals.sum()
+
+
+def sp_fit_loss(idx, vals, W, H, beta) -> float:
+    pos, neg = sp_terms(idx, vals, W, H, beta)
+    return float(((sp_v_norm(vals, beta) + pos - neg) * 2).sqrt())
+
+
+def sp_w_step(idx, vals, shape, W, H, beta, gamma, l1=0.0, l2=0.0):
+    ii, jj = idx[0], idx[1]
+    if beta == 2:     # grad of neg = V^T H, grad of pos = W H^T H
+        neg = torch.zeros_like(W).index_add_(0, jj, vals[:, None] * H[ii])
+        return _apply(W, neg, W @ (H.t() @ H), False, gamma, l1, l2)
+    g = vals / ((W[jj] * H[ii]).sum(1) + EPS)
+    neg = torch.zeros_like(W).index_add_(0, jj, g[:, None] * H[ii])
+    return _apply(W, neg, H.sum(0, keepdim=True), True, gamma, l1, l2)
+
+
+def sp_h_step(idx, vals, shape, W, H, beta, gamma, l1=0.0, l2=0.0):
+    ii, jj = idx[0], idx[1]
+    if beta == 2:
+        neg = torch.zeros_like(H).index_add_(0, ii, vals[:, None] * W[jj])
+        return _apply(H, neg, H @ (W.t() @ W), False, gamma, l1, l2)
+    g = vals / ((W[jj] * H[ii]).sum(1) + EPS)
+    neg = torch.zeros_like(H).index_add_(0, ii, g[:, None] * W[jj])
+    return _apply(H, neg, W.sum(0), True, gamma, l1, l2)
+
+
+def sp_fit(idx, vals, shape, W0, H0, beta=1, tol=1e-4, max_iter=200, alpha=0, l1_ratio=0):
+    """The fit driver of nmf.py:297-409 on a sparse target.  Returns (W, H, n_iter, losses) like ``fit``."""
+    W, H = W0.clone().float(), H0.clone().float()
+    gamma, l1, l2 = gamma_of(beta), alpha * l1_ratio, alpha * (1 - l1_ratio)
+    loss_init = sp_fit_loss(idx, vals, W, H, beta)
+    losses, prev, n_iter = [loss_init], loss_init, -1
+    for n_iter in range(max_iter):
+        W = sp_w_step(idx, vals, shape, W, H, beta, gamma, l1, l2)
+        H = sp_h_step(idx, vals, shape, W, H, beta, gamma, l1, l2)
+        if n_iter % 10 == 9:
+            loss = sp_fit_loss(idx, vals, W, H, beta)
+            losses.append(loss)
+            if (prev - loss) / loss_init < tol:
+                break
+            prev = loss
+    return W, H, n_iter + 1, losses
+
+
+# --------------------------------------------------------------------------
 # column-sharded NMF (SURVEY.md section 8e): simulated on one process.
 # Shard g owns V[:, Cg] and W[Cg]; H is replicated.  W half-step is local, the
 # H half-step sums per-shard partial numerators/denominators (the all-reduce),

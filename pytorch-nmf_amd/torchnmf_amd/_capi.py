@@ -96,6 +96,13 @@ SIGNATURES = {
     'nmfmu_conv_apply_pack_w': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_sp_partial': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                   C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_sp_loss_neg': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_gram_part_bytes': (C.c_size_t, [C.c_int]),
+    'nmfmu_gram': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_rowmat': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

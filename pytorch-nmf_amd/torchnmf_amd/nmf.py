@@ -117,8 +117,9 @@ class BaseComponent(nn.Module):
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
         """
-        if V.is_sparse:
-            raise NotImplementedError('sparse targets (nmf.py:95-119, 602-638) are outside this engine\'s scope')
+        sparse = V.is_sparse
+        if sparse and not isinstance(self, NMF):
+            raise NotImplementedError('sparse targets are supported by NMF only (as in the reference)')
         W, H = self.W, self.H
         assert W is not None and H is not None
         _require_device(V, 'fit')
@@ -132,7 +133,13 @@ class BaseComponent(nn.Module):
         V = V.detach()
         if V.dtype != torch.float32:
             V = V.float()
-        eng = self._make_engine(V, beta, l1, l2, precision, process_group)
+        if sparse:
+            if process_group is not None:
+                raise NotImplementedError('sparse targets are not sharded')
+            from .sparse_engine import SparseMU
+            eng = SparseMU(V, W.data, H.data, beta, l1, l2, update_W=W.requires_grad, update_H=H.requires_grad)
+        else:
+            eng = self._make_engine(V, beta, l1, l2, precision, process_group)
 
         has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
         assert not has_bad, "Target should be non-negative."

@@ -689,3 +689,51 @@ def test_graph_replay_is_bit_identical_to_eager_launches(dev, kind, monkeypatch)
         out[mode] = (n, m.W.data.cpu().clone(), m.H.data.cpu().clone())
     assert out['1'][0] == out['0'][0] == 25
     assert torch.equal(out['1'][1], out['0'][1]) and torch.equal(out['1'][2], out['0'][2])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# sparse-COO target: nmf.py:351-398, 602-638
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('beta', [1, 2])
+@pytest.mark.parametrize('tag,args', [('run', (NO_STOP, 25, 0.0, 0.0)), ('reg', (NO_STOP, 10, 0.1, 0.5)),
+                                      ('stop', (1e-3, 200, 0.0, 0.0))])
+def test_sparse_fit_g9_golden(dev, beta, tag, args):
+    from torchnmf_amd.nmf import NMF
+    g = load_golden('g9_sparse')
+    V = torch.sparse_coo_tensor(t(g['indices']), t(g['values']), tuple(g['shape'])).to(dev)
+    m = NMF(W=t(g['W0']), H=t(g['H0'])).to(dev)
+    tol, it, alpha, l1r = args
+    n = m.fit(V, beta, tol, it, alpha=alpha, l1_ratio=l1r)
+    assert n == int(g[f'b{beta}_{tag}_n'])
+    assert rel_err(m.W.data.cpu(), g[f'b{beta}_{tag}_W']) < TOL and rel_err(m.H.data.cpu(), g[f'b{beta}_{tag}_H']) < TOL
+
+
+@pytest.mark.parametrize('beta', [1, 2])
+@pytest.mark.parametrize('rank', [16, 100, 200])
+def test_fit_sparse_equals_dense(dev, beta, rank):
+    """The reference's own sparse test (tests/test_nmf_sparse.py:8-37) on the device: same factors from the sparse
+    and the dense representation of one matrix (dense path in its fp32-grade mode where available)."""
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(rank)
+    Vd = torch.rand(500, 700, generator=g)
+    Vd = torch.where(Vd > 0.93, Vd, torch.zeros(()))
+    W0, H0 = torch.randn(700, rank, generator=g).abs(), torch.randn(500, rank, generator=g).abs()
+    ms, md = NMF(W=W0, H=H0).to(dev), NMF(W=W0, H=H0).to(dev)
+    ms.fit(Vd.to_sparse().to(dev), beta, 0, 5, alpha=0.1, l1_ratio=0.5)
+    md.fit(Vd.to(dev), beta, 0, 5, alpha=0.1, l1_ratio=0.5, precision='bf16x3' if rank <= 128 else 'bf16')
+    tol = TOL if rank <= 128 else 2e-2
+    assert rel_err(ms.W.data.cpu(), md.W.data.cpu()) < tol and rel_err(ms.H.data.cpu(), md.H.data.cpu()) < tol
+
+
+def test_sparse_fit_errors(dev):
+    from torchnmf_amd.nmf import NMF, NMFD
+    V = torch.rand(30, 20)
+    Vs = torch.where(V > 0.5, V, torch.zeros(())).to_sparse().to(dev)
+    m = NMF((30, 20), 4).to(dev)
+    with pytest.raises(NotImplementedError):
+        m.fit(Vs, beta=0.5)
+    with pytest.raises(AssertionError):
+        m.fit((-Vs).coalesce())
+    with pytest.raises(NotImplementedError):
+        NMFD((1, 20, 30), 3, 2).to(dev).fit(torch.rand(1, 20, 30).to_sparse().to(dev))
+    assert m.fit(Vs, beta=1, max_iter=12) <= 12 and bool(torch.all(m.W >= 0))

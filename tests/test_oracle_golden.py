@@ -214,3 +214,23 @@ def test_g8_convnd_oracle(name, beta):
     if beta == 1:
         W, H, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 10, 0.1, 0.5, kind='convnd')
         assert rel_err(W, g[f'{name}_reg_W10']) < 1e-5 and rel_err(H, g[f'{name}_reg_H10']) < 1e-5
+
+
+# ---- sparse-COO target ---------------------------------------------------------------
+@pytest.mark.parametrize('beta', [1, 2])
+@pytest.mark.parametrize('tag,args', [('run', (NO_STOP, 25, 0.0, 0.0)), ('reg', (NO_STOP, 10, 0.1, 0.5)),
+                                      ('stop', (1e-3, 200, 0.0, 0.0))])
+def test_g9_sparse_oracle(beta, tag, args):
+    g = load_golden('g9_sparse')
+    idx, vals = torch.from_numpy(g['indices']), torch.from_numpy(g['values'])
+    W0, H0 = torch.from_numpy(g['W0']), torch.from_numpy(g['H0'])
+    assert O.sp_fit_loss(idx, vals, W0, H0, beta) == pytest.approx(float(g[f'b{beta}_loss_init']), rel=1e-5)
+    W, H, n, losses = O.sp_fit(idx, vals, tuple(g['shape']), W0, H0, beta, *args)
+    assert n == int(g[f'b{beta}_{tag}_n'])
+    assert rel_err(W, g[f'b{beta}_{tag}_W']) < 5e-6 and rel_err(H, g[f'b{beta}_{tag}_H']) < 5e-6
+    assert np.allclose(losses[1:], g[f'b{beta}_{tag}_losses'], rtol=1e-5)
+    # the property the reference tests (tests/test_nmf_sparse.py:8-37): the sparse updates equal the dense ones
+    V = torch.sparse_coo_tensor(idx, vals, tuple(g['shape'])).to_dense()
+    Wd, Hd, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 5)
+    Ws, Hs, _, _ = O.sp_fit(idx, vals, tuple(g['shape']), W0, H0, beta, NO_STOP, 5)
+    assert rel_err(Ws, Wd) < 5e-6 and rel_err(Hs, Hd) < 5e-6

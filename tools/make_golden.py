@@ -17,6 +17,7 @@ Sets:
   g5_nmfd        NMFD (1,33,50) r4 T=3 ; (1,65,300) r4 T=12 ; (2,20,64) r3 T=5
   g6_beta_div    metrics.beta_div known answers incl. zeros
   g8_convnd      NMF2D (1,4,20,18) r3 k=(3,4), (2,3,12,10) r2 k=(2,2); NMF3D (1,3,8,9,10) r2 k=(2,3,2): 20 iterations
+  g9_sparse      NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}: factors, losses, n_iter
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
 import os
@@ -243,11 +244,41 @@ def g8():
     np.savez_compressed(os.path.join(OUT, 'g8_convnd.npz'), **out)
 
 
+def g9():
+    """Sparse-COO target through the reference's sparse branches (its dense-equals-sparse property is
+    tests/test_nmf_sparse.py:8-37; here the sparse run's own outputs are stored, including its loss formula)."""
+    g = torch.Generator().manual_seed(1009)
+    N, C, R = 120, 90, 5
+    D = torch.rand(N, C, generator=g)
+    mask = torch.rand(N, C, generator=g) < 0.12
+    mask[7, :] = False          # an empty row and an empty column
+    mask[:, 11] = False
+    idx = torch.nonzero(mask).T
+    vals = D[idx[0], idx[1]]
+    Vs = torch.sparse_coo_tensor(idx, vals, (N, C)).coalesce()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    out = {'indices': Vs.indices().numpy(), 'values': Vs.values().numpy(), 'shape': np.array([N, C]),
+           'W0': W0.numpy(), 'H0': H0.numpy()}
+    for beta in (1, 2):
+        for tag, (tol, it, alpha, l1r) in {'run': (NO_STOP, 25, 0.0, 0.0), 'reg': (NO_STOP, 10, 0.1, 0.5),
+                                            'stop': (1e-3, 200, 0.0, 0.0)}.items():
+            W, H, n, losses = run_ref(ref_nmf.NMF, Vs, W0, H0, beta, tol, it, alpha, l1r)
+            out[f'b{beta}_{tag}_W'], out[f'b{beta}_{tag}_H'] = W.numpy(), H.numpy()
+            out[f'b{beta}_{tag}_n'] = np.int64(n)
+            out[f'b{beta}_{tag}_losses'] = np.array(losses, dtype=np.float64)
+        m = ref_nmf.NMF(W=W0.clone(), H=H0.clone())
+        with torch.no_grad():
+            pos, neg = m._sp_recon_beta_pos_neg(Vs, m.H, m.W, beta)
+            out[f'b{beta}_loss_init'] = np.float64(float((ref_nmf._get_V_norm(Vs, beta) + pos - neg).mul(2).sqrt()))
+    np.savez_compressed(os.path.join(OUT, 'g9_sparse.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
