@@ -218,6 +218,12 @@ class NMF(BaseComponent):
         for p in (self.W, self.H):
             if not p.data.is_contiguous():
                 p.data = p.data.contiguous()
+        if self.W.shape[1] > 256:      # beyond the fused kernel's register-resident rank: the GEMM engine (T = 1)
+            if group is not None:
+                raise NotImplementedError('column sharding is implemented for ranks up to 256')
+            from .nmfd_engine import WideRankMU
+            return WideRankMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
+                              update_W=self.W.requires_grad, update_H=self.H.requires_grad)
         return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
                        update_W=self.W.requires_grad, update_H=self.H.requires_grad)
 

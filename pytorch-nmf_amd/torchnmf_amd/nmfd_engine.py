@@ -219,6 +219,36 @@ class ConvMU:
         return float(self.loss_part.double().sum().item())
 
 
+class WideRankMU:
+    """``NMF.fit`` for ranks above 256.  The fused kernel keeps a rank-wide accumulator tile in registers, which
+    stops at a padded rank of 256; a wider NMF is the T = 1 member of the NMFD family -- V^T as (1, C, N), W as
+    (C, R, 1), H^T as (1, R, N) -- and runs on the GEMM engine, whose effective rank R*T is unbounded.  W shares
+    storage with the parameter; H is kept transposed and copied back after every H half-step (N x R floats)."""
+
+    graphable = False
+
+    def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True):
+        assert V.dim() == 2 and W.dim() == 2 and H.dim() == 2
+        self.H_user = H
+        self.Ht = H.t().contiguous().unsqueeze(0)
+        self.eng = ConvMU(V.t().contiguous().unsqueeze(0), W.unsqueeze(2), self.Ht, beta, l1, l2, precision=precision,
+                          update_W=update_W, update_H=update_H)
+        self.precision_name = self.eng.precision_name
+
+    def target_flags(self):
+        return self.eng.target_flags()
+
+    def w_step(self):
+        self.eng.w_step()
+
+    def h_step(self):
+        self.eng.h_step()
+        self.H_user.copy_(self.Ht[0].t())
+
+    def divergence(self) -> float:
+        return self.eng.divergence()
+
+
 def reconstruct(H: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     """``NMFD / NMF2D / NMF3D.reconstruct`` (nmf.py:776-779, 857-860, 937-940) on the device: Wm @ Hu^T through the
     split-bf16 GEMM, fp32 out."""

@@ -584,8 +584,7 @@ def test_unsupported_combinations_raise(dev):
     with pytest.raises(NotImplementedError):
         m.fit(V.to(dev), precision='bf16x3')      # split precision needs padded rank <= 128
     assert m.fit(V.to(dev), max_iter=3) == 3       # 'auto' falls back to bf16 for wide ranks
-    with pytest.raises(NotImplementedError):
-        NMF(V.shape, 300).to(dev).fit(V.to(dev))   # rank > 256
+    assert NMF(V.shape, 300).to(dev).fit(V.to(dev), max_iter=3) == 3   # rank > 256: GEMM engine (WideRankMU)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -737,3 +736,19 @@ def test_sparse_fit_errors(dev):
     with pytest.raises(NotImplementedError):
         NMFD((1, 20, 30), 3, 2).to(dev).fit(torch.rand(1, 20, 30).to_sparse().to(dev))
     assert m.fit(Vs, beta=1, max_iter=12) <= 12 and bool(torch.all(m.W >= 0))
+
+
+@pytest.mark.parametrize('beta', [1, 2, 0.5])
+def test_rank_above_256_runs_on_the_gemm_engine(dev, beta):
+    """Ranks beyond the fused kernel's 256 (the reference has no limit): NMF as the T = 1 member of the NMFD family."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(300)
+    N, C, R = 350, 420, 300
+    V = torch.rand(N, C, generator=g) + 1e-3
+    W0, H0 = torch.randn(C, R, generator=g).abs(), torch.randn(N, R, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), beta, 1e-4, 30, alpha=0.05, l1_ratio=0.5)
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 30, 0.05, 0.5)
+    assert n == nr and rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+    assert rel_err(m().cpu(), Hr @ Wr.t()) < TOL
