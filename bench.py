@@ -51,7 +51,7 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph instead of launching '
                     'every kernel eagerly (measured no faster on MI355X; fit() does this with TORCHNMF_AMD_GRAPH=1)')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
-    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d', 'sparse'],
+    ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d', 'sparse', 'plca'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
     ap.add_argument('--taps', type=int, default=400)
     ap.add_argument('--kernel2d', type=int, nargs=2, default=[8, 16],
@@ -272,8 +272,78 @@ def main_sparse(a):
         'cpu_baseline': cpu}))
 
 
+def main_plca(a):
+    """PLCA's EM iteration (plca.py:248-290) on the fused kernels; shape = BASELINE configs[1]."""
+    dev = torch.device('cuda', 0)
+    from torchnmf_amd.plca import _PlcaEM, get_norm
+    N, Cc, R = a.rows, a.cols, a.rank
+    g = torch.Generator(device=dev).manual_seed(1000)
+    V = torch.rand(N, Cc, device=dev, generator=g).bfloat16().float()
+    W = torch.rand(Cc, R, device=dev, generator=g)
+    H = torch.rand(N, R, device=dev, generator=g)
+    Z = torch.rand(R, device=dev, generator=g)
+    Vc, Wc, Hc, Zc = (V.cpu(), W.cpu(), H.cpu(), Z.cpu()) if a.cpu_iters > 0 else (None,) * 4
+    for t_ in (W, H, Z):
+        t_.div_(get_norm(t_))
+    em = _PlcaEM((V / V.sum()).contiguous(), W, H, Z, a.precision)
+    del V
+
+    def step():
+        em.em_step(True, True, True, 1.0, 1.0, 1.0)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    flops = 6.0 * N * Cc * R          # as the reference computes it: one reconstruction + the two backward products
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    em.be.mu_partial(em.step_h)
+    ev[0].record()
+    for _ in range(a.steps):
+        em.be.mu_partial(em.step_h)
+    ev[1].record()
+    torch.cuda.synchronize()
+    k_ms = ev[0].elapsed_time(ev[1]) / a.steps
+    ach = 4.0 * N * Cc * R / (k_ms * 1e-3) / 1e12
+    cpu = None
+    if a.cpu_iters > 0:
+        from oracle import aten_port
+        torch.set_flush_denormal(True)
+        cs = min(Cc, 8192)
+        cores, tried = pick_threads(lambda: aten_port.plca_iterations(Vc[:, :cs].contiguous(), Wc[:cs].contiguous(), Hc, Zc, 1))
+        aten_port.plca_iterations(Vc, Wc, Hc, Zc, 1)
+        t0 = time.perf_counter()
+        aten_port.plca_iterations(Vc, Wc, Hc, Zc, a.cpu_iters)
+        dt = (time.perf_counter() - t0) / a.cpu_iters
+        cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+               'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4),
+               'sample': f"{a.cpu_iters} timed EM iterations (+1 warm-up) of the same workload, fp32, the reference's op "
+                         f'sequence (oracle/aten_port.py: plca_iterations)'}
+    print(json.dumps({
+        'metric': f'EM GFLOP/s (algorithmic 6*N*C*R per iteration), PLCA {N}x{Cc} rank-{R}; EM iterations/s alongside',
+        'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
+        'data': 'synthetic',
+        'config': {'workload': f'PLCA {N}x{Cc} rank={R} (SURVEY 8 row f4; shape of BASELINE configs[1])',
+                   'precision': a.precision, 'parallelism': 'single GPU'},
+        'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'nmfmu::fused_kernel',
+                     'avg_launch_ms': round(k_ms, 5),
+                     'note': 'each EM iteration launches the fused kernel twice (both contractions recompute the '
+                             'reconstruction: 8*N*C*R executed for 6*N*C*R algorithmic)'},
+        'cpu_baseline': cpu}))
+
+
 def main():
     a = parse()
+    if a.workload == 'plca':
+        assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'PLCA is not sharded'
+        torch.cuda.set_device(0)
+        return main_plca(a)
     if a.workload == 'sparse':
         assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'the sparse path is not sharded'
         torch.cuda.set_device(0)

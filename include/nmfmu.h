@@ -112,6 +112,11 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
  * load_state_dict changed W/H; the apply step keeps them current afterwards). */
 int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream);
 
+/* nmfmu_pack_factor_scaled: images and column sums of f[row][r] * scale[r] (the master stays as it is).  PLCA feeds
+ * the first GEMM of the fused kernel with the Z-scaled panel and the second with the unscaled one. */
+int nmfmu_pack_factor_scaled(const nmfmu_factor* fac, int rank, int r_pad, int precision, const float* scale,
+                             void* stream);
+
 /* ---- the MU half-step ----------------------------------------------------------------------------------------
  * nmfmu_mu_partial: reconstruct + both backward passes of nmf.py:376-378 / 389-391, fused:
  *   slab_num[s] = sum over the s-th contraction chunk of  Gn(X, owner panel^T) @ panel      (nmf.py:77)
@@ -273,6 +278,21 @@ int nmfmu_sp_loss_neg(const int32_t* rowptr, const int32_t* colidx, const float*
 size_t nmfmu_gram_part_bytes(int rank);   /* scratch of nmfmu_gram */
 int nmfmu_gram(const float* f, int rows, int rank, float* part, float* gram, void* stream);
 int nmfmu_rowmat(const float* owner, int rows, int rank, const float* gram, float* den, int r_pad, void* stream);
+
+/* ---- PLCA's EM update (plca.py:248-290) -----------------------------------------------------------------------------
+ * With G = Vn / (H diag(Z) W^T + eps) the factor "gradients" are (G^T H) * Z, (G W) * Z and Z.grad[r] = sum W * (G^T H);
+ * nmfmu_mu_partial delivers the unscaled numerators G^T H / G W when the step's panel struct carries the image of the
+ * Z-scaled factor as p1 (reconstruction) and of the unscaled factor as p2.  part: nmfmu_plca_part_bytes() of scratch.
+ *   nmfmu_plca_em        f *= relu(num * z_old) (skipped when update == 0); colsum_out = column sums of the result;
+ *                        zgrad_out (may be NULL) = sum_rows f_old * num
+ *   nmfmu_plca_normalize f /= divider[r]; when alpha != 1: f += alpha - 1, clamped below at eps; colsum_out = column sums
+ *   nmfmu_plca_scale     f /= colsum[r] */
+size_t nmfmu_plca_part_bytes(int rows, int r_pad);
+int nmfmu_plca_em(float* f, int rows, int rank, int r_pad, const float* num, int nslab, int rows_pad, const float* z_old,
+                  int update, float* part, float* colsum_out, float* zgrad_out, void* stream);
+int nmfmu_plca_normalize(float* f, int rows, int rank, int r_pad, const float* divider, float alpha, float* part,
+                         float* colsum_out, void* stream);
+int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */

@@ -150,3 +150,26 @@ def sp_mu_iterations(V, W0, H0, beta=1, n_iter=1):
         pos, neg = terms(H, W.detach())
         update(H, pos, neg, W.detach().sum(0) if beta == 1 else None)
     return W.data, H.data
+
+
+def plca_iterations(V, W0, H0, Z0, n_iter=1):
+    """PLCA's EM iteration with the reference's op sequence (plca.py:248-290, all factors trainable, no priors): one
+    reconstruction H @ (W * Z).T, one backward with V / (WZH + eps), relu / mul / div in place."""
+    def nrm(x):
+        return x.sum([d for d in range(x.dim()) if d != 1], keepdim=True) if x.dim() > 1 else x.sum()
+    W = torch.nn.Parameter(W0.clone().float() / nrm(W0.float()))
+    H = torch.nn.Parameter(H0.clone().float() / nrm(H0.float()))
+    Z = torch.nn.Parameter(Z0.clone().float() / Z0.float().sum())
+    Vn = V / V.sum()
+    for _ in range(n_iter):
+        for p in (W, H, Z):
+            p.grad = None
+        WZH = H @ (W * Z).t()
+        WZH.backward(Vn / WZH.add(EPS))
+        with torch.no_grad():
+            Z.data.mul_(Z.grad.relu())
+            z_prior = Z.data.clone()
+            Z.data.div_(Z.data.sum())
+            W.data.mul_(W.grad.relu()).div_(z_prior)
+            H.data.mul_(H.grad.relu()).div_(z_prior)
+    return W.data, H.data, Z.data

@@ -411,6 +411,85 @@ def sp_fit(idx, vals, shape, W0, H0, beta=1, tol=1e-4, max_iter=200, alpha=0, l1
 
 
 # --------------------------------------------------------------------------
+# PLCA (plca.py:311-373) fitted by EM (plca.py:193-304):  V / V.sum() ~ H diag(Z) W^T.
+# One reconstruction per iteration feeds all three updates (unlike NMF's alternating half-steps): with
+# G = Vn / (H diag(Z) W^T + eps) the reference's WZH.backward(G) leaves
+#   W.grad = (G^T H) * Z      H.grad = (G W) * Z      Z.grad[r] = sum_{n,c} G[n,c] H[n,r] W[c,r]
+# --------------------------------------------------------------------------
+def plca_norm(x: torch.Tensor) -> torch.Tensor:
+    """get_norm of plca.py:27-35: sum over everything but axis 1 (vectors: total sum)."""
+    if x.dim() > 1:
+        return x.sum([d for d in range(x.dim()) if d != 1], keepdim=True)
+    return x.sum()
+
+
+def plca_reconstruct(H, W, Z):
+    return H @ (W * Z).t()          # plca.py:371-373
+
+
+def _plca_prior(x, alpha):
+    """plca.py:258-260, 272-275, 286-289 without the final renormalisation: add alpha - 1, clamp below at eps."""
+    x = x + (alpha - 1)
+    return torch.where(x > EPS, x, torch.full_like(x, EPS))   # F.threshold(x, eps, eps)
+
+
+def plca_em_step(Vn, W, H, Z, W_alpha=1.0, H_alpha=1.0, Z_alpha=1.0, train=(True, True, True)):
+    """One EM iteration (plca.py:248-290).  ``train`` = (W, H, Z) trainable flags."""
+    tW, tH, tZ = train
+    G = Vn / (plca_reconstruct(H, W, Z) + EPS)
+    GtH, GW = G.t() @ H, G @ W
+    Wg, Hg, Zg = GtH * Z, GW * Z, (W * GtH).sum(0)
+    z_prior = None
+    if tZ:
+        Z = Z * Zg.relu()
+        z_prior = Z.clone()
+        if Z_alpha != 1:
+            Z = _plca_prior(Z, Z_alpha)
+        Z = Z / Z.sum()
+    if tW:
+        W = W * Wg.relu()
+        if z_prior is None:
+            div = plca_norm(W)
+            z_prior = div.squeeze()
+        else:
+            div = z_prior
+        W = W / div
+        if W_alpha != 1:
+            W = _plca_prior(W, W_alpha)
+            W = W / plca_norm(W)
+    if tH:
+        H = H * Hg.relu()
+        div = plca_norm(H) if z_prior is None else z_prior
+        H = H / div
+        if H_alpha != 1:
+            H = _plca_prior(H, H_alpha)
+            H = H / plca_norm(H)
+    return W, H, Z
+
+
+def plca_loss(V, W, H, Z, norm) -> float:
+    return float((beta_div(plca_reconstruct(H, W, Z) * norm, V, 1) * 2).sqrt())   # plca.py:245-246, 294-295 (kl_div; V = Vn * norm)
+
+
+def plca_fit(V, W0, H0, Z0, tol=1e-4, max_iter=200, W_alpha=1.0, H_alpha=1.0, Z_alpha=1.0, train=(True, True, True)):
+    """Returns (W, H, Z, n_iter, norm, losses) -- n_iter is the LAST iteration index, as plca.py:304 returns it."""
+    W, H, Z = W0 / plca_norm(W0), H0 / plca_norm(H0), Z0 / plca_norm(Z0)     # the constructor, plca.py:91-121
+    norm = V.sum()
+    Vn = V / norm
+    loss_init = plca_loss(V, W, H, Z, norm)
+    losses, prev, n_iter = [loss_init], loss_init, -1
+    for n_iter in range(max_iter):
+        W, H, Z = plca_em_step(Vn, W, H, Z, W_alpha, H_alpha, Z_alpha, train)
+        if n_iter % 10 == 9:
+            loss = plca_loss(V, W, H, Z, norm)
+            losses.append(loss)
+            if (prev - loss) / loss_init < tol:
+                break
+            prev = loss
+    return W, H, Z, n_iter, float(norm), losses
+
+
+# --------------------------------------------------------------------------
 # column-sharded NMF (SURVEY.md section 8e): simulated on one process.
 # Shard g owns V[:, Cg] and W[Cg]; H is replicated.  W half-step is local, the
 # H half-step sums per-shard partial numerators/denominators (the all-reduce),

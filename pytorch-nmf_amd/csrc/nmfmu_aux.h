@@ -21,6 +21,7 @@ struct ApplyArgs {
   float l1, l2, gamma;
   // trainer.BetaMu semantics (trainer.py:93-112) instead of fit's (nmf.py:78-92): eps added after the penalties,
   // orthogonality penalty, and grad[row][r] = relu(den) - relu(num) written out (p.grad of trainer.py:98)
+  const float* scale;   // PACK_ONLY: images (and column sums) of f[row][r] * scale[r]; the master is not touched
   int trainer;
   float ortho;
   float* grad;          // [rows][rank] or nullptr

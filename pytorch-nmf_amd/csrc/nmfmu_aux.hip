@@ -127,6 +127,10 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
       const float* fp = a.f + (size_t)row * a.rank + r;
       const int nv = min(4, a.rank - r);
       for (int i = 0; i < nv; ++i) f[i] = fp[i];
+      if constexpr (PACK_ONLY) {
+        if (a.scale)
+          for (int i = 0; i < nv; ++i) f[i] *= a.scale[r + i];
+      }
       if constexpr (!PACK_ONLY) {
         const size_t e = (size_t)row * R_PAD + r;
         float4 n4 = *reinterpret_cast<const float4*>(a.num + e);

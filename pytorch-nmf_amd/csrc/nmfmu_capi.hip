@@ -150,7 +150,8 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
                        panel_rows_pad, flags, block_rows / 128, S(stream));
 }
 
-int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream) {
+static int pack_factor_common(const nmfmu_factor* fac, int rank, int r_pad, int precision, const float* scale,
+                              void* stream) {
   if (!fac || !fac->f || !fac->p1_hi || !fac->p2_hi || !fac->colsum || !fac->colsum_part) return NMFMU_ERR_ARG;
   if (r_pad != pad_rank(rank) || fac->rows_pad != pad_rows(fac->rows)) return NMFMU_ERR_ARG;
   const bool x3 = precision == NMFMU_PREC_BF16X3;
@@ -161,7 +162,18 @@ int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precisio
   a.colsum_part = fac->colsum_part, a.colsum = fac->colsum;
   a.rows = fac->rows, a.rank = rank, a.rows_pad = fac->rows_pad;
   a.gamma = 1.f;
+  a.scale = scale;
   return launch_apply(r_pad, a, x3, /*pack_only=*/true, S(stream));
+}
+
+int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream) {
+  return pack_factor_common(fac, rank, r_pad, precision, nullptr, stream);
+}
+
+int nmfmu_pack_factor_scaled(const nmfmu_factor* fac, int rank, int r_pad, int precision, const float* scale,
+                             void* stream) {
+  if (!scale) return NMFMU_ERR_ARG;
+  return pack_factor_common(fac, rank, r_pad, precision, scale, stream);
 }
 
 int nmfmu_mu_partial(const nmfmu_step* st, void* stream) {

@@ -1,0 +1,114 @@
+// PLCA's EM update (reference: plca.py:248-290) around the fused kernel.
+//
+// The O(N C R) work of an EM iteration -- G = Vn / (H diag(Z) W^T + eps), G^T H and G W -- runs on the fused MU kernel
+// with a split panel (first GEMM reads the image of the Z-scaled factor, second GEMM the unscaled one).  What is left
+// is O((N + C) R) per factor, the three small kernels here:
+//   plca_em        f *= relu(num * z_old)          + column sums of the result + Z.grad partials  sum_rows f_old * num
+//   plca_normalize f /= divider ; Dirichlet prior: f += alpha - 1, clamp below at eps ; column sums of the result
+//   plca_scale     f /= colsum                     (renormalisation after a prior)
+// Column sums are two-stage and order-fixed (deterministic), like everywhere else in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nmfmu.h"
+#include "nmfmu_aux.h"
+#include "nmfmu_fused.h"
+
+namespace nmfmu {
+
+constexpr int kPlcaRows = 32;   // factor rows per workgroup
+
+// threads: column r = tid % r_pad, row group g = tid / r_pad (256 / r_pad groups); rows g, g + groups, ... of the block
+template <int MODE>   // 0: em, 1: normalize
+__global__ void __launch_bounds__(256) plca_kernel(float* __restrict__ f, int rows, int rank, int r_pad,
+                                                   const float* __restrict__ num, int nslab, size_t plane,
+                                                   const float* __restrict__ vec, float alpha, int update,
+                                                   float* __restrict__ cs_part, float* __restrict__ zg_part) {
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x, r = tid % r_pad, g = tid / r_pad, groups = 256 / r_pad;
+  const int row0 = blockIdx.x * kPlcaRows;
+  float cs = 0.f, zg = 0.f;
+  if (r < rank) {
+    const float v = vec[r];   // MODE 0: z_old[r];  MODE 1: divider[r]
+    for (int rl = g; rl < kPlcaRows; rl += groups) {
+      const int row = row0 + rl;
+      if (row >= rows) break;
+      const size_t i = (size_t)row * rank + r;
+      float x = f[i];
+      if constexpr (MODE == 0) {
+        float n = 0.f;
+        for (int s = 0; s < nslab; ++s) n += num[s * plane + (size_t)row * r_pad + r];   // unscaled numerator
+        zg += x * n;                                   // Z.grad[r] = sum f_old * num   (plca.py:250)
+        x *= fmaxf(n * v, 0.f);                        // f *= relu(f.grad), f.grad = num * z_old  (plca.py:263, 277)
+      } else {
+        x /= v;                                        // plca.py:270, 284
+        if (alpha != 1.f) {
+          x += alpha - 1.f;                            // plca.py:272-274, 286-288
+          x = x > kEps ? x : kEps;                     // F.threshold(x, eps, eps)
+        }
+      }
+      if (update) f[i] = x;
+      cs += x;
+    }
+  }
+  red[0][tid] = cs;
+  red[1][tid] = zg;
+  __syncthreads();
+  if (g == 0) {
+    for (int k = 1; k < groups; ++k) cs += red[0][k * r_pad + r], zg += red[1][k * r_pad + r];
+    cs_part[(size_t)blockIdx.x * r_pad + r] = cs;
+    if (zg_part) zg_part[(size_t)blockIdx.x * r_pad + r] = zg;
+  }
+}
+
+__global__ void __launch_bounds__(256) plca_scale_kernel(float* __restrict__ f, int64_t n, int rank,
+                                                         const float* __restrict__ colsum) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) f[i] /= colsum[i % rank];
+}
+
+}  // namespace nmfmu
+
+using namespace nmfmu;
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int nblk_of(int rows) { return (rows + kPlcaRows - 1) / kPlcaRows; }
+}  // namespace
+
+extern "C" {
+
+size_t nmfmu_plca_part_bytes(int rows, int r_pad) {
+  return rows > 0 && r_pad > 0 ? (size_t)2 * nblk_of(rows) * r_pad * 4 : 0;
+}
+
+int nmfmu_plca_em(float* f, int rows, int rank, int r_pad, const float* num, int nslab, int rows_pad, const float* z_old,
+                  int update, float* part, float* colsum_out, float* zgrad_out, void* stream) {
+  if (!f || !num || !z_old || !part || !colsum_out || rows <= 0 || rank <= 0 || nslab < 1) return NMFMU_ERR_ARG;
+  if (r_pad != nmfmu_pad_rank(rank) || rows_pad < rows) return NMFMU_ERR_ARG;
+  const int nb = nblk_of(rows);
+  float* zg_part = zgrad_out ? part + (size_t)nb * r_pad : nullptr;
+  hipLaunchKernelGGL(plca_kernel<0>, dim3(nb), dim3(256), 0, S(stream), f, rows, rank, r_pad, num, nslab,
+                     (size_t)rows_pad * r_pad, z_old, 1.f, update, part, zg_part);
+  int e = launch_colsum_finalize(part, nb, r_pad, colsum_out, S(stream));   // two-stage, order-fixed (nmfmu_aux.hip)
+  if (!e && zgrad_out) e = launch_colsum_finalize(zg_part, nb, r_pad, zgrad_out, S(stream));
+  return e;
+}
+
+int nmfmu_plca_normalize(float* f, int rows, int rank, int r_pad, const float* divider, float alpha, float* part,
+                         float* colsum_out, void* stream) {
+  if (!f || !divider || !part || !colsum_out || rows <= 0 || rank <= 0 || r_pad != nmfmu_pad_rank(rank)) return NMFMU_ERR_ARG;
+  const int nb = nblk_of(rows);
+  hipLaunchKernelGGL(plca_kernel<1>, dim3(nb), dim3(256), 0, S(stream), f, rows, rank, r_pad, nullptr, 0, (size_t)0, divider,
+                     alpha, 1, part, nullptr);
+  return launch_colsum_finalize(part, nb, r_pad, colsum_out, S(stream));
+}
+
+int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* stream) {
+  if (!f || !colsum || rows <= 0 || rank <= 0) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)rows * rank;
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(plca_scale_kernel, dim3(grid), dim3(256), 0, S(stream), f, n, rank, colsum);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -9,4 +9,4 @@ Only the dense beta-divergence MU hot path of yoyololicon/pytorch-NMF is impleme
 name = 'torchnmf_amd'
 __version__ = '0.1.0'
 
-from . import constants, metrics, nmf, trainer  # noqa: E402,F401
+from . import constants, metrics, nmf, plca, trainer  # noqa: E402,F401

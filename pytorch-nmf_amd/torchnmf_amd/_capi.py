@@ -103,6 +103,13 @@ SIGNATURES = {
     'nmfmu_gram_part_bytes': (C.c_size_t, [C.c_int]),
     'nmfmu_gram': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_rowmat': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_pack_factor_scaled': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_plca_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'nmfmu_plca_em': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_plca_normalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    'nmfmu_plca_scale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

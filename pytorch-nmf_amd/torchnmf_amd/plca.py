@@ -1,0 +1,280 @@
+"""``PLCA`` -- probabilistic latent component analysis ``V / V.sum() ~ H diag(Z) W^T`` fitted by EM on the MI355X
+(reference: plca.py:22-373).
+
+One EM iteration needs ``G = Vn / (H diag(Z) W^T + eps)``, ``G^T H`` and ``G W`` -- the same fused reconstruction ->
+ratio -> contraction the NMF beta = 1 half-step performs, with the latent weights folded into the panel of the first
+GEMM only.  Both contractions run on ``nmfmu::fused_kernel`` (through ``nmfmu_mu_partial`` with a split panel: image of
+the Z-scaled factor for the reconstruction, image of the unscaled factor for the second GEMM); the O((N + C) R)
+remainder of plca.py:248-290 (multiply by relu(grad), divide by the latent prior, Dirichlet prior, renormalise) runs in
+the small ``nmfmu_plca_*`` kernels, and only the R-element latent vector is updated with torch scalar ops.
+``SIPLCA*`` (the shift-invariant variants) are not implemented.
+"""
+from collections.abc import Iterable
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi
+from .constants import eps as _EPS
+from .engine import DEFAULT_BACKEND_FACTORY, FactorBuf, StepBuf, _ptr
+from .nmf import _require_device
+
+__all__ = ['PLCA', 'BaseComponent']
+
+
+def get_norm(x: Tensor) -> Tensor:
+    """plca.py:27-35: sum over every axis but 1 (a vector: its total)."""
+    if x.ndim > 1:
+        return x.sum([d for d in range(x.dim()) if d != 1], keepdim=True)
+    return x.sum()
+
+
+def _new(spec, trainable, label):
+    if isinstance(spec, Tensor):
+        assert bool(torch.all(spec >= 0.)), f"Tensor {label} should be non-negative."
+        p = nn.Parameter(torch.empty(*spec.size()), requires_grad=trainable)
+        p.data.copy_(spec)
+    elif isinstance(spec, Iterable):
+        p = nn.Parameter(torch.randn(*tuple(spec)).abs())
+    else:
+        return None
+    p.data.div_(get_norm(p.data))          # plca.py:91, 105
+    return p
+
+
+class BaseComponent(nn.Module):
+    """Base of the PLCA modules (plca.py:38-191): W, H normalised over everything but the rank axis, Z a distribution."""
+
+    def __init__(self, rank=None, W=None, H=None, Z=None, trainable_W=True, trainable_H=True, trainable_Z=True):
+        super().__init__()
+        self.register_parameter('W', _new(W, trainable_W, 'W'))
+        self.register_parameter('H', _new(H, trainable_H, 'H'))
+        infer = None
+        if self.W is not None:
+            infer = self.W.shape[1]
+        if self.H is not None:
+            infer = self.H.shape[1]
+        if isinstance(Z, Tensor):
+            assert Z.ndim == 1, "Z should be one dimensional."
+            assert bool(torch.all(Z >= 0.)), "Tensor Z should be non-negative."
+            z = nn.Parameter(torch.empty(Z.numel()), requires_grad=trainable_Z)
+            z.data.copy_(Z)
+        elif isinstance(rank, int):
+            z = nn.Parameter(torch.ones(rank) / rank)
+        else:
+            z = None
+        self.register_parameter('Z', z)
+        if z is not None:
+            z.data.div_(get_norm(z.data))   # plca.py:121
+            infer = z.shape[0]
+        if infer is None:
+            assert rank, "A rank should be given when W, H and Z are not available!"
+        else:
+            if self.Z is not None:
+                assert self.Z.shape[0] == infer, "Latent size of Z does not match with others!"
+            if self.H is not None:
+                assert self.H.shape[1] == infer, "Latent size of H does not match with others!"
+            if self.W is not None:
+                assert self.W.shape[1] == infer, "Latent size of W does not match with others!"
+                self.out_channels = self.W.shape[0]
+                if self.W.ndim > 2:
+                    self.kernel_size = tuple(self.W.shape[2:])
+            rank = infer
+        self.rank = rank
+
+    def extra_repr(self) -> str:
+        s = f'{self.rank}'
+        if self.W is not None:
+            s += f', out_channels={self.out_channels}'
+            if hasattr(self, 'kernel_size'):
+                s += f', kernel_size={self.kernel_size}'
+        return s
+
+    def forward(self, H: Tensor = None, W: Tensor = None, Z: Tensor = None, norm: Optional[float] = None) -> Tensor:
+        """plca.py:155-183: reconstruction with the module's own tensors substituted for missing arguments."""
+        H = self.H if H is None else H
+        W = self.W if W is None else W
+        Z = self.Z if Z is None else Z
+        out = self.reconstruct(H, W, Z)
+        return out if norm is None else out * norm
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
+        raise NotImplementedError
+
+    def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
+        raise NotImplementedError
+
+
+class _PlcaEM:
+    """Device state of one PLCA fit: packed Vn (both orientations), factor images (scaled and unscaled), slabs."""
+
+    def __init__(self, Vn, W, H, Z, precision):
+        self.be = DEFAULT_BACKEND_FACTORY()
+        self.lib = be = self.be.lib
+        N, Cc = Vn.shape
+        R = W.shape[1]
+        self.R, self.r_pad = R, self.be.pad_rank(R)
+        if precision in (None, 'auto'):
+            precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
+        self.prec = _capi.PRECISIONS[precision]
+        if not self.be.supported(self.r_pad, self.prec):
+            raise NotImplementedError(f'precision {precision!r} is not available for rank {R}')
+        dev = Vn.device
+        self.W, self.H, self.Z = W, H, Z
+        mk = lambda t: FactorBuf(t, self.r_pad, self.prec, self.be)
+        self.fW, self.fWz, self.fH, self.fHz = mk(W), mk(W), mk(H), mk(H)   # the *z buffers carry images of f * Z
+        self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
+        n_pad, c_pad = self.fH.rows_pad, self.fW.rows_pad
+        br = 128
+        xp_h = self.be.pack_x(Vn, False, self.prec, br, n_pad, c_pad, self.flags)
+        xp_w = self.be.pack_x(Vn, True, self.prec, br, c_pad, n_pad, None)
+        ns_h = self.be.choose_nsplit(n_pad, c_pad, br, dev)
+        ns_w = self.be.choose_nsplit(c_pad, n_pad, br, dev)
+
+        def step(xp, owner, p1_src, p2_src, ns):
+            st = StepBuf(xp, owner, p2_src, R, self.r_pad, ns, self.prec, _capi.STAGE_DMA, br, 1.0, 1.0, 0.0, 0.0,
+                         need_den=False)
+            # split panel: reconstruction from the Z-scaled images, second GEMM from the unscaled ones
+            st.struct.panel.p1_hi, st.struct.panel.p1_lo = _ptr(p1_src.p1_hi), _ptr(p1_src.p1_lo)
+            return st
+        self.step_w = step(xp_w, self.fW, self.fHz, self.fH, ns_w)   # num'_W = G^T H
+        self.step_h = step(xp_h, self.fH, self.fWz, self.fW, ns_h)   # num'_H = G W
+        # loss: beta_div(H (W Z)^T, Vn, 1) -- owner H, panel entirely the scaled W
+        self.step_l = StepBuf(xp_h, self.fH, self.fWz, R, self.r_pad, ns_h, self.prec, _capi.STAGE_DMA, br, 1.0, 1.0, 0.0,
+                              0.0, need_den=False)
+        self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        nb = max(self.lib.nmfmu_plca_part_bytes(max(N, Cc), self.r_pad), 16)
+        self.part = self.be.alloc(nb, dev)
+        self.cs = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)
+        self.cs2 = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)
+        self.zg = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)
+        self.zpad = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)   # Z padded to r_pad for the kernels
+        self.div = torch.ones(self.r_pad, dtype=torch.float32, device=dev)
+        self.repack()
+
+    def _s(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def repack(self):
+        self.zpad[:self.R] = self.Z
+        for plain, scaled in ((self.fW, self.fWz), (self.fH, self.fHz)):
+            self.be.pack_factor(plain, self.R, self.r_pad, self.prec)
+            _capi.check(self.lib.nmfmu_pack_factor_scaled(plain_struct(scaled), self.R, self.r_pad, self.prec,
+                                                          self.zpad.data_ptr(), self._s()), 'nmfmu_pack_factor_scaled')
+
+    def divergence(self) -> float:
+        self.be.loss(self.step_l, self.loss_part, self.loss_out)
+        return float(self.loss_out.item())
+
+    def _factor_update(self, f, st, z_old, trainable, alpha, z_prior, want_zgrad):
+        """plca.py:262-289 for one factor; returns the latent prior to use for the next factor."""
+        rows = f.shape[0]
+        _capi.check(self.lib.nmfmu_plca_em(f.data_ptr(), rows, self.R, self.r_pad, st.slab_num.data_ptr(), st.nsplit,
+                                           st.owner.rows_pad, z_old.data_ptr(), int(trainable), self.part.data_ptr(),
+                                           self.cs.data_ptr(), self.zg.data_ptr() if want_zgrad else None, self._s()),
+                    'nmfmu_plca_em')
+        if not trainable:
+            return z_prior
+        if z_prior is None:
+            z_prior = self.cs[:self.R].clone()          # get_norm of the multiplied factor (plca.py:265-266, 279)
+        self.div[:self.R] = z_prior
+        _capi.check(self.lib.nmfmu_plca_normalize(f.data_ptr(), rows, self.R, self.r_pad, self.div.data_ptr(), float(alpha),
+                                                  self.part.data_ptr(), self.cs2.data_ptr(), self._s()),
+                    'nmfmu_plca_normalize')
+        if alpha != 1:
+            _capi.check(self.lib.nmfmu_plca_scale(f.data_ptr(), rows, self.R, self.cs2.data_ptr(), self._s()),
+                        'nmfmu_plca_scale')
+        return z_prior
+
+    def em_step(self, tW, tH, tZ, W_alpha, H_alpha, Z_alpha):
+        """One EM iteration (plca.py:248-290): every update uses the gradients of ONE reconstruction."""
+        eps = _EPS
+        self.be.mu_partial(self.step_w)
+        self.be.mu_partial(self.step_h)
+        z_old = self.zpad.clone()
+        # W first on the device (its pass also yields Z.grad), but Z's new value must be known before W is divided
+        # by the latent prior: plca_em only multiplies, the division happens in _factor_update's second kernel.
+        _capi.check(self.lib.nmfmu_plca_em(self.W.data_ptr(), self.W.shape[0], self.R, self.r_pad,
+                                           self.step_w.slab_num.data_ptr(), self.step_w.nsplit, self.fW.rows_pad,
+                                           z_old.data_ptr(), 0, self.part.data_ptr(), self.cs.data_ptr(),
+                                           self.zg.data_ptr(), self._s()), 'nmfmu_plca_em')
+        z_prior = None
+        if tZ:                                          # plca.py:253-260
+            z1 = self.Z.data * self.zg[:self.R].relu()
+            z_prior = z1.clone()
+            if Z_alpha != 1:
+                z1 = z1 + (Z_alpha - 1)
+                z1 = torch.where(z1 > eps, z1, torch.full_like(z1, eps))
+            self.Z.data.copy_(z1 / z1.sum())
+        z_prior = self._factor_update(self.W.data, self.step_w, z_old, tW, W_alpha, z_prior, False)
+        self._factor_update(self.H.data, self.step_h, z_old, tH, H_alpha, z_prior, False)
+        self.repack()
+
+
+def plain_struct(fb: FactorBuf):
+    import ctypes
+    return ctypes.byref(fb.struct)
+
+
+class PLCA(BaseComponent):
+    """``V ~ H diag(Z) W^T`` with V (N, C), W (C, R), H (N, R), Z (R,) (reference: plca.py:311-373)."""
+
+    def __init__(self, Vshape=None, rank=None, **kwargs):
+        if isinstance(Vshape, Iterable):
+            M, K = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (K, rank)
+            kwargs['H'] = (M, rank)
+        super().__init__(rank, **kwargs)
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
+        """``H @ (W * Z).T`` (plca.py:371-373) on the device (exact-fp32 MFMA kernel of NMF.reconstruct)."""
+        from .nmf import NMF
+        return NMF.reconstruct(H, W.detach() * Z.detach())
+
+    @torch.no_grad()
+    def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
+        """EM fit (plca.py:193-304).  Returns ``(n_iter, norm)`` like the reference: the index of the last iteration and
+        ``V.sum()``.  Scalar Dirichlet hyper-parameters only."""
+        W, H, Z = self.W, self.H, self.Z
+        assert W is not None and H is not None and Z is not None
+        for t_, what in ((V, 'fit'), (W, 'fit'), (H, 'fit'), (Z, 'fit')):
+            _require_device(t_, what)
+        for a in (W_alpha, H_alpha, Z_alpha):
+            if isinstance(a, Tensor):
+                raise NotImplementedError('tensor-valued Dirichlet hyper-parameters are not implemented')
+        V = V.detach().float()
+        assert bool(torch.all(V >= 0.)), "Target should be non-negative."
+        assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0])
+        norm = V.sum()
+        Vn = (V.contiguous() / norm).contiguous()
+        for p in (W, H, Z):
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+        em = _PlcaEM(Vn, W.data, H.data, Z.data, precision)
+        nrm = float(norm.item())
+        loss_init = previous = (2.0 * nrm * em.divergence()) ** 0.5      # kl_div(WZH * norm, V), plca.py:245-246
+        pbar = None
+        if verbose:
+            from tqdm import tqdm
+            pbar = tqdm(total=max_iter)
+        n_iter = -1
+        try:
+            for n_iter in range(max_iter):
+                em.em_step(W.requires_grad, H.requires_grad, Z.requires_grad, W_alpha, H_alpha, Z_alpha)
+                if n_iter % 10 == 9:
+                    loss = (2.0 * nrm * em.divergence()) ** 0.5
+                    if pbar is not None:
+                        pbar.set_postfix(loss=loss)
+                        pbar.update(10)
+                    if (previous - loss) / loss_init < tol:
+                        break
+                    previous = loss
+        finally:
+            if pbar is not None:
+                pbar.close()
+        return n_iter, norm

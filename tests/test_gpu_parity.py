@@ -752,3 +752,42 @@ def test_rank_above_256_runs_on_the_gemm_engine(dev, beta):
     Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 30, 0.05, 0.5)
     assert n == nr and rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
     assert rel_err(m().cpu(), Hr @ Wr.t()) < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------
+# PLCA: plca.py:193-373
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,ctor,fitkw', [
+    ('plain', {}, {}), ('prior', {}, dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01)), ('frozenZ', dict(trainable_Z=False), {}),
+    ('frozenW', dict(trainable_W=False), {}), ('stop', {}, dict(tol=1e-3, max_iter=200))])
+def test_plca_fit_g10_golden(dev, name, ctor, fitkw):
+    from torchnmf_amd.plca import PLCA
+    g = load_golden('g10_plca')
+    m = PLCA(W=t(g['W0']), H=t(g['H0']), Z=t(g['Z0']), **ctor).to(dev)
+    if name == 'plain':
+        assert rel_err(m().cpu(), g['recon_init']) < 1e-5 and rel_err(m(norm=3.0).cpu(), 3.0 * g['recon_init']) < 1e-5
+    fitkw = dict(fitkw)
+    fitkw.setdefault('tol', NO_STOP)
+    fitkw.setdefault('max_iter', 30)
+    n, norm = m.fit(t(g['V']).to(dev), **fitkw)
+    assert n == int(g[f'{name}_n']) and float(norm) == pytest.approx(float(g[f'{name}_norm']), rel=1e-5)
+    for p, k in ((m.W, 'W'), (m.H, 'H'), (m.Z, 'Z')):
+        assert rel_err(p.data.cpu(), g[f'{name}_{k}']) < TOL, (k, rel_err(p.data.cpu(), g[f'{name}_{k}']))
+
+
+@pytest.mark.parametrize('rank,prec', [(5, 'bf16x3'), (100, 'bf16x3'), (100, 'bf16'), (200, None)])
+def test_plca_medium_against_oracle(dev, rank, prec):
+    from oracle import mu_oracle as O
+    from torchnmf_amd.plca import PLCA
+    g = torch.Generator().manual_seed(rank)
+    N, C = 330, 520
+    V = torch.rand(N, C, generator=g)
+    W0, H0, Z0 = torch.rand(C, rank, generator=g), torch.rand(N, rank, generator=g), torch.rand(rank, generator=g)
+    m = PLCA(W=W0, H=H0, Z=Z0).to(dev)
+    n, norm = m.fit(V.to(dev), NO_STOP, 6, W_alpha=1.001, precision=prec)
+    Wr, Hr, Zr, nr, _, _ = O.plca_fit(V, W0, H0, Z0, NO_STOP, 6, W_alpha=1.001)
+    tol = TOL if prec == 'bf16x3' else 2e-2
+    assert n == nr
+    for p, ref in ((m.W, Wr), (m.H, Hr), (m.Z, Zr)):
+        assert rel_err(p.data.cpu(), ref) < tol, rel_err(p.data.cpu(), ref)
+    assert m.W.data.sum(0).cpu() == pytest.approx(torch.ones(rank).numpy(), rel=1e-4)

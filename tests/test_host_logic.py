@@ -179,6 +179,28 @@ def test_nmf2d_nmf3d_constructors():
         m()
 
 
+def test_plca_constructor_rules():
+    """plca.py:60-140, 352-361: arguments are normalised, Z defaults to uniform, rank inference and its asserts."""
+    from torchnmf_amd.plca import PLCA
+    m = PLCA((20, 30), 5)
+    assert tuple(m.W.shape) == (30, 5) and tuple(m.H.shape) == (20, 5) and tuple(m.Z.shape) == (5,)
+    assert torch.allclose(m.W.sum(0), torch.ones(5)) and torch.allclose(m.H.sum(0), torch.ones(5))
+    assert torch.allclose(m.Z.data, torch.full((5,), 0.2)) and m.rank == 5 and m.out_channels == 30
+    g = load_golden('g10_plca')
+    m = PLCA(W=t(g['W0']), H=t(g['H0']), Z=t(g['Z0']), trainable_Z=False)
+    assert rel_err(m.W.data, g['W_init']) < 1e-6 and rel_err(m.H.data, g['H_init']) < 1e-6 and rel_err(m.Z.data, g['Z_init']) < 1e-6
+    assert not m.Z.requires_grad and m.W.requires_grad
+    assert PLCA((7, 9)).rank == 9
+    with pytest.raises(AssertionError):
+        PLCA(W=torch.rand(9, 3), H=torch.rand(7, 4))
+    with pytest.raises(AssertionError):
+        PLCA(W=-torch.rand(9, 3), H=torch.rand(7, 3))
+    with pytest.raises(AssertionError):
+        PLCA(W=torch.rand(9, 3), H=torch.rand(7, 3), Z=torch.rand(3, 1))
+    with pytest.raises(_capi.NmfmuError):          # no CPU fallback
+        m()
+
+
 # ---- trainer.BetaMu host logic on the stand-in backend --------------------------------------------------------
 @pytest.mark.parametrize('case', ['b1_plain_both', 'b0.5_pen_both', 'b2_plain_W', 'b3_plain_H', 'b-1_pen_both'])
 def test_betamu_step_matches_reference(cpu_engine, case):

@@ -234,3 +234,22 @@ def test_g9_sparse_oracle(beta, tag, args):
     Wd, Hd, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 5)
     Ws, Hs, _, _ = O.sp_fit(idx, vals, tuple(g['shape']), W0, H0, beta, NO_STOP, 5)
     assert rel_err(Ws, Wd) < 5e-6 and rel_err(Hs, Hd) < 5e-6
+
+
+# ---- PLCA --------------------------------------------------------------------------
+G10_CASES = {'plain': {}, 'prior': dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01), 'frozenZ': dict(train=(True, True, False)),
+             'frozenW': dict(train=(False, True, True)), 'stop': dict(tol=1e-3, max_iter=200)}
+
+
+@pytest.mark.parametrize('name', list(G10_CASES))
+def test_g10_plca_oracle(name):
+    g = load_golden('g10_plca')
+    V, W0, H0, Z0 = (torch.from_numpy(g[k]) for k in ('V', 'W0', 'H0', 'Z0'))
+    kw = dict(G10_CASES[name])
+    kw.setdefault('tol', NO_STOP)
+    kw.setdefault('max_iter', 30)
+    W, H, Z, n, norm, losses = O.plca_fit(V, W0, H0, Z0, **kw)
+    assert n == int(g[f'{name}_n']) and norm == pytest.approx(float(g[f'{name}_norm']), rel=1e-6)
+    for t_, k in ((W, 'W'), (H, 'H'), (Z, 'Z')):
+        assert rel_err(t_, g[f'{name}_{k}']) < 5e-6
+    assert np.allclose(losses[1:], g[f'{name}_losses'], rtol=1e-5)

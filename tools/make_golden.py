@@ -18,6 +18,7 @@ Sets:
   g6_beta_div    metrics.beta_div known answers incl. zeros
   g8_convnd      NMF2D (1,4,20,18) r3 k=(3,4), (2,3,12,10) r2 k=(2,2); NMF3D (1,3,8,9,10) r2 k=(2,3,2): 20 iterations
   g9_sparse      NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}: factors, losses, n_iter
+  g10_plca       plca.PLCA.fit (EM, plca.py:244-304): plain / Dirichlet priors / frozen Z / frozen W
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
 import os
@@ -274,11 +275,41 @@ def g9():
     np.savez_compressed(os.path.join(OUT, 'g9_sparse.npz'), **out)
 
 
+def g10():
+    """PLCA (plca.py:311-373) fitted by the reference's EM loop (plca.py:193-304)."""
+    from torchnmf import plca as ref_plca
+    ref_plca.tqdm = _LossTap
+    g = torch.Generator().manual_seed(1010)
+    N, C, R = 50, 40, 4
+    V = torch.rand(N, C, generator=g)
+    W0 = torch.rand(C, R, generator=g)
+    H0 = torch.rand(N, R, generator=g)
+    Z0 = torch.rand(R, generator=g)
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy(), 'Z0': Z0.numpy()}
+    cases = {'plain': dict(), 'prior': dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01),
+             'frozenZ': dict(trainable_Z=False), 'frozenW': dict(trainable_W=False), 'stop': dict(tol=1e-3, max_iter=200)}
+    for name, kw in cases.items():
+        ctor = {k: v for k, v in kw.items() if k.startswith('trainable')}
+        fitkw = {k: v for k, v in kw.items() if not k.startswith('trainable')}
+        m = ref_plca.PLCA(W=W0.clone(), H=H0.clone(), Z=Z0.clone(), **ctor)
+        if name == 'plain':   # the constructor normalises its arguments (plca.py:91, 105, 121)
+            out['W_init'], out['H_init'], out['Z_init'] = m.W.data.numpy().copy(), m.H.data.numpy().copy(), m.Z.data.numpy().copy()
+            out['recon_init'] = m().detach().numpy().copy()
+        _LossTap.log = []
+        fitkw.setdefault('tol', NO_STOP)
+        fitkw.setdefault('max_iter', 30)
+        n, norm = m.fit(V, **fitkw)
+        out[f'{name}_W'], out[f'{name}_H'], out[f'{name}_Z'] = m.W.data.numpy().copy(), m.H.data.numpy().copy(), m.Z.data.numpy().copy()
+        out[f'{name}_n'], out[f'{name}_norm'] = np.int64(n), np.float64(float(norm))
+        out[f'{name}_losses'] = np.array(_LossTap.log, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g10_plca.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
