@@ -228,6 +228,8 @@ class DenseMU:
         N, Cc = V.shape
         R = W.shape[1]
         assert W.shape == (Cc, R) and H.shape == (N, R)
+        if V.stride(1) != 1 or V.dtype != torch.float32:     # nmfmu_pack_x reads rows with a row pitch only
+            V = V.float().contiguous()
         self.rank = R
         self.r_pad = self.be.pad_rank(R)
         if precision in (None, 'auto'):

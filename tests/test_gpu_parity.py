@@ -791,3 +791,21 @@ def test_plca_medium_against_oracle(dev, rank, prec):
     for p, ref in ((m.W, Wr), (m.H, Hr), (m.Z, Zr)):
         assert rel_err(p.data.cpu(), ref) < tol, rel_err(p.data.cpu(), ref)
     assert m.W.data.sum(0).cpu() == pytest.approx(torch.ones(rank).numpy(), rel=1e-4)
+
+
+def test_fit_accepts_strided_and_non_fp32_targets(dev):
+    """A transposed view, a row-strided slice and a float64 target give the same factors as their contiguous fp32 copy."""
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(4)
+    base = torch.rand(300, 210, generator=g)
+    W0, H0 = torch.rand(300, 12, generator=g), torch.rand(210, 12, generator=g)
+    Vt = base.t()                                    # (210, 300) view with stride(1) != 1
+    big = torch.rand(210, 640, generator=g)
+    views = {'transposed': (Vt.to(dev).t().t() if False else base.to(dev).t(), Vt.contiguous()),
+             'row_strided': (big.to(dev)[:, :300], big[:, :300].contiguous()),
+             'float64': (Vt.contiguous().double().to(dev), Vt.contiguous())}
+    for name, (v_dev, v_ref) in views.items():
+        m1, m2 = NMF(W=W0, H=H0).to(dev), NMF(W=W0, H=H0).to(dev)
+        m1.fit(v_dev, 1, NO_STOP, 5)
+        m2.fit(v_ref.to(dev), 1, NO_STOP, 5)
+        assert torch.equal(m1.W.data, m2.W.data) and torch.equal(m1.H.data, m2.H.data), name
