@@ -362,6 +362,9 @@ def main():
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.force_dist and 'RANK' not in os.environ:          # plain `python bench.py --force-dist`: a world of one
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+            os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', device_id=dev)   # RCCL
         group = dist.group.WORLD
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
@@ -436,7 +439,10 @@ def main():
     flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R     # 4 (6) contractions of 2NCR
     total_gflops = flops_per_iter_gpu * world / (ms_per_step * 1e-3) / 1e9
 
-    # ---- roofline leg: the same steps again, with hipEvents around every fused launch
+    # ---- roofline leg: the same K steps once more, right after the timed region, with hipEvents around every fused
+    # launch.  (Recording the events inside the timed region was measured: it costs 2 % of throughput and, with the
+    # queue saturated, folds the ~6 us dispatch gap in front of each kernel into its span -- W 0.193 / H 0.160 ms
+    # instead of 0.178 / 0.148 ms, the latter agreeing with the kernel-trace durations.)
     roof = None
     if not a.no_roofline:
         eng.timer = KernelTimer(4 * a.steps)
