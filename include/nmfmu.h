@@ -165,6 +165,10 @@ int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream
  * part: 1024 doubles of scratch. */
 int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double* part, double* out, void* stream);
 
+/* nmfmu_norms: out[0] = sum |x|, out[1] = sum x^2 over n fp32 elements (metrics.sparseness, metrics.py:99-115).
+ * part: 1024 doubles of scratch. */
+int nmfmu_norms(const float* x, int64_t n, double* part, double* out, void* stream);
+
 /* nmfmu_reconstruct: out[m][k] = sum_r owner[m][r] panel[k][r]  (NMF.reconstruct, nmf.py:691-693) computed from the
  * fp32 masters with fp32 MFMA; out is row-major [owner.rows][panel.rows], ld elements per row. */
 int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int rank, float* out, int64_t ld,

@@ -372,6 +372,32 @@ int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int k
   return (int)hipGetLastError();
 }
 
+// metrics.sparseness (metrics.py:99-115) needs ||x||_1 and ||x||_2: out[0] = sum |x|, out[1] = sum x^2
+__global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  __shared__ double red[2][4];
+  double a1 = 0.0, a2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = (double)x[i];
+    a1 += fabs(v), a2 += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a1 += __shfl_xor(a1, o, 64), a2 += __shfl_xor(a2, o, 64);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a1, red[1][threadIdx.x >> 6] = a2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[gridDim.x + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+int launch_norms(const float* x, int64_t n, double* part, double* out, hipStream_t s) {
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 512));   // part holds 2 * 512 doubles
+  hipLaunchKernelGGL(norms_kernel, dim3(grid), dim3(256), 0, s, x, n, part);
+  hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(1), dim3(256), 0, s, part, grid, out);
+  hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(1), dim3(256), 0, s, part + grid, grid, out + 1);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // reconstruct: out[m][k] = sum_r A[m][r] B[k][r], fp32 in / fp32 out (NMF.reconstruct, nmf.py:691-693).
 // Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  128x128 output tile per workgroup (4 waves, 64x64 = 2x2 MFMA tiles

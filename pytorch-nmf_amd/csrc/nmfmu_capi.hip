@@ -264,6 +264,11 @@ int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double
   return launch_beta_div(x, y, n, beta, nmfmu_beta_kind(beta), part, out, S(stream));
 }
 
+int nmfmu_norms(const float* x, int64_t n, double* part, double* out, void* stream) {
+  if (!x || !part || !out || n <= 0) return NMFMU_ERR_ARG;
+  return launch_norms(x, n, part, out, S(stream));
+}
+
 int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int rank, float* out, int64_t ld,
                       void* stream) {
   if (!owner || !panel || !out || m <= 0 || k <= 0 || rank <= 0 || ld < k) return NMFMU_ERR_ARG;

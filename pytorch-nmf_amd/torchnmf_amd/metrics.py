@@ -12,7 +12,7 @@ from torch import Tensor
 
 from . import _capi
 
-__all__ = ['kl_div', 'euclidean', 'is_div', 'beta_div']
+__all__ = ['kl_div', 'euclidean', 'is_div', 'beta_div', 'sparseness']
 
 
 def beta_div(input: Tensor, target: Tensor, beta: float = 2) -> Tensor:
@@ -43,3 +43,17 @@ def euclidean(input: Tensor, target: Tensor) -> Tensor:
 def is_div(input: Tensor, target: Tensor) -> Tensor:
     """Itakura-Saito divergence = beta_div(beta=0) (metrics.py:42-57)."""
     return beta_div(input, target, 0)
+
+
+def sparseness(x: Tensor) -> Tensor:
+    """Hoyer's sparseness measure ``(sqrt(N) - |x|_1 / |x|_2) / (sqrt(N) - 1)`` (metrics.py:99-115)."""
+    if x.device.type != 'cuda':
+        raise _capi.NmfmuError('sparseness: tensors must live on the ROCm device (no CPU fallback)')
+    lib = _capi.load()
+    xf = x.detach().float().contiguous().reshape(-1)
+    part = torch.empty(1024, dtype=torch.float64, device=x.device)
+    out = torch.zeros(2, dtype=torch.float64, device=x.device)
+    _capi.check(lib.nmfmu_norms(xf.data_ptr(), xf.numel(), part.data_ptr(), out.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream), 'nmfmu_norms')
+    n = xf.numel()
+    return ((n ** 0.5 - out[0] / out[1].sqrt()) / (n ** 0.5 - 1)).float()

@@ -809,3 +809,20 @@ def test_fit_accepts_strided_and_non_fp32_targets(dev):
         m1.fit(v_dev, 1, NO_STOP, 5)
         m2.fit(v_ref.to(dev), 1, NO_STOP, 5)
         assert torch.equal(m1.W.data, m2.W.data) and torch.equal(m1.H.data, m2.H.data), name
+
+
+@pytest.mark.parametrize('n', [1, 2, 1000, 70001])
+def test_metrics_sparseness(dev, n):
+    """metrics.sparseness (metrics.py:99-115): 0 for a constant vector, 1 for a one-hot one, the closed form between."""
+    from torchnmf_amd.metrics import sparseness
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    if n > 1:
+        want = (n ** 0.5 - x.norm(1) / x.norm(2)) / (n ** 0.5 - 1)
+        assert float(sparseness(x.to(dev))) == pytest.approx(float(want), rel=1e-5, abs=1e-6)
+        assert float(sparseness(torch.ones(n, device=dev))) == pytest.approx(0.0, abs=1e-5)
+        hot = torch.zeros(n, device=dev)
+        hot[n // 2] = 3.0
+        assert float(sparseness(hot)) == pytest.approx(1.0, abs=1e-6)
+        assert float(sparseness(x.reshape(-1, 1).repeat(1, 2).to(dev))) == pytest.approx(
+            float((( 2 * n) ** 0.5 - (x.norm(1) * 2) / (x.norm(2) * 2 ** 0.5)) / ((2 * n) ** 0.5 - 1)), rel=1e-5, abs=1e-6)
