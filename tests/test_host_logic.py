@@ -260,20 +260,29 @@ def test_betamu_argument_checks_and_unsupported_graphs(cpu_engine):
     assert rel_err(m2.W.data, W_ref) < 5e-6
 
 
-def test_fused_kernels_do_not_spill_to_scratch(tmp_path):
-    """Guard: every instantiation of the rank-128 fused kernel must keep its accumulators in registers
-    (a dynamically indexed register array silently moves to scratch memory and runs ~6x slower)."""
+@pytest.mark.parametrize('unit', ['nmfmu_inst_r128', 'nmfmu_inst_r256'])
+def test_fused_kernels_do_not_spill_to_scratch(tmp_path, unit):
+    """Guard: the fused kernels must keep their accumulators in registers.  A runtime-indexed register array silently
+    moves to scratch memory AND is kept up to date from inside the main loop: the padded-rank-256 kernels ran 3x slower
+    that way until their epilogue loops became compile-time (static_for).  Checked with the library's own flags for
+    every instantiation of the rank-128 unit and for every LDS-DMA (STAGE = 1, the product path) instantiation of the
+    rank-256 unit; its register-staged debug variants (STAGE = 0) are allowed their few spilled words."""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
-    src = os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', 'nmfmu_inst_r128.hip')
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Rpass-analysis=kernel-resource-usage',
-                        '-c', src, '-o', str(tmp_path / 'x.o')], capture_output=True, text=True)
+    src = os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', unit + '.hip')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-Wno-inline-asm',
+                        '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', str(tmp_path / 'x.o')],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = r.stderr.split('Function Name: ')[1:]
-    assert len(blocks) >= 32
+    assert len(blocks) >= 16
     for b in blocks:
         m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b)
+        k = re.search(r'fused_kernelILi(\d+)ELi(\d+)ELb(\d)ELi(\d)ELi(\d)ELi(\d)E', b.split('\n')[0])
+        if k and k.group(1) == '256' and k.group(5) == '0':
+            assert int(m.group(1)) <= 256, b.split('\n')[0]
+            continue
         assert m and int(m.group(1)) == 0, b.split('\n')[0]
