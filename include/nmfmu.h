@@ -298,6 +298,21 @@ int nmfmu_plca_normalize(float* f, int rows, int rank, int r_pad, const float* d
                          float* colsum_out, void* stream);
 int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* stream);
 
+/* ---- shift-invariant PLCA (SIPLCA / SIPLCA2 / SIPLCA3, plca.py:376-606) on the NMFD GEMM path ----------------------
+ * Same EM update as PLCA with W (C, R, *T), H (B, R, *Lh): factors are addressed [outer][rank][inner], the unscaled
+ * numerator as num[o * num_pitch + r * inner + i].
+ *   nmfmu_conv_pack_w_scaled : Wm / WmT planes of W * scale[r] (the reconstruction operand W * Z); W is not modified
+ *   nmfmu_convnd_fold        : out[b][r][j] = sum_t y[(r,t)][(b, j + t)]  (the fold of nmfmu_convnd_fold_apply_h alone)
+ *   nmfmu_plca3              : mode 0 em (vec = z_old), 1 normalize (vec = divider, alpha), 2 scale (vec = colsum);
+ *                              part: nmfmu_plca3_part_bytes(rank) of scratch */
+int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,
+                             void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
+int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, const float* y,
+                      int bl_pad, void* stream);
+size_t nmfmu_plca3_part_bytes(int rank);
+int nmfmu_plca3(int mode, float* f, int outer, int rank, int inner, const float* num, int64_t num_pitch, const float* vec,
+                float alpha, int update, float* part, float* colsum_out, float* zgrad_out, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */
 int nmfmu_timer_create(int n_events, void** timer);

@@ -424,7 +424,23 @@ def plca_norm(x: torch.Tensor) -> torch.Tensor:
 
 
 def plca_reconstruct(H, W, Z):
-    return H @ (W * Z).t()          # plca.py:371-373
+    """PLCA: H @ (W * Z).T (plca.py:371-373).  SIPLCA / SIPLCA2 / SIPLCA3: convNd(H, W.flip * Z) (plca.py:447-449,
+    522-525, 602-605) = the NMFD-family reconstruction with W scaled by Z along the rank axis."""
+    if W.dim() == 2:
+        return H @ (W * Z).t()
+    return convnd_reconstruct(H, W * Z.view(1, -1, *([1] * (W.dim() - 2))))
+
+
+def _plca_products(Vn, W, H, Z):
+    """(G^T H, G W) generalised: the gradients of the reconstruction w.r.t. W and H, WITHOUT the factor Z."""
+    G = Vn / (plca_reconstruct(H, W, Z) + EPS)
+    if W.dim() == 2:
+        return G.t() @ H, G @ W
+    return _convnd_grad_w(G, H, W), _convnd_grad_h(G, W, H)
+
+
+def _rank_view(Z, x):
+    return Z.view(1, -1, *([1] * (x.dim() - 2))) if x.dim() > 1 else Z
 
 
 def _plca_prior(x, alpha):
@@ -436,9 +452,9 @@ def _plca_prior(x, alpha):
 def plca_em_step(Vn, W, H, Z, W_alpha=1.0, H_alpha=1.0, Z_alpha=1.0, train=(True, True, True)):
     """One EM iteration (plca.py:248-290).  ``train`` = (W, H, Z) trainable flags."""
     tW, tH, tZ = train
-    G = Vn / (plca_reconstruct(H, W, Z) + EPS)
-    GtH, GW = G.t() @ H, G @ W
-    Wg, Hg, Zg = GtH * Z, GW * Z, (W * GtH).sum(0)
+    GtH, GW = _plca_products(Vn, W, H, Z)
+    Wg, Hg = GtH * _rank_view(Z, W), GW * _rank_view(Z, H)
+    Zg = (W * GtH).sum([d for d in range(W.dim()) if d != 1])
     z_prior = None
     if tZ:
         Z = Z * Zg.relu()
@@ -450,16 +466,16 @@ def plca_em_step(Vn, W, H, Z, W_alpha=1.0, H_alpha=1.0, Z_alpha=1.0, train=(True
         W = W * Wg.relu()
         if z_prior is None:
             div = plca_norm(W)
-            z_prior = div.squeeze()
+            z_prior = div.reshape(-1)
         else:
-            div = z_prior
+            div = _rank_view(z_prior, W)
         W = W / div
         if W_alpha != 1:
             W = _plca_prior(W, W_alpha)
             W = W / plca_norm(W)
     if tH:
         H = H * Hg.relu()
-        div = plca_norm(H) if z_prior is None else z_prior
+        div = plca_norm(H) if z_prior is None else _rank_view(z_prior, H)
         H = H / div
         if H_alpha != 1:
             H = _plca_prior(H, H_alpha)

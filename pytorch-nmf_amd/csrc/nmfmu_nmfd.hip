@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
                                                                 const float* __restrict__ kl_den, int c_pad, int rp_pad,
                                                                 float l1, float l2, float gamma, int update,
                                                                 uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
-                                                                uint16_t* wmt_lo) {
+                                                                uint16_t* wmt_lo, const float* __restrict__ scale) {
   constexpr int LDT = 65;
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
         v = mu_update(v, num[o], kl_den ? kl_den[kk / T] : den[o], kl_den != nullptr, l1, l2, gamma);
         W[wi] = v;
       }
+      if (scale) v *= scale[kk / T];   // planes of W * Z (shift-invariant PLCA); the master is not scaled
     }
     tile[cl * LDT + kl] = v;
   }
@@ -388,7 +389,8 @@ __global__ void __launch_bounds__(256) convnd_fold_apply_h_kernel(float* __restr
                                                                   const float* __restrict__ ynum,
                                                                   const float* __restrict__ yden,
                                                                   const float* __restrict__ kl_den, int bl_pad,
-                                                                  float l1, float l2, float gamma) {
+                                                                  float l1, float l2, float gamma,
+                                                                  float* __restrict__ fold_out) {
   const int64_t n = (int64_t)B * R * g.lh_tot;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int jf = (int)(i % g.lh_tot), br = (int)(i / g.lh_tot), r = br % R, b = br / R;
@@ -403,7 +405,8 @@ __global__ void __launch_bounds__(256) convnd_fold_apply_h_kernel(float* __restr
           neg += ynum[o];
           if (!kl_den) pos += yden[o];
         }
-    H[i] = mu_update(H[i], neg, kl_den ? kl_den[r] : pos, kl_den != nullptr, l1, l2, gamma);
+    if (fold_out) fold_out[i] = neg;   // fold only (shift-invariant PLCA applies its own update)
+    else H[i] = mu_update(H[i], neg, kl_den ? kl_den[r] : pos, kl_den != nullptr, l1, l2, gamma);
   }
 }
 
@@ -517,9 +520,9 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
   return (int)hipGetLastError();
 }
 
-int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
-                            const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
-                            void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+static int conv_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                       const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
+                       void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream) {
   if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
   if (update && (!num || (!den && !kl_den))) return NMFMU_ERR_ARG;
   if (c_pad < channels || rp_pad < (int64_t)rank * taps || c_pad % 64 || rp_pad % 64 || (wm_lo == nullptr) != (wmt_lo == nullptr))
@@ -528,12 +531,26 @@ int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const fl
   if (wm_lo)
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
-                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo);
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale);
   else
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
-                       nullptr);
+                       nullptr, scale);
   return (int)hipGetLastError();
+}
+
+int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                            const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
+                            void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+  return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
+                     wmt_lo, nullptr, stream);
+}
+
+int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,
+                             void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+  if (!scale) return NMFMU_ERR_ARG;
+  return conv_pack_w(w, channels, rank, taps, nullptr, nullptr, nullptr, c_pad, rp_pad, 0.f, 0.f, 1.f, 0, wm_hi, wm_lo, wmt_hi,
+                     wmt_lo, scale, stream);
 }
 
 int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
@@ -582,7 +599,18 @@ int nmfmu_convnd_fold_apply_h(float* h, int batch, int rank, int ndim, const int
   if (bl_pad < (int64_t)batch * g.l_tot) return NMFMU_ERR_ARG;
   const int64_t n = (int64_t)batch * rank * g.lh_tot;
   hipLaunchKernelGGL(convnd_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, g, y_num,
-                     y_den, kl_den, bl_pad, l1, l2, gamma);
+                     y_den, kl_den, bl_pad, l1, l2, gamma, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, const float* y,
+                      int bl_pad, void* stream) {
+  ConvGeom g;
+  if (!out || !y || batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g)) return NMFMU_ERR_ARG;
+  if (bl_pad < (int64_t)batch * g.l_tot) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * rank * g.lh_tot;
+  hipLaunchKernelGGL(convnd_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), out, batch, rank, g, y,
+                     (const float*)nullptr, y /* non-null: skips the den loop */, bl_pad, 0.f, 0.f, 1.f, out);
   return (int)hipGetLastError();
 }
 

@@ -66,6 +66,69 @@ __global__ void __launch_bounds__(256) plca_scale_kernel(float* __restrict__ f, 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) f[i] /= colsum[i % rank];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Shift-invariant PLCA (plca.py:376-606): W is (C, R, *T) and H is (B, R, *Lh) -- the rank axis sits in the middle, so
+// a factor is addressed as [outer][R][inner] (W: outer = C, inner = prod T; H: outer = B, inner = prod Lh) and the
+// unscaled numerator as num[o * num_pitch + r * inner + i] (W: a row of the [c_pad][rp_pad] GEMM output; H: the folded
+// [B][R][Lh] buffer).  Workgroup (r, chunk) walks its slice of the (outer x inner) index space of rank r; the chunk
+// partials are combined in order (deterministic).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPlca3Chunks = 64;
+
+template <int MODE>   // 0: em, 1: normalize, 2: scale
+__global__ void __launch_bounds__(256) plca3_kernel(float* __restrict__ f, int outer, int R, int inner,
+                                                    const float* __restrict__ num, int64_t num_pitch,
+                                                    const float* __restrict__ vec, float alpha, int update,
+                                                    float* __restrict__ part) {
+  __shared__ float red[2][256];
+  const int r = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const int64_t n = (int64_t)outer * inner;
+  const int64_t per = (n + kPlca3Chunks - 1) / kPlca3Chunks, e0 = ch * per, e1 = min(n, e0 + per);
+  const float v = vec[r];
+  float cs = 0.f, zg = 0.f;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const int64_t o = e / inner, i = e - o * inner;
+    const size_t idx = ((size_t)o * R + r) * inner + i;
+    float x = f[idx];
+    if constexpr (MODE == 0) {
+      const float nv = num[(size_t)o * num_pitch + (size_t)r * inner + i];
+      zg += x * nv;
+      x *= fmaxf(nv * v, 0.f);
+    } else if constexpr (MODE == 1) {
+      x /= v;
+      if (alpha != 1.f) {
+        x += alpha - 1.f;
+        x = x > kEps ? x : kEps;
+      }
+    } else {
+      x /= v;
+    }
+    if (update) f[idx] = x;
+    cs += x;
+  }
+  red[0][tid] = cs;
+  red[1][tid] = zg;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[0][tid] += red[0][tid + o], red[1][tid] += red[1][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && part) {
+    part[((size_t)r * kPlca3Chunks + ch) * 2] = red[0][0];
+    part[((size_t)r * kPlca3Chunks + ch) * 2 + 1] = red[1][0];
+  }
+}
+
+__global__ void __launch_bounds__(64) plca3_final_kernel(const float* __restrict__ part, int R, float* __restrict__ cs_out,
+                                                         float* __restrict__ zg_out) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= R) return;
+  float cs = 0.f, zg = 0.f;
+  for (int ch = 0; ch < kPlca3Chunks; ++ch) cs += part[((size_t)r * kPlca3Chunks + ch) * 2], zg += part[((size_t)r * kPlca3Chunks + ch) * 2 + 1];
+  cs_out[r] = cs;
+  if (zg_out) zg_out[r] = zg;
+}
+
 }  // namespace nmfmu
 
 using namespace nmfmu;
@@ -108,6 +171,28 @@ int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* st
   const int64_t n = (int64_t)rows * rank;
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(plca_scale_kernel, dim3(grid), dim3(256), 0, S(stream), f, n, rank, colsum);
+  return (int)hipGetLastError();
+}
+
+size_t nmfmu_plca3_part_bytes(int rank) { return rank > 0 ? (size_t)rank * kPlca3Chunks * 2 * 4 : 0; }
+
+/* mode 0: em (num, z_old), 1: normalize (divider, alpha), 2: scale (colsum) -- see nmfmu_plca_* for the semantics */
+int nmfmu_plca3(int mode, float* f, int outer, int rank, int inner, const float* num, int64_t num_pitch, const float* vec,
+                float alpha, int update, float* part, float* colsum_out, float* zgrad_out, void* stream) {
+  if (!f || !vec || outer <= 0 || rank <= 0 || inner <= 0 || mode < 0 || mode > 2) return NMFMU_ERR_ARG;
+  if (mode == 0 && (!num || num_pitch < (int64_t)rank * inner)) return NMFMU_ERR_ARG;
+  if (mode != 2 && (!part || !colsum_out)) return NMFMU_ERR_ARG;
+  const dim3 grid(rank, kPlca3Chunks);
+  if (mode == 0)
+    hipLaunchKernelGGL(plca3_kernel<0>, grid, dim3(256), 0, S(stream), f, outer, rank, inner, num, num_pitch, vec, 1.f, update, part);
+  else if (mode == 1)
+    hipLaunchKernelGGL(plca3_kernel<1>, grid, dim3(256), 0, S(stream), f, outer, rank, inner, nullptr, (int64_t)0, vec, alpha, 1, part);
+  else
+    hipLaunchKernelGGL(plca3_kernel<2>, grid, dim3(256), 0, S(stream), f, outer, rank, inner, nullptr, (int64_t)0, vec, 1.f, 1,
+                       (float*)nullptr);
+  if (mode != 2)
+    hipLaunchKernelGGL(plca3_final_kernel, dim3((rank + 63) / 64), dim3(64), 0, S(stream), part, rank, colsum_out,
+                       mode == 0 ? zgrad_out : nullptr);
   return (int)hipGetLastError();
 }
 

@@ -111,6 +111,13 @@ SIGNATURES = {
     'nmfmu_plca_normalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     'nmfmu_plca_scale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_pack_w_scaled': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_convnd_fold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
+    'nmfmu_plca3_part_bytes': (C.c_size_t, [C.c_int]),
+    'nmfmu_plca3': (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),

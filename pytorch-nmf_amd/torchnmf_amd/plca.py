@@ -7,7 +7,8 @@ GEMM only.  Both contractions run on ``nmfmu::fused_kernel`` (through ``nmfmu_mu
 the Z-scaled factor for the reconstruction, image of the unscaled factor for the second GEMM); the O((N + C) R)
 remainder of plca.py:248-290 (multiply by relu(grad), divide by the latent prior, Dirichlet prior, renormalise) runs in
 the small ``nmfmu_plca_*`` kernels, and only the R-element latent vector is updated with torch scalar ops.
-``SIPLCA*`` (the shift-invariant variants) are not implemented.
+``SIPLCA`` / ``SIPLCA2`` / ``SIPLCA3`` (plca.py:376-606) are to PLCA what NMFD / NMF2D / NMF3D are to NMF: the same EM
+update on the NMFD GEMM engine (``_ConvPlcaEM``), with W * Z as the reconstruction operand.
 """
 from collections.abc import Iterable
 from typing import Optional
@@ -20,7 +21,7 @@ from .constants import eps as _EPS
 from .engine import DEFAULT_BACKEND_FACTORY, FactorBuf, StepBuf, _ptr
 from .nmf import _require_device
 
-__all__ = ['PLCA', 'BaseComponent']
+__all__ = ['PLCA', 'SIPLCA', 'SIPLCA2', 'SIPLCA3', 'BaseComponent']
 
 
 def get_norm(x: Tensor) -> Tensor:
@@ -103,8 +104,50 @@ class BaseComponent(nn.Module):
     def reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
         raise NotImplementedError
 
-    def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
+    def _make_em(self, Vn, precision):
         raise NotImplementedError
+
+    @torch.no_grad()
+    def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
+        """EM fit (plca.py:193-304).  Returns ``(n_iter, norm)`` like the reference: the index of the last iteration and
+        ``V.sum()``.  Scalar Dirichlet hyper-parameters only."""
+        W, H, Z = self.W, self.H, self.Z
+        assert W is not None and H is not None and Z is not None
+        for t_, what in ((V, 'fit'), (W, 'fit'), (H, 'fit'), (Z, 'fit')):
+            _require_device(t_, what)
+        for a in (W_alpha, H_alpha, Z_alpha):
+            if isinstance(a, Tensor):
+                raise NotImplementedError('tensor-valued Dirichlet hyper-parameters are not implemented')
+        V = V.detach().float()
+        assert bool(torch.all(V >= 0.)), "Target should be non-negative."
+        norm = V.sum()
+        Vn = (V.contiguous() / norm).contiguous()
+        for p in (W, H, Z):
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+        em = self._make_em(Vn, precision)
+        nrm = float(norm.item())
+        loss_init = previous = (2.0 * nrm * em.divergence()) ** 0.5      # kl_div(WZH * norm, V), plca.py:245-246
+        pbar = None
+        if verbose:
+            from tqdm import tqdm
+            pbar = tqdm(total=max_iter)
+        n_iter = -1
+        try:
+            for n_iter in range(max_iter):
+                em.em_step(W.requires_grad, H.requires_grad, Z.requires_grad, W_alpha, H_alpha, Z_alpha)
+                if n_iter % 10 == 9:
+                    loss = (2.0 * nrm * em.divergence()) ** 0.5
+                    if pbar is not None:
+                        pbar.set_postfix(loss=loss)
+                        pbar.update(10)
+                    if (previous - loss) / loss_init < tol:
+                        break
+                    previous = loss
+        finally:
+            if pbar is not None:
+                pbar.close()
+        return n_iter, norm
 
 
 class _PlcaEM:
@@ -236,45 +279,150 @@ class PLCA(BaseComponent):
         from .nmf import NMF
         return NMF.reconstruct(H, W.detach() * Z.detach())
 
-    @torch.no_grad()
-    def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
-        """EM fit (plca.py:193-304).  Returns ``(n_iter, norm)`` like the reference: the index of the last iteration and
-        ``V.sum()``.  Scalar Dirichlet hyper-parameters only."""
-        W, H, Z = self.W, self.H, self.Z
-        assert W is not None and H is not None and Z is not None
-        for t_, what in ((V, 'fit'), (W, 'fit'), (H, 'fit'), (Z, 'fit')):
-            _require_device(t_, what)
-        for a in (W_alpha, H_alpha, Z_alpha):
-            if isinstance(a, Tensor):
-                raise NotImplementedError('tensor-valued Dirichlet hyper-parameters are not implemented')
-        V = V.detach().float()
-        assert bool(torch.all(V >= 0.)), "Target should be non-negative."
-        assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0])
-        norm = V.sum()
-        Vn = (V.contiguous() / norm).contiguous()
-        for p in (W, H, Z):
-            if not p.data.is_contiguous():
-                p.data = p.data.contiguous()
-        em = _PlcaEM(Vn, W.data, H.data, Z.data, precision)
-        nrm = float(norm.item())
-        loss_init = previous = (2.0 * nrm * em.divergence()) ** 0.5      # kl_div(WZH * norm, V), plca.py:245-246
-        pbar = None
-        if verbose:
-            from tqdm import tqdm
-            pbar = tqdm(total=max_iter)
-        n_iter = -1
-        try:
-            for n_iter in range(max_iter):
-                em.em_step(W.requires_grad, H.requires_grad, Z.requires_grad, W_alpha, H_alpha, Z_alpha)
-                if n_iter % 10 == 9:
-                    loss = (2.0 * nrm * em.divergence()) ** 0.5
-                    if pbar is not None:
-                        pbar.set_postfix(loss=loss)
-                        pbar.update(10)
-                    if (previous - loss) / loss_init < tol:
-                        break
-                    previous = loss
-        finally:
-            if pbar is not None:
-                pbar.close()
-        return n_iter, norm
+    def _make_em(self, Vn, precision):
+        assert Vn.dim() == 2 and Vn.shape == (self.H.shape[0], self.W.shape[0])
+        return _PlcaEM(Vn, self.W.data, self.H.data, self.Z.data, precision)
+
+
+class _ConvPlcaEM:
+    """EM state of a shift-invariant PLCA fit on the NMFD GEMM engine (``ConvMU`` supplies the packed targets, the
+    Toeplitz operands of H and the GEMM plumbing).  Per iteration: W * Z planes -> reconstruction + ratio GEMMs ->
+    unscaled numerators (G2; G4 + fold) -> the ``nmfmu_plca3`` update kernels (plca.py:248-290)."""
+
+    def __init__(self, Vn, W, H, Z, precision):
+        from .nmfd_engine import ConvMU, _Planes
+        import ctypes as C
+        self.C = C
+        self.eng = e = ConvMU(Vn, W, H, 1.0, precision=precision)
+        self.lib = e.lib
+        self.W, self.H, self.Z = W, H, Z
+        x3 = e.precision == _capi.PREC_BF16X3
+        dev = Vn.device
+        self.wm_s = _Planes(e.c_pad, e.rp_pad, x3, dev)      # W * Z, [c][(r,t)]: the reconstruction operand
+        self.wmt_s = _Planes(e.rp_pad, e.c_pad, x3, dev)     # (written alongside, unused)
+        self.numh = torch.empty(e.B * e.R * e.Lh, dtype=torch.float32, device=dev)
+        self.part = torch.empty(max(self.lib.nmfmu_plca3_part_bytes(e.R) // 4, 4), dtype=torch.float32, device=dev)
+        self.cs = torch.zeros(e.R, dtype=torch.float32, device=dev)
+        self.cs2 = torch.zeros(e.R, dtype=torch.float32, device=dev)
+        self.zg = torch.zeros(e.R, dtype=torch.float32, device=dev)
+        self.div = torch.ones(e.R, dtype=torch.float32, device=dev)
+        self.repack()
+
+    @staticmethod
+    def _s():
+        return torch.cuda.current_stream().cuda_stream
+
+    def repack(self):
+        e = self.eng
+        e.refresh_images()                                   # unscaled Wm / WmT planes, H operands, rank sums
+        _capi.check(self.lib.nmfmu_conv_pack_w_scaled(self.W.data_ptr(), e.C, e.R, e.T, self.Z.data_ptr(), e.c_pad,
+                                                      e.rp_pad, _ptr(self.wm_s.hi), _ptr(self.wm_s.lo),
+                                                      _ptr(self.wmt_s.hi), _ptr(self.wmt_s.lo), self._s()),
+                    'nmfmu_conv_pack_w_scaled')
+
+    def divergence(self) -> float:
+        e = self.eng
+        e._gemm(self.wm_s, e.hu, _capi.EPI_LOSS, x=e.x_w, out=e.loss_part, m_valid=e.C, n_valid=e.B * e.L)
+        return float(e.loss_part.double().sum().item())
+
+    def _plca3(self, mode, f, outer, inner, num, pitch, vec, alpha, update, want_zg):
+        e = self.eng
+        _capi.check(self.lib.nmfmu_plca3(mode, f.data_ptr(), outer, e.R, inner, _ptr(num), pitch, vec.data_ptr(),
+                                         float(alpha), int(update), self.part.data_ptr(),
+                                         (self.cs if mode == 0 else self.cs2).data_ptr(),
+                                         self.zg.data_ptr() if want_zg else None, self._s()), 'nmfmu_plca3')
+
+    def _factor_update(self, f, outer, inner, num, pitch, z_old, trainable, alpha, z_prior):
+        if not trainable:
+            return z_prior
+        self._plca3(0, f, outer, inner, num, pitch, z_old, 1.0, True, False)
+        if z_prior is None:
+            z_prior = self.cs.clone()
+        self.div.copy_(z_prior)
+        self._plca3(1, f, outer, inner, None, 0, self.div, alpha, True, False)
+        if alpha != 1:
+            self._plca3(2, f, outer, inner, None, 0, self.cs2, 1.0, True, False)
+        return z_prior
+
+    def em_step(self, tW, tH, tZ, W_alpha, H_alpha, Z_alpha):
+        e = self.eng
+        # one reconstruction (twice, once per output layout) feeds every update of the iteration
+        e._gemm(self.wm_s, e.hu, _capi.EPI_RATIO, x=e.x_w, gn=e.gn)            # Gn [c][(b,l)]
+        e._gemm(e.gn, e.hut, _capi.EPI_F32, out=e.num_w)                        # (G^T H) [c][(r,t)], unscaled
+        e._gemm(e.hu, self.wm_s, _capi.EPI_RATIO, x=e.x_h, gn=e.gnt)           # Gn [(b,l)][c]
+        e._gemm(e.wmt, e.gnt, _capi.EPI_F32, out=e.y)                           # Y [(r,t)][(b,l)] from the unscaled W
+        _capi.check(self.lib.nmfmu_convnd_fold(self.numh.data_ptr(), e.B, e.R, e.nd, e._lh_arr, e._t_arr, e.y.data_ptr(),
+                                               e.bl_pad, self._s()), 'nmfmu_convnd_fold')
+        z_old = self.Z.clone()
+        # Z.grad = sum W * (G^T H): the em pass over W with update = 0
+        self._plca3(0, self.W, e.C, e.T, e.num_w, e.rp_pad, z_old, 1.0, False, True)
+        z_prior = None
+        if tZ:
+            z1 = self.Z * self.zg.relu()
+            z_prior = z1.clone()
+            if Z_alpha != 1:
+                z1 = z1 + (Z_alpha - 1)
+                z1 = torch.where(z1 > _EPS, z1, torch.full_like(z1, _EPS))
+            self.Z.copy_(z1 / z1.sum())
+        z_prior = self._factor_update(self.W, e.C, e.T, e.num_w, e.rp_pad, z_old, tW, W_alpha, z_prior)
+        self._factor_update(self.H, e.B, e.Lh, self.numh, e.R * e.Lh, z_old, tH, H_alpha, z_prior)
+        self.repack()
+
+
+def _conv_reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
+    from .nmfd_engine import reconstruct
+    return reconstruct(H, W.detach() * Z.detach().view(1, -1, *([1] * (W.dim() - 2))))
+
+
+class _ShiftInvariant(BaseComponent):
+    def _make_em(self, Vn, precision):
+        assert Vn.dim() == self.W.dim() and Vn.shape[0] == self.H.shape[0] and Vn.shape[1] == self.W.shape[0]
+        return _ConvPlcaEM(Vn, self.W.data, self.H.data, self.Z.data, precision)
+
+    @staticmethod
+    def reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
+        """``convNd(H, W.flip * Z, padding = T - 1)`` (plca.py:447-449, 522-525, 602-605)."""
+        return _conv_reconstruct(H, W, Z)
+
+
+def _ntuple(x, n):
+    return tuple(x) if isinstance(x, Iterable) else (x,) * n
+
+
+class SIPLCA(_ShiftInvariant):
+    """Shift-invariant PLCA, V (B, C, L), W (C, R, T), H (B, R, L - T + 1) (reference: plca.py:376-449)."""
+
+    def __init__(self, Vshape=None, rank=None, T=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            T, = _ntuple(T, 1)
+            batch, K, M = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (K, rank, T)
+            kwargs['H'] = (batch, rank, M - T + 1)
+        super().__init__(rank, **kwargs)
+
+
+class SIPLCA2(_ShiftInvariant):
+    """2-D shift-invariant PLCA (reference: plca.py:452-525)."""
+
+    def __init__(self, Vshape=None, rank=None, kernel_size=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            ks = _ntuple(kernel_size, 2)
+            batch, channel, K, M = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (channel, rank) + ks
+            kwargs['H'] = (batch, rank, K - ks[0] + 1, M - ks[1] + 1)
+        super().__init__(rank, **kwargs)
+
+
+class SIPLCA3(_ShiftInvariant):
+    """3-D shift-invariant PLCA (reference: plca.py:528-605)."""
+
+    def __init__(self, Vshape=None, rank=None, kernel_size=1, **kwargs):
+        if isinstance(Vshape, Iterable):
+            ks = _ntuple(kernel_size, 3)
+            batch, channel, N, K, M = Vshape
+            rank = rank if rank else K
+            kwargs['W'] = (channel, rank) + ks
+            kwargs['H'] = (batch, rank, N - ks[0] + 1, K - ks[1] + 1, M - ks[2] + 1)
+        super().__init__(rank, **kwargs)

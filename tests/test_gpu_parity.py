@@ -826,3 +826,34 @@ def test_metrics_sparseness(dev, n):
         assert float(sparseness(hot)) == pytest.approx(1.0, abs=1e-6)
         assert float(sparseness(x.reshape(-1, 1).repeat(1, 2).to(dev))) == pytest.approx(
             float((( 2 * n) ** 0.5 - (x.norm(1) * 2) / (x.norm(2) * 2 ** 0.5)) / ((2 * n) ** 0.5 - 1)), rel=1e-5, abs=1e-6)
+
+
+@pytest.mark.parametrize('name,cls', [('1d', 'SIPLCA'), ('2d', 'SIPLCA2'), ('3d', 'SIPLCA3')])
+@pytest.mark.parametrize('case,ctor,fitkw', [('plain', {}, {}), ('prior', {}, dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01)),
+                                             ('frozenZ', dict(trainable_Z=False), {})])
+def test_siplca_fit_g11_golden(dev, name, cls, case, ctor, fitkw):
+    """Shift-invariant PLCA (plca.py:376-606) against the reference's outputs."""
+    from torchnmf_amd import plca
+    g = load_golden('g11_siplca')
+    m = getattr(plca, cls)(W=t(g[f'{name}_W0']), H=t(g[f'{name}_H0']), Z=t(g[f'{name}_Z0']), **ctor).to(dev)
+    if case == 'plain':
+        assert rel_err(m().cpu(), g[f'{name}_recon_init']) < 1e-5
+    n, norm = m.fit(t(g[f'{name}_V']).to(dev), tol=NO_STOP, max_iter=20, **fitkw)
+    assert n == int(g[f'{name}_{case}_n']) and float(norm) == pytest.approx(float(g[f'{name}_{case}_norm']), rel=1e-5)
+    for p, k in ((m.W, 'W'), (m.H, 'H'), (m.Z, 'Z')):
+        assert rel_err(p.data.cpu(), g[f'{name}_{case}_{k}']) < TOL, (k, rel_err(p.data.cpu(), g[f'{name}_{case}_{k}']))
+
+
+def test_siplca_implicit_operands_against_oracle(dev):
+    """Taps and frames that are multiples of 8: the reconstruction operand comes from the window tables of H."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.plca import SIPLCA
+    g = torch.Generator().manual_seed(88)
+    V = torch.rand(2, 70, 304, generator=g)
+    W0, H0, Z0 = torch.rand(70, 5, 16, generator=g), torch.rand(2, 5, 289, generator=g), torch.rand(5, generator=g)
+    m = SIPLCA(W=W0, H=H0, Z=Z0).to(dev)
+    n, _ = m.fit(V.to(dev), tol=NO_STOP, max_iter=4, H_alpha=1.001)
+    Wr, Hr, Zr, nr, _, _ = O.plca_fit(V, W0, H0, Z0, tol=NO_STOP, max_iter=4, H_alpha=1.001)
+    assert n == nr
+    for p, ref in ((m.W, Wr), (m.H, Hr), (m.Z, Zr)):
+        assert rel_err(p.data.cpu(), ref) < TOL

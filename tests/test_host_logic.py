@@ -201,6 +201,18 @@ def test_plca_constructor_rules():
         m()
 
 
+def test_siplca_constructors():
+    """plca.py:430-445, 505-520, 585-600: the docstring shapes and the rank default."""
+    from torchnmf_amd.plca import SIPLCA, SIPLCA2, SIPLCA3
+    m = SIPLCA((1, 33, 50), 16, 3)
+    assert tuple(m.W.shape) == (33, 16, 3) and tuple(m.H.shape) == (1, 16, 48) and tuple(m.Z.shape) == (16,)
+    assert torch.allclose(m.W.sum((0, 2)), torch.ones(16)) and torch.allclose(m.H.sum((0, 2)), torch.ones(16))
+    m = SIPLCA2((1, 3, 14, 12), 2, (2, 3))
+    assert tuple(m.W.shape) == (3, 2, 2, 3) and tuple(m.H.shape) == (1, 2, 13, 10) and m.kernel_size == (2, 3)
+    m = SIPLCA3((1, 2, 6, 7, 8), kernel_size=2)
+    assert tuple(m.W.shape) == (2, 7, 2, 2, 2) and m.rank == 7 and tuple(m.H.shape) == (1, 7, 5, 6, 7)
+
+
 # ---- trainer.BetaMu host logic on the stand-in backend --------------------------------------------------------
 @pytest.mark.parametrize('case', ['b1_plain_both', 'b0.5_pen_both', 'b2_plain_W', 'b3_plain_H', 'b-1_pen_both'])
 def test_betamu_step_matches_reference(cpu_engine, case):

@@ -253,3 +253,17 @@ def test_g10_plca_oracle(name):
     for t_, k in ((W, 'W'), (H, 'H'), (Z, 'Z')):
         assert rel_err(t_, g[f'{name}_{k}']) < 5e-6
     assert np.allclose(losses[1:], g[f'{name}_losses'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['1d', '2d', '3d'])
+@pytest.mark.parametrize('case', ['plain', 'prior', 'frozenZ'])
+def test_g11_siplca_oracle(name, case):
+    """SIPLCA / SIPLCA2 / SIPLCA3 (plca.py:376-606): the PLCA EM step on the convNd reconstruction."""
+    g = load_golden('g11_siplca')
+    V, W0, H0, Z0 = (torch.from_numpy(g[f'{name}_{k}']) for k in ('V', 'W0', 'H0', 'Z0'))
+    kw = {'plain': {}, 'prior': dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01), 'frozenZ': dict(train=(True, True, False))}[case]
+    W, H, Z, n, norm, losses = O.plca_fit(V, W0, H0, Z0, tol=NO_STOP, max_iter=20, **kw)
+    assert n == int(g[f'{name}_{case}_n'])
+    for t_, k in ((W, 'W'), (H, 'H'), (Z, 'Z')):
+        assert rel_err(t_, g[f'{name}_{case}_{k}']) < 1e-5
+    assert np.allclose(losses[1:], g[f'{name}_{case}_losses'], rtol=1e-5)

@@ -18,6 +18,7 @@ Sets:
   g6_beta_div    metrics.beta_div known answers incl. zeros
   g8_convnd      NMF2D (1,4,20,18) r3 k=(3,4), (2,3,12,10) r2 k=(2,2); NMF3D (1,3,8,9,10) r2 k=(2,3,2): 20 iterations
   g9_sparse      NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}: factors, losses, n_iter
+  g11_siplca     plca.SIPLCA / SIPLCA2 / SIPLCA3 (shift-invariant PLCA, plca.py:376-606): plain / priors / frozen Z
   g10_plca       plca.PLCA.fit (EM, plca.py:244-304): plain / Dirichlet priors / frozen Z / frozen W
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
@@ -305,11 +306,40 @@ def g10():
     np.savez_compressed(os.path.join(OUT, 'g10_plca.npz'), **out)
 
 
+def g11():
+    """SIPLCA, SIPLCA2, SIPLCA3 fitted by the same EM loop (plca.py:193-304) with convNd reconstructions."""
+    from torchnmf import plca as ref_plca
+    ref_plca.tqdm = _LossTap
+    out = {}
+    shapes = {'1d': (ref_plca.SIPLCA, (2, 20, 60), 3, (4,)), '2d': (ref_plca.SIPLCA2, (1, 3, 14, 12), 2, (2, 3)),
+              '3d': (ref_plca.SIPLCA3, (1, 2, 6, 7, 8), 2, (2, 2, 3))}
+    cases = {'plain': ({}, {}), 'prior': ({}, dict(W_alpha=1.02, H_alpha=0.99, Z_alpha=1.01)),
+             'frozenZ': (dict(trainable_Z=False), {})}
+    for name, (cls, vshape, R, ks) in shapes.items():
+        g = torch.Generator().manual_seed(1011 + len(vshape))
+        V = torch.rand(*vshape, generator=g)
+        W0 = torch.rand(vshape[1], R, *ks, generator=g)
+        H0 = torch.rand(vshape[0], R, *[l - k + 1 for l, k in zip(vshape[2:], ks)], generator=g)
+        Z0 = torch.rand(R, generator=g)
+        out[f'{name}_V'], out[f'{name}_W0'], out[f'{name}_H0'], out[f'{name}_Z0'] = V.numpy(), W0.numpy(), H0.numpy(), Z0.numpy()
+        for cname, (ctor, fitkw) in cases.items():
+            m = cls(W=W0.clone(), H=H0.clone(), Z=Z0.clone(), **ctor)
+            if cname == 'plain':
+                out[f'{name}_recon_init'] = m().detach().numpy().copy()
+            _LossTap.log = []
+            n, norm = m.fit(V, tol=NO_STOP, max_iter=20, **fitkw)
+            key = f'{name}_{cname}'
+            out[f'{key}_W'], out[f'{key}_H'], out[f'{key}_Z'] = m.W.data.numpy().copy(), m.H.data.numpy().copy(), m.Z.data.numpy().copy()
+            out[f'{key}_n'], out[f'{key}_norm'] = np.int64(n), np.float64(float(norm))
+            out[f'{key}_losses'] = np.array(_LossTap.log, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g11_siplca.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
