@@ -16,7 +16,7 @@
 
 namespace nmfmu {
 
-constexpr int kPlcaRows = 32;   // factor rows per workgroup
+constexpr int kPlcaRows = 32;   // factor rows per workgroup (128 measured slower: too few workgroups for the short factor)
 
 // threads: column r = tid % r_pad, row group g = tid / r_pad (256 / r_pad groups); rows g, g + groups, ... of the block
 template <int MODE>   // 0: em, 1: normalize

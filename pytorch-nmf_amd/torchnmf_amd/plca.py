@@ -212,48 +212,50 @@ class _PlcaEM:
         self.be.loss(self.step_l, self.loss_part, self.loss_out)
         return float(self.loss_out.item())
 
-    def _factor_update(self, f, st, z_old, trainable, alpha, z_prior, want_zgrad):
-        """plca.py:262-289 for one factor; returns the latent prior to use for the next factor."""
-        rows = f.shape[0]
-        _capi.check(self.lib.nmfmu_plca_em(f.data_ptr(), rows, self.R, self.r_pad, st.slab_num.data_ptr(), st.nsplit,
-                                           st.owner.rows_pad, z_old.data_ptr(), int(trainable), self.part.data_ptr(),
+    def _em(self, f, st, z_old, update, want_zgrad):
+        """f *= relu(num * z_old) (when ``update``); column sums of the result -> self.cs; Z.grad partials -> self.zg."""
+        _capi.check(self.lib.nmfmu_plca_em(f.data_ptr(), f.shape[0], self.R, self.r_pad, st.slab_num.data_ptr(), st.nsplit,
+                                           st.owner.rows_pad, z_old.data_ptr(), int(update), self.part.data_ptr(),
                                            self.cs.data_ptr(), self.zg.data_ptr() if want_zgrad else None, self._s()),
                     'nmfmu_plca_em')
-        if not trainable:
-            return z_prior
+
+    def _normalize(self, f, alpha, z_prior):
+        """plca.py:265-275 / 279-289 after the multiplication; returns the latent prior for the next factor."""
         if z_prior is None:
-            z_prior = self.cs[:self.R].clone()          # get_norm of the multiplied factor (plca.py:265-266, 279)
+            z_prior = self.cs[:self.R].clone()          # get_norm of the multiplied factor
         self.div[:self.R] = z_prior
-        _capi.check(self.lib.nmfmu_plca_normalize(f.data_ptr(), rows, self.R, self.r_pad, self.div.data_ptr(), float(alpha),
-                                                  self.part.data_ptr(), self.cs2.data_ptr(), self._s()),
+        _capi.check(self.lib.nmfmu_plca_normalize(f.data_ptr(), f.shape[0], self.R, self.r_pad, self.div.data_ptr(),
+                                                  float(alpha), self.part.data_ptr(), self.cs2.data_ptr(), self._s()),
                     'nmfmu_plca_normalize')
         if alpha != 1:
-            _capi.check(self.lib.nmfmu_plca_scale(f.data_ptr(), rows, self.R, self.cs2.data_ptr(), self._s()),
+            _capi.check(self.lib.nmfmu_plca_scale(f.data_ptr(), f.shape[0], self.R, self.cs2.data_ptr(), self._s()),
                         'nmfmu_plca_scale')
         return z_prior
 
     def em_step(self, tW, tH, tZ, W_alpha, H_alpha, Z_alpha):
         """One EM iteration (plca.py:248-290): every update uses the gradients of ONE reconstruction."""
-        eps = _EPS
         self.be.mu_partial(self.step_w)
         self.be.mu_partial(self.step_h)
         z_old = self.zpad.clone()
-        # W first on the device (its pass also yields Z.grad), but Z's new value must be known before W is divided
-        # by the latent prior: plca_em only multiplies, the division happens in _factor_update's second kernel.
-        _capi.check(self.lib.nmfmu_plca_em(self.W.data_ptr(), self.W.shape[0], self.R, self.r_pad,
-                                           self.step_w.slab_num.data_ptr(), self.step_w.nsplit, self.fW.rows_pad,
-                                           z_old.data_ptr(), 0, self.part.data_ptr(), self.cs.data_ptr(),
-                                           self.zg.data_ptr(), self._s()), 'nmfmu_plca_em')
+        # W's multiplication pass also yields Z.grad = sum W_old * (G^T H); the division by the latent prior, which needs
+        # the new Z first (plca.py:253-270), is the separate normalize kernel
+        self._em(self.W.data, self.step_w, z_old, tW, True)
+        cs_w = self.cs[:self.R].clone() if tW else None
         z_prior = None
         if tZ:                                          # plca.py:253-260
             z1 = self.Z.data * self.zg[:self.R].relu()
             z_prior = z1.clone()
             if Z_alpha != 1:
                 z1 = z1 + (Z_alpha - 1)
-                z1 = torch.where(z1 > eps, z1, torch.full_like(z1, eps))
+                z1 = torch.where(z1 > _EPS, z1, torch.full_like(z1, _EPS))
             self.Z.data.copy_(z1 / z1.sum())
-        z_prior = self._factor_update(self.W.data, self.step_w, z_old, tW, W_alpha, z_prior, False)
-        self._factor_update(self.H.data, self.step_h, z_old, tH, H_alpha, z_prior, False)
+        if tW:
+            if z_prior is None:
+                z_prior = cs_w
+            z_prior = self._normalize(self.W.data, W_alpha, z_prior)
+        if tH:
+            self._em(self.H.data, self.step_h, z_old, True, False)
+            self._normalize(self.H.data, H_alpha, z_prior)
         self.repack()
 
 
