@@ -125,6 +125,9 @@ class BaseComponent(nn.Module):
         _require_device(V, 'fit')
         _require_device(W, 'fit')
         _require_device(H, 'fit')
+        if W.dtype != torch.float32 or H.dtype != torch.float32:
+            raise NotImplementedError('factors must be float32 (the engine keeps fp32 masters and bf16 operand images); '
+                                      f'got W {W.dtype}, H {H.dtype}')
         if precision is None:
             precision = os.environ.get('TORCHNMF_AMD_PRECISION', 'auto')
         beta = float(beta)

@@ -349,6 +349,13 @@ def test_fit_smoke_like_reference(dev, beta, tol, alpha, l1_ratio):
     assert not torch.any(torch.isnan(m.W)) and not torch.any(torch.isnan(m.H))
 
 
+def test_fit_rejects_non_fp32_factors(dev):
+    from torchnmf_amd.nmf import NMF
+    m = NMF((20, 30), 4).double().to(dev)
+    with pytest.raises(NotImplementedError):
+        m.fit(torch.rand(20, 30, device=dev))
+
+
 def test_fit_error_behaviour(dev):
     from torchnmf_amd.nmf import NMF
     m = NMF((20, 30), 4).to(dev)
