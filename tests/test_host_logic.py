@@ -98,6 +98,14 @@ def test_no_cpu_fallback():
         m.sparse_fit(torch.rand(20, 30))
 
 
+def test_eps_is_the_same_on_both_sides_of_the_abi():
+    """constants.eps (reference constants.py:3) and nmfmu::kEps in the HIP sources are the same fp32 value."""
+    from torchnmf_amd.constants import eps
+    src = open(os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', 'nmfmu_fused.h')).read()
+    k = float(re.search(r'constexpr float kEps = ([0-9.e+-]+)f;', src).group(1))
+    assert np.float32(k) == np.float32(eps) == np.float32(torch.finfo(torch.float32).eps)
+
+
 # ---- the C ABI surface ------------------------------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'nmfmu.h')).read()
