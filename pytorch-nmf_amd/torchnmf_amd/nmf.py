@@ -112,7 +112,8 @@ class BaseComponent(nn.Module):
 
         Extra keyword-only arguments (not in the reference):
           precision      'bf16x3' (default where available: split-bf16 MFMA, matches the fp32 reference to
-                         ~1e-5), 'bf16' (fastest; V and operands rounded to bf16), or None/'auto'.
+                         ~1e-5; above rank 128 on the GEMM engine), 'bf16' (fastest; V and operands rounded to
+                         bf16), or None/'auto' (= 'bf16x3').
                          The environment variable TORCHNMF_AMD_PRECISION overrides the default.
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
@@ -221,9 +222,18 @@ class NMF(BaseComponent):
         for p in (self.W, self.H):
             if not p.data.is_contiguous():
                 p.data = p.data.contiguous()
-        if self.W.shape[1] > 256:      # beyond the fused kernel's register-resident rank: the GEMM engine (T = 1)
-            if group is not None:
-                raise NotImplementedError('column sharding is implemented for ranks up to 256')
+        R = self.W.shape[1]
+        # The fused kernel keeps rank-wide accumulators in registers: bf16 operands up to rank 256, the fp32-grade
+        # split-bf16 mode up to rank 128.  Everything else runs on the GEMM engine (NMF = the T = 1 member of the
+        # NMFD family), which has no rank limit.  'auto' means "meets the 1e-4 parity bar", so it leaves the fused
+        # kernel at rank 129 already; precision='bf16' keeps the fast kernel up to rank 256.
+        wide = R > 256 or (R > 128 and precision in (None, 'auto', 'bf16x3'))
+        if wide and group is not None:
+            if R > 256 or precision == 'bf16x3':
+                raise NotImplementedError('column sharding is implemented for the fused kernels (rank <= 256; '
+                                          'bf16x3 up to rank 128)')
+            wide, precision = False, 'bf16'           # sharded 'auto' at rank 129..256: the fused bf16 kernel
+        if wide:
             from .nmfd_engine import WideRankMU
             return WideRankMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
                               update_W=self.W.requires_grad, update_H=self.H.requires_grad)

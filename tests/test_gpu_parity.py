@@ -587,10 +587,13 @@ def test_rank_above_128_bf16(dev, rank, beta):
 def test_unsupported_combinations_raise(dev):
     from torchnmf_amd.nmf import NMF
     V = torch.rand(64, 80)
+    from torchnmf_amd.engine import DenseMU
     m = NMF(V.shape, 200).to(dev)
-    with pytest.raises(NotImplementedError):
-        m.fit(V.to(dev), precision='bf16x3')      # split precision needs padded rank <= 128
-    assert m.fit(V.to(dev), max_iter=3) == 3       # 'auto' falls back to bf16 for wide ranks
+    with pytest.raises(NotImplementedError):       # the fused kernel's split precision stops at padded rank 128 ...
+        DenseMU(V.to(dev), m.W.data, m.H.data, 1.0, precision='bf16x3')
+    assert m.fit(V.to(dev), max_iter=3, precision='bf16x3') == 3   # ... so fit() takes the GEMM engine there,
+    assert m.fit(V.to(dev), max_iter=3) == 3                       # which is also what 'auto' means above rank 128
+    assert m.fit(V.to(dev), max_iter=3, precision='bf16') == 3     # the fast fused kernel on request
     assert NMF(V.shape, 300).to(dev).fit(V.to(dev), max_iter=3) == 3   # rank > 256: GEMM engine (WideRankMU)
 
 
@@ -864,3 +867,16 @@ def test_siplca_implicit_operands_against_oracle(dev):
     assert n == nr
     for p, ref in ((m.W, Wr), (m.H, Hr), (m.Z, Zr)):
         assert rel_err(p.data.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize('rank', [129, 200])
+def test_auto_precision_meets_the_parity_bar_above_rank_128(dev, rank):
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(rank)
+    V = torch.rand(260, 330, generator=g) + 1e-3
+    W0, H0 = torch.randn(330, rank, generator=g).abs(), torch.randn(260, rank, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), 1, NO_STOP, 5)
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 5)
+    assert n == nr and rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
