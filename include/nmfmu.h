@@ -124,6 +124,12 @@ int nmfmu_pack_factor_scaled(const nmfmu_factor* fac, int rank, int r_pad, int p
  */
 int nmfmu_mu_partial(const nmfmu_step* st, void* stream);
 
+/* nmfmu_den_partial: the positive term alone for a generic beta (not 0, 1, 2), WITHOUT a target:
+ *   slab_num[s] = sum over the s-th contraction chunk of (owner panel^T + eps)^(beta-1) @ panel      (st->xp may be NULL)
+ * This is the dense pass the reference makes for sparse targets (nmf.py:628-636).  nmfmu_loss likewise accepts
+ * st->xp == NULL and then evaluates beta_div against an all-zero target, i.e. sum (S + eps)^beta / beta. */
+int nmfmu_den_partial(const nmfmu_step* st, void* stream);
+
 /* nmfmu_mu_step: one complete single-device half-step = nmfmu_mu_partial + nmfmu_mu_apply.  When the contraction is
  * not split (nsplit == 1) and beta == 1 the apply runs inside the fused kernel's epilogue (no slab round trip).
  * kl_den: column sums of the panel (beta == 1), else ignored.  phase: 0 = everything, 1 = only the fused kernel,

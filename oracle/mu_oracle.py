@@ -341,7 +341,7 @@ def fit(V: torch.Tensor, W0: torch.Tensor, H0: torch.Tensor, beta: float = 1, to
 
 
 # --------------------------------------------------------------------------
-# sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}.  The reference differentiates the scalars
+# sparse-COO target (nmf.py:351-398, 602-638).  The reference differentiates the scalars
 #   beta = 1: pos = W.sum(0) . H.sum(0)            neg = sum_nnz v log(WH + eps)          (nmf.py:624-626)
 #   beta = 2: pos = 1/2 <H W^T W, H>               neg = <V^T H, W>                        (nmf.py:616-619)
 # whose gradients are the dense numerator / denominator terms restricted to the stored entries (zeros of V add
@@ -355,16 +355,21 @@ def sp_terms(idx, vals, W, H, beta):
         pos = ((H @ W.t() @ W).reshape(-1) @ H.reshape(-1)) * 0.5
         VtH = torch.zeros(W.shape[0], H.shape[1]).index_add_(0, jj, vals[:, None] * H[ii])
         return pos, VtH.reshape(-1) @ W.reshape(-1)
-    assert beta == 1, 'the sparse oracle covers beta in {1, 2}'
     s = (W[jj] * H[ii]).sum(1)
-    return W.sum(0) @ H.sum(0), vals @ (s + EPS).log()
+    if beta == 1:
+        return W.sum(0) @ H.sum(0), vals @ (s + EPS).log()
+    # generic beta (nmf.py:628-636): the positive term runs over EVERY entry of the reconstruction
+    pos = (H @ W.t() + EPS).pow(beta).sum() / beta
+    return pos, vals @ (s + EPS).pow(beta - 1) / (beta - 1)
 
 
 def sp_v_norm(vals, beta):
     """nmf.py:172-181."""
     if beta == 2:
         return vals @ vals * 0.5
-    return vals @ vals.log() - vals.sum()
+    if beta == 1:
+        return vals @ vals.log() - vals.sum()
+    return vals.pow(beta).sum() / beta / (beta - 1)
 
 
 def sp_fit_loss(idx, vals, W, H, beta) -> float:
@@ -372,24 +377,35 @@ def sp_fit_loss(idx, vals, W, H, beta) -> float:
     return float(((sp_v_norm(vals, beta) + pos - neg) * 2).sqrt())
 
 
-def sp_w_step(idx, vals, shape, W, H, beta, gamma, l1=0.0, l2=0.0):
+def _sp_num(idx, vals, W, H, beta, for_w):
+    """Gradient of ``neg`` w.r.t. W (for_w) or H: the dense numerator restricted to the stored entries."""
     ii, jj = idx[0], idx[1]
-    if beta == 2:     # grad of neg = V^T H, grad of pos = W H^T H
-        neg = torch.zeros_like(W).index_add_(0, jj, vals[:, None] * H[ii])
+    if beta == 2:
+        g = vals
+    else:
+        s = (W[jj] * H[ii]).sum(1) + EPS
+        g = vals / s if beta == 1 else vals * s.pow(beta - 2)
+    if for_w:
+        return torch.zeros_like(W).index_add_(0, jj, g[:, None] * H[ii])
+    return torch.zeros_like(H).index_add_(0, ii, g[:, None] * W[jj])
+
+
+def sp_w_step(idx, vals, shape, W, H, beta, gamma, l1=0.0, l2=0.0):
+    neg = _sp_num(idx, vals, W, H, beta, True)
+    if beta == 1:
+        return _apply(W, neg, H.sum(0, keepdim=True), True, gamma, l1, l2)
+    if beta == 2:     # grad of pos = W H^T H
         return _apply(W, neg, W @ (H.t() @ H), False, gamma, l1, l2)
-    g = vals / ((W[jj] * H[ii]).sum(1) + EPS)
-    neg = torch.zeros_like(W).index_add_(0, jj, g[:, None] * H[ii])
-    return _apply(W, neg, H.sum(0, keepdim=True), True, gamma, l1, l2)
+    return _apply(W, neg, (H @ W.t() + EPS).pow(beta - 1).t() @ H, False, gamma, l1, l2)   # dense positive term
 
 
 def sp_h_step(idx, vals, shape, W, H, beta, gamma, l1=0.0, l2=0.0):
-    ii, jj = idx[0], idx[1]
+    neg = _sp_num(idx, vals, W, H, beta, False)
+    if beta == 1:
+        return _apply(H, neg, W.sum(0), True, gamma, l1, l2)
     if beta == 2:
-        neg = torch.zeros_like(H).index_add_(0, ii, vals[:, None] * W[jj])
         return _apply(H, neg, H @ (W.t() @ W), False, gamma, l1, l2)
-    g = vals / ((W[jj] * H[ii]).sum(1) + EPS)
-    neg = torch.zeros_like(H).index_add_(0, ii, g[:, None] * W[jj])
-    return _apply(H, neg, W.sum(0), True, gamma, l1, l2)
+    return _apply(H, neg, (H @ W.t() + EPS).pow(beta - 1) @ W, False, gamma, l1, l2)
 
 
 def sp_fit(idx, vals, shape, W0, H0, beta=1, tol=1e-4, max_iter=200, alpha=0, l1_ratio=0):

@@ -16,9 +16,12 @@ namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+static bool stage_is_reg(const nmfmu_step* st) { return st->stage == NMFMU_STAGE_REG; }
+
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
                    const float* fuse_kl_den = nullptr) {
-  if (!st || !st->xp || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
+  if (!st || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
+  if (!st->xp && mode == kModeMU) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
   const int G = st->block_rows / 128;
@@ -55,9 +58,10 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     a.colsum_part = st->owner.colsum_part;
     a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   }
-  if (mode == kModeMU) {
+  if (mode == kModeMU || mode == kModeDen) {
     if (!a.slab_num || !a.p2_hi || (x3 && !a.p2_lo)) return NMFMU_ERR_ARG;
-    if (kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
+    if (mode == kModeMU && kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
+    if (mode == kModeDen && (kind != kGen || G != 1 || stage_is_reg(st))) return NMFMU_ERR_UNSUPPORTED;
   } else if (!loss_part) {
     return NMFMU_ERR_ARG;
   }
@@ -180,6 +184,12 @@ int nmfmu_mu_partial(const nmfmu_step* st, void* stream) {
   if (!st) return NMFMU_ERR_ARG;
   if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
   return fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream));
+}
+
+int nmfmu_den_partial(const nmfmu_step* st, void* stream) {
+  if (!st) return NMFMU_ERR_ARG;
+  if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  return fused_dispatch(st, kModeDen, nullptr, st->owner.rows, st->panel.rows, S(stream));
 }
 
 int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream) {

@@ -58,7 +58,9 @@ namespace nmfmu {
 constexpr float kEps = 1.1920928955078125e-07f;  // constants.py:3 of the reference
 
 enum BetaKind : int { kKL = 0, kEuc = 1, kIS = 2, kGen = 3 };
-enum FusedMode : int { kModeMU = 0, kModeLoss = 1 };
+// kModeDen: the positive term alone, den = Gp(S) @ panel with no target at all (sparse targets with a generic beta:
+// the reference's dense pass of nmf.py:628-636).  The loss mode also runs without a target (xp == nullptr: X = 0).
+enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2 };
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -124,6 +126,7 @@ struct FusedCfg {
   static constexpr int IMG = kBK * ROWB;     // bytes of one image tile (= 128 * R_PAD)
   static constexpr int NPL = X3 ? 2 : 1;     // planes (hi / lo)
   static constexpr bool LOSS = MODE == kModeLoss;
+  static constexpr bool DEN = MODE == kModeDen;
   static constexpr int NIMG = (LOSS ? 1 : 2) * NPL;
   static constexpr int P1HI = 0;
   static constexpr int P1LO = IMG;           // valid when X3
@@ -135,7 +138,7 @@ struct FusedCfg {
   // pipelined path: two-slot rings for P1 and P2 (one tile of lead), three-slot ring for X (two tiles of lead)
   static constexpr int LDS_BYTES = SP ? 2 * 2 * IMG + 3 * XTILE : 2 * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
-  static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS;
+  static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
   // the software-pipelined beta == 1 kernel keeps two S tiles live: it gets the whole register file (one wave per SIMD)
   static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128 || G > 1) ? 1 : 2;   // (SP: 512 threads, 1 workgroup)
@@ -272,8 +275,16 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
 
   const char* xbase =
       reinterpret_cast<const char*>(a.xp) + ((size_t)mb * a.ktiles * 4 + wave) * (G * NQ * 1024) + lane * 16;
+  const bool no_x = C::DEN || a.xp == nullptr;   // (uniform) no target: the X registers stay zero
   auto load_x = [&](int t, u32x4(&x)[G][NQ]) {
     const char* p = xbase + (size_t)t * (4 * G * NQ * 1024);
+    if (no_x) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) x[g][q] = u32x4{0u, 0u, 0u, 0u};
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -426,6 +437,7 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
             float n0, n1, p0, p1;
             mu_elem<BETA>(s0, x0, a.beta, n0, p0);
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
+            if constexpr (C::DEN) n0 = p0, n1 = p1;   // denominator-only pass: the one operand set carries Gp
             const uint32_t nh = pack_bf16(n0, n1);
             gnh[g][tt][d] = nh;
             if constexpr (X3) gnl[g][tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
@@ -833,7 +845,7 @@ int launch_one(const FusedArgs& a, int grid, hipStream_t s) {
 // Which (beta, precision, mode) combinations get the 256-row (G = 2) tile: only those whose accumulators fit the
 // 512-register file without spilling -- beta == 1 numerators and the loss, bf16 operands, padded rank <= 128.
 constexpr bool has_g2(int r_pad, int beta, bool x3, int mode) {
-  return !x3 && r_pad <= 128 && (beta == kKL || mode == kModeLoss);
+  return !x3 && r_pad <= 128 && mode != kModeDen && (beta == kKL || mode == kModeLoss);
 }
 
 template <int R_PAD, bool ALLOW_X3>
@@ -852,7 +864,9 @@ int launch_fused_dispatch(int beta_kind, int x3, int mode, int stage, int g, con
   NMFMU_CASE_BETA(false, kModeMU, 1)
   NMFMU_CASE_BETA(false, kModeLoss, 0)
   NMFMU_CASE_BETA(false, kModeLoss, 1)
+  NMFMU_CASE(kGen, false, kModeDen, 1)
   if constexpr (ALLOW_X3) {
+    NMFMU_CASE(kGen, true, kModeDen, 1)
     NMFMU_CASE_BETA(true, kModeMU, 0)
     NMFMU_CASE_BETA(true, kModeMU, 1)
     NMFMU_CASE_BETA(true, kModeLoss, 0)

@@ -23,13 +23,15 @@ __device__ __forceinline__ float wave_sum(float v) {   // xor butterfly: every l
 }
 
 // RL = rank slots per lane (r_pad / 64 rounded up; r_pad 32 uses half a wave's lanes with zeros beyond the rank)
-template <int RL, bool KL>
+// KIND: kKL g = v / (s + eps); kEuc g = v; kGen g = v (s + eps)^(beta - 2)
+template <int RL, int KIND>
 __global__ void __launch_bounds__(256) sp_partial_kernel(const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colidx,
                                                          const float* __restrict__ vals, int rows,
                                                          const float* __restrict__ owner,
                                                          const float* __restrict__ panel, int rank,
-                                                         float* __restrict__ num, int r_pad) {
+                                                         float* __restrict__ num, int r_pad, float beta) {
+  constexpr bool KL = KIND != kEuc;   // needs the dot product
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -76,7 +78,10 @@ __global__ void __launch_bounds__(256) sp_partial_kernel(const int32_t* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) part[u] += __shfl_xor(part[u], o, 64);
 #pragma unroll
-      for (int u = 0; u < U; ++u) g[u] = v[u] / (part[u] + kEps);   // nmf.py:65 restricted to the stored entries
+      for (int u = 0; u < U; ++u) {       // nmf.py:65 / 72 restricted to the stored entries
+        const float se = part[u] + kEps;
+        g[u] = KIND == kKL ? v[u] / se : v[u] * exp2f((beta - 2.f) * log2f(se));
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)           // entries accumulate in storage order: deterministic
@@ -92,13 +97,13 @@ __global__ void __launch_bounds__(256) sp_partial_kernel(const int32_t* __restri
 
 // neg term of the tracked loss: sum over stored entries of v log(s + eps) (beta == 1) or v s (beta == 2); one
 // double partial per workgroup (4 rows), summed on the host side of the ABI in a fixed order by sp_reduce_kernel.
-template <int RL, bool KL>
+template <int RL, int KIND>
 __global__ void __launch_bounds__(256) sp_loss_kernel(const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ colidx,
                                                       const float* __restrict__ vals, int rows,
                                                       const float* __restrict__ owner,
                                                       const float* __restrict__ panel, int rank,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part, float beta) {
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
@@ -119,7 +124,9 @@ __global__ void __launch_bounds__(256) sp_loss_kernel(const int32_t* __restrict_
         partial += r < rank ? a[q] * panel[(size_t)col * rank + r] : 0.f;
       }
       const float s = wave_sum(partial);
-      tot += KL ? (double)(vals[p] * logf(s + kEps)) : (double)(vals[p] * s);
+      tot += KIND == kKL ? (double)(vals[p] * logf(s + kEps))
+           : KIND == kEuc ? (double)(vals[p] * s)
+                          : (double)(vals[p] * exp2f((beta - 1.f) * log2f(s + kEps)) / (beta - 1.f));   // nmf.py:636
     }
   }
   if (lane == 0) red[w] = tot;
@@ -200,16 +207,16 @@ int nmfmu_sp_partial(const int32_t* rowptr, const int32_t* colidx, const float* 
   if (!rowptr || !colidx || !vals || !owner || !panel || !num || owner_rows <= 0 || rank <= 0) return NMFMU_ERR_ARG;
   if (r_pad != nmfmu_pad_rank(rank)) return NMFMU_ERR_ARG;
   const int kind = nmfmu_beta_kind(beta);
-  if (kind != NMFMU_BETA_KL && kind != NMFMU_BETA_EUC) return NMFMU_ERR_UNSUPPORTED;
+  if (kind == NMFMU_BETA_IS) return NMFMU_ERR_UNSUPPORTED;   // beta == 0 is rejected for sparse targets (nmf.py:332-336)
   const dim3 grid((owner_rows + 3) / 4), block(256);
-  const bool kl = kind == NMFMU_BETA_KL;
-#define L(RLV)                                                                                                        \
-  if (kl) hipLaunchKernelGGL((sp_partial_kernel<RLV, true>), grid, block, 0, S(stream), rowptr, colidx, vals, owner_rows, \
-                             owner, panel, rank, num, r_pad);                                                         \
-  else hipLaunchKernelGGL((sp_partial_kernel<RLV, false>), grid, block, 0, S(stream), rowptr, colidx, vals, owner_rows,  \
-                          owner, panel, rank, num, r_pad);
+#define L2(RLV, K)                                                                                                   \
+  hipLaunchKernelGGL((sp_partial_kernel<RLV, K>), grid, block, 0, S(stream), rowptr, colidx, vals, owner_rows, owner,  \
+                     panel, rank, num, r_pad, beta);
+#define L(RLV)                                                                         \
+  if (kind == NMFMU_BETA_KL) { L2(RLV, kKL) } else if (kind == NMFMU_BETA_EUC) { L2(RLV, kEuc) } else { L2(RLV, kGen) }
   if (r_pad <= 64) { L(1) } else if (r_pad == 128) { L(2) } else { L(4) }
 #undef L
+#undef L2
   return (int)hipGetLastError();
 }
 
@@ -218,17 +225,17 @@ int nmfmu_sp_loss_neg(const int32_t* rowptr, const int32_t* colidx, const float*
   if (!rowptr || !colidx || !vals || !owner || !panel || !part || !out || owner_rows <= 0 || rank <= 0 || rank > 256)
     return NMFMU_ERR_ARG;
   const int kind = nmfmu_beta_kind(beta);
-  if (kind != NMFMU_BETA_KL && kind != NMFMU_BETA_EUC) return NMFMU_ERR_UNSUPPORTED;
+  if (kind == NMFMU_BETA_IS) return NMFMU_ERR_UNSUPPORTED;
   const int nblk = (owner_rows + 3) / 4;
-  const bool kl = kind == NMFMU_BETA_KL;
   const int r_pad = nmfmu_pad_rank(rank);
-#define L(RLV)                                                                                                       \
-  if (kl) hipLaunchKernelGGL((sp_loss_kernel<RLV, true>), dim3(nblk), dim3(256), 0, S(stream), rowptr, colidx, vals,   \
-                             owner_rows, owner, panel, rank, part);                                                  \
-  else hipLaunchKernelGGL((sp_loss_kernel<RLV, false>), dim3(nblk), dim3(256), 0, S(stream), rowptr, colidx, vals,     \
-                          owner_rows, owner, panel, rank, part);
+#define L2(RLV, K)                                                                                                   \
+  hipLaunchKernelGGL((sp_loss_kernel<RLV, K>), dim3(nblk), dim3(256), 0, S(stream), rowptr, colidx, vals, owner_rows,  \
+                     owner, panel, rank, part, beta);
+#define L(RLV)                                                                         \
+  if (kind == NMFMU_BETA_KL) { L2(RLV, kKL) } else if (kind == NMFMU_BETA_EUC) { L2(RLV, kEuc) } else { L2(RLV, kGen) }
   if (r_pad <= 64) { L(1) } else if (r_pad == 128) { L(2) } else { L(4) }
 #undef L
+#undef L2
   hipLaunchKernelGGL(sp_reduce_kernel, dim3(1), dim3(256), 0, S(stream), part, nblk, out);
   return (int)hipGetLastError();
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_pack_factor': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
+    'nmfmu_den_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_mu_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_mu_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

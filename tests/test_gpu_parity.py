@@ -739,8 +739,8 @@ def test_sparse_fit_errors(dev):
     V = torch.rand(30, 20)
     Vs = torch.where(V > 0.5, V, torch.zeros(())).to_sparse().to(dev)
     m = NMF((30, 20), 4).to(dev)
-    with pytest.raises(NotImplementedError):
-        m.fit(Vs, beta=0.5)
+    with pytest.raises(ValueError):                # a sparse target always contains zeros (nmf.py:332-336)
+        m.fit(Vs, beta=0)
     with pytest.raises(AssertionError):
         m.fit((-Vs).coalesce())
     with pytest.raises(NotImplementedError):
@@ -880,3 +880,31 @@ def test_auto_precision_meets_the_parity_bar_above_rank_128(dev, rank):
     n = m.fit(V.to(dev), 1, NO_STOP, 5)
     Wr, Hr, nr, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 5)
     assert n == nr and rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+
+
+@pytest.mark.parametrize('beta', [0.5, 1.5, 3])
+@pytest.mark.parametrize('tag,args', [('run', (NO_STOP, 20, 0.0, 0.0)), ('reg', (NO_STOP, 10, 0.1, 0.5))])
+def test_sparse_fit_generic_beta_g9_golden(dev, beta, tag, args):
+    """Generic beta on a sparse target: gather kernel for the numerator, target-less fused pass for the dense positive
+    term (nmfmu_den_partial), target-less loss."""
+    from torchnmf_amd.nmf import NMF
+    g = load_golden('g9_sparse')
+    V = torch.sparse_coo_tensor(t(g['indices']), t(g['values']), tuple(g['shape'])).to(dev)
+    m = NMF(W=t(g['W0']), H=t(g['H0'])).to(dev)
+    tol, it, alpha, l1r = args
+    n = m.fit(V, beta, tol, it, alpha=alpha, l1_ratio=l1r)
+    assert n == int(g[f'b{beta}_{tag}_n'])
+    assert rel_err(m.W.data.cpu(), g[f'b{beta}_{tag}_W']) < TOL and rel_err(m.H.data.cpu(), g[f'b{beta}_{tag}_H']) < TOL
+
+
+@pytest.mark.parametrize('beta', [0.5, 1.5, 3])
+def test_fit_sparse_equals_dense_generic_beta(dev, beta):
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(int(beta * 10))
+    Vd = torch.rand(400, 900, generator=g)
+    Vd = torch.where(Vd > 0.9, Vd, torch.zeros(()))
+    W0, H0 = torch.randn(900, 40, generator=g).abs(), torch.randn(400, 40, generator=g).abs()
+    ms, md = NMF(W=W0, H=H0).to(dev), NMF(W=W0, H=H0).to(dev)
+    ms.fit(Vd.to_sparse().to(dev), beta, 0, 5)
+    md.fit(Vd.to(dev), beta, 0, 5, precision='bf16x3')
+    assert rel_err(ms.W.data.cpu(), md.W.data.cpu()) < TOL and rel_err(ms.H.data.cpu(), md.H.data.cpu()) < TOL

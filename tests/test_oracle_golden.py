@@ -267,3 +267,17 @@ def test_g11_siplca_oracle(name, case):
     for t_, k in ((W, 'W'), (H, 'H'), (Z, 'Z')):
         assert rel_err(t_, g[f'{name}_{case}_{k}']) < 1e-5
     assert np.allclose(losses[1:], g[f'{name}_{case}_losses'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('beta', [0.5, 1.5, 3])
+@pytest.mark.parametrize('tag,args', [('run', (NO_STOP, 20, 0.0, 0.0)), ('reg', (NO_STOP, 10, 0.1, 0.5))])
+def test_g9_sparse_oracle_generic_beta(beta, tag, args):
+    """The generic-beta branch (nmf.py:628-636): numerator over the stored entries, positive term over every entry."""
+    g = load_golden('g9_sparse')
+    idx, vals = torch.from_numpy(g['indices']), torch.from_numpy(g['values'])
+    W0, H0 = torch.from_numpy(g['W0']), torch.from_numpy(g['H0'])
+    assert O.sp_fit_loss(idx, vals, W0, H0, beta) == pytest.approx(float(g[f'b{beta}_loss_init']), rel=1e-5)
+    W, H, n, losses = O.sp_fit(idx, vals, tuple(g['shape']), W0, H0, beta, *args)
+    assert n == int(g[f'b{beta}_{tag}_n'])
+    assert rel_err(W, g[f'b{beta}_{tag}_W']) < 1e-5 and rel_err(H, g[f'b{beta}_{tag}_H']) < 1e-5
+    assert np.allclose(losses[1:], g[f'b{beta}_{tag}_losses'], rtol=1e-5)

@@ -273,6 +273,17 @@ def g9():
         with torch.no_grad():
             pos, neg = m._sp_recon_beta_pos_neg(Vs, m.H, m.W, beta)
             out[f'b{beta}_loss_init'] = np.float64(float((ref_nmf._get_V_norm(Vs, beta) + pos - neg).mul(2).sqrt()))
+    # the generic-beta branch (nmf.py:628-636): the positive term is a dense pass over all of W H^T
+    for beta in (0.5, 1.5, 3):
+        for tag, (it, alpha, l1r) in {'run': (20, 0.0, 0.0), 'reg': (10, 0.1, 0.5)}.items():
+            W, H, n, losses = run_ref(ref_nmf.NMF, Vs, W0, H0, beta, NO_STOP, it, alpha, l1r)
+            out[f'b{beta}_{tag}_W'], out[f'b{beta}_{tag}_H'] = W.numpy(), H.numpy()
+            out[f'b{beta}_{tag}_n'] = np.int64(n)
+            out[f'b{beta}_{tag}_losses'] = np.array(losses, dtype=np.float64)
+        m = ref_nmf.NMF(W=W0.clone(), H=H0.clone())
+        with torch.no_grad():
+            pos, neg = m._sp_recon_beta_pos_neg(Vs, m.H, m.W, beta)
+            out[f'b{beta}_loss_init'] = np.float64(float((ref_nmf._get_V_norm(Vs, beta) + pos - neg).mul(2).sqrt()))
     np.savez_compressed(os.path.join(OUT, 'g9_sparse.npz'), **out)
 
 
