@@ -159,6 +159,16 @@ int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int
 int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                         float ortho, float* grad, void* stream);
 
+/* trainer.BetaMu on a CHAIN of NMF layers (nn.Sequential, tests/test_trainer.py:10-32): the matrix products of the
+ * forward / backward passes are nmfmu_reconstruct calls; these are the two pieces in between.
+ *   nmfmu_mu_terms      : gn, gp = the seeds of trainer.py:75-91 from the prediction s and the target v (n elements;
+ *                         beta == 1 gives gp = 1)
+ *   nmfmu_trainer_update: trainer.py:93-112 on a plain row-major parameter f[rows][cols] with neg / pos of the same shape
+ *                         (grad may be NULL) */
+int nmfmu_mu_terms(const float* s, const float* v, int64_t n, float beta, float* gn, float* gp, void* stream);
+int nmfmu_trainer_update(float* f, int rows, int cols, const float* neg, const float* pos, float l1, float l2, float ortho,
+                         float gamma, float* grad, void* stream);
+
 /* ---- loss -----------------------------------------------------------------------------------------------------
  * nmfmu_loss: beta_div(owner panel^T, X) of metrics.py:60-96 without materialising the reconstruction
  * (replaces nmf.py:360-361 and 400-401).  loss_part: nmfmu_loss_part_count() floats of scratch; *out (device

@@ -228,6 +228,40 @@ def nmfd_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
     return _apply(H, neg, _nmfd_grad_h(gp, W, Lh), False, gamma, l1, l2)
 
 
+def betamu_chain_step(V, X0, Ws, beta, l1=0.0, l2=0.0, ortho=0.0, order=None):
+    """One ``BetaMu.step`` over a CHAIN of NMF layers, prediction = X0 @ W1^T @ W2^T ... (nn.Sequential of NMF layers,
+    tests/test_trainer.py:10-32).  Parameters are updated in ``order`` (names 'X0', 'W1', 'W2', ...; default W1, X0,
+    W2, ... = torch's parameter order), each from a freshly evaluated closure (trainer.py:72).  Gradients through the
+    chain in closed form:  X_k = X_{k-1} W_k^T,  G_{k-1} = G_k W_k,  dW_k = G_k^T X_{k-1},  dX0 = G_0."""
+    Ws = list(Ws)
+    gamma = gamma_of(beta)
+    if order is None:
+        order = ['W1', 'X0'] + [f'W{k}' for k in range(2, len(Ws) + 1)]
+    grads = {}
+    for name in order:
+        xs = [X0]
+        for W in Ws:
+            xs.append(xs[-1] @ W.t())
+        gn, gp = betamu_terms(V, xs[-1], beta)
+
+        def back(G):
+            k = len(Ws)
+            while True:
+                if name == f'W{k}':
+                    return G.t() @ xs[k - 1]
+                G = G @ Ws[k - 1]
+                k -= 1
+                if k == 0:
+                    return G
+        neg, pos = back(gn), back(gp)
+        if name == 'X0':
+            X0, grads[name] = betamu_update(X0, neg, pos, gamma, l1, l2, ortho)
+        else:
+            k = int(name[1:])
+            Ws[k - 1], grads[name] = betamu_update(Ws[k - 1], neg, pos, gamma, l1, l2, ortho)
+    return X0, Ws, grads
+
+
 # --------------------------------------------------------------------------
 # NMF2D / NMF3D (nmf.py:782-942): the same model with 2 / 3 shift axes.  V (B,C,*L), W (C,R,*T), H (B,R,*(L-T+1)),
 #   V[b,c,l] ~ sum_{r,t} W[c,r,t] H[b,r,l-t]      (vector l, t; nmf.py:857-860, 937-940: convNd(H, W.flip, pad=T-1))

@@ -35,6 +35,9 @@ int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, 
 int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s);
 int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int kind, double* part, double* out,
                     hipStream_t s);
+int launch_mu_terms(const float* s, const float* v, int64_t n, float beta, int kind, float* gn, float* gp, hipStream_t st);
+int launch_trainer_update(float* f, int rows, int cols, const float* neg, const float* pos, float l1, float l2, float ortho,
+                          float gamma, float* grad, hipStream_t st);
 int launch_norms(const float* x, int64_t n, double* part, double* out, hipStream_t s);
 int launch_reconstruct(const float* A, int M, const float* B, int K, int R, float* out, int64_t ld, hipStream_t s);
 int launch_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, hipStream_t s);

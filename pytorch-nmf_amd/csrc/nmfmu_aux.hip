@@ -372,6 +372,68 @@ int launch_beta_div(const float* x, const float* y, int64_t n, float beta, int k
   return (int)hipGetLastError();
 }
 
+// trainer.BetaMu on a chain of layers (trainer.py:75-112): the two pieces that are not matrix products.
+// (1) the back-propagated seeds of trainer.py:75-91 on plain arrays:  gn, gp = f(V, WH, beta)
+template <int BETA>
+__global__ void __launch_bounds__(256) mu_terms_kernel(const float* __restrict__ s, const float* __restrict__ v, int64_t n,
+                                                       float beta, float* __restrict__ gn, float* __restrict__ gp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float a, b;
+    mu_elem<BETA>(BETA == kEuc ? s[i] : s[i] + kEps, v[i], beta, a, b);
+    gn[i] = a;
+    gp[i] = BETA == kKL ? 1.f : b;      // beta == 1 back-propagates ones (trainer.py:84)
+  }
+}
+
+int launch_mu_terms(const float* s, const float* v, int64_t n, float beta, int kind, float* gn, float* gp, hipStream_t st) {
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
+  switch (kind) {
+    case kKL: hipLaunchKernelGGL(mu_terms_kernel<kKL>, dim3(grid), dim3(256), 0, st, s, v, n, beta, gn, gp); break;
+    case kEuc: hipLaunchKernelGGL(mu_terms_kernel<kEuc>, dim3(grid), dim3(256), 0, st, s, v, n, beta, gn, gp); break;
+    case kIS: hipLaunchKernelGGL(mu_terms_kernel<kIS>, dim3(grid), dim3(256), 0, st, s, v, n, beta, gn, gp); break;
+    default: hipLaunchKernelGGL(mu_terms_kernel<kGen>, dim3(grid), dim3(256), 0, st, s, v, n, beta, gn, gp); break;
+  }
+  return (int)hipGetLastError();
+}
+
+// (2) trainer.py:93-112 on a plain row-major parameter [rows][cols]; one workgroup per row (row sum for the
+// orthogonality penalty in a fixed order)
+__global__ void __launch_bounds__(256) trainer_update_kernel(float* __restrict__ f, int cols, const float* __restrict__ neg,
+                                                             const float* __restrict__ pos, float l1, float l2, float ortho,
+                                                             float gamma, float* __restrict__ grad) {
+  __shared__ float red[256];
+  const size_t base = (size_t)blockIdx.x * cols;
+  float rs = 0.f;
+  if (ortho > 0.f) {
+    for (int c = threadIdx.x; c < cols; c += 256) rs += f[base + c];
+    red[threadIdx.x] = rs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    rs = red[0];
+  }
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float x = f[base + c];
+    const float ng = fmaxf(neg[base + c], 0.f);
+    float ps = fmaxf(pos[base + c], 0.f);
+    if (grad) grad[base + c] = ps - ng;             // trainer.py:98
+    if (l1 > 0.f) ps += l1;
+    if (l2 > 0.f) ps += l2 * x;
+    if (ortho > 0.f) ps += ortho * (rs - x);        // trainer.py:105-106
+    float mult = (ng + kEps) / (ps + kEps);         // trainer.py:108-110
+    if (gamma != 1.f) mult = powf(mult, gamma);
+    f[base + c] = x * mult;
+  }
+}
+
+int launch_trainer_update(float* f, int rows, int cols, const float* neg, const float* pos, float l1, float l2, float ortho,
+                          float gamma, float* grad, hipStream_t st) {
+  hipLaunchKernelGGL(trainer_update_kernel, dim3(rows), dim3(256), 0, st, f, cols, neg, pos, l1, l2, ortho, gamma, grad);
+  return (int)hipGetLastError();
+}
+
 // metrics.sparseness (metrics.py:99-115) needs ||x||_1 and ||x||_2: out[0] = sum |x|, out[1] = sum x^2
 __global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
   __shared__ double red[2][4];

@@ -274,6 +274,17 @@ int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double
   return launch_beta_div(x, y, n, beta, nmfmu_beta_kind(beta), part, out, S(stream));
 }
 
+int nmfmu_mu_terms(const float* s, const float* v, int64_t n, float beta, float* gn, float* gp, void* stream) {
+  if (!s || !v || !gn || !gp || n <= 0) return NMFMU_ERR_ARG;
+  return launch_mu_terms(s, v, n, beta, nmfmu_beta_kind(beta), gn, gp, S(stream));
+}
+
+int nmfmu_trainer_update(float* f, int rows, int cols, const float* neg, const float* pos, float l1, float l2, float ortho,
+                         float gamma, float* grad, void* stream) {
+  if (!f || !neg || !pos || rows <= 0 || cols <= 0 || !(ortho >= 0.f)) return NMFMU_ERR_ARG;
+  return launch_trainer_update(f, rows, cols, neg, pos, l1, l2, ortho, gamma, grad, S(stream));
+}
+
 int nmfmu_norms(const float* x, int64_t n, double* part, double* out, void* stream) {
   if (!x || !part || !out || n <= 0) return NMFMU_ERR_ARG;
   return launch_norms(x, n, part, out, S(stream));

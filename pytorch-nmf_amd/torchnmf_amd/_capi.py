@@ -84,6 +84,9 @@ SIGNATURES = {
     'nmfmu_loss_part_count': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_loss': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_beta_div': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_mu_terms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_trainer_update': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p, C.c_void_p]),
     'nmfmu_norms': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_reconstruct': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p]),

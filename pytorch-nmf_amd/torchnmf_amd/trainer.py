@@ -1,10 +1,16 @@
 """``BetaMu`` -- the optimizer-style entry to the same multiplicative update (reference: trainer.py:8-121).
 
 The reference's ``BetaMu.step(closure)`` back-propagates ``output_neg`` / ``output_pos`` through whatever graph the
-closure built.  When the closure's prediction is the direct output of ONE ``NMF`` layer those two backward passes
-are exactly the numerator / denominator contractions of the fused HIP kernel, so this
-class runs them there and applies trainer.py:93-112 in ``nmfmu_trainer_apply``.  Anything else (stacked layers,
-arithmetic on the prediction, NMFD) is outside this engine and raises ``NotImplementedError`` -- there is no autograd
+closure built.  Two graph shapes are recognised through the provenance tag ``forward()`` leaves on its output:
+
+* ONE ``NMF`` layer: the two backward passes are exactly the numerator / denominator contractions of the fused HIP
+  kernel; they run there and trainer.py:93-112 is applied by ``nmfmu_trainer_apply``.
+* a CHAIN of ``NMF`` layers (``nn.Sequential``, each layer's output feeding the next one's ``H`` -- the reference's own
+  trainer test, tests/test_trainer.py:10-32): prediction = X0 W1^T W2^T ...; the forward products, the back-propagated
+  seeds ``G_{k-1} = G_k W_k`` and the parameter gradients ``G_k^T X_{k-1}`` are exact-fp32 MFMA products
+  (``nmfmu_reconstruct``), the seeds come from ``nmfmu_mu_terms`` and the update from ``nmfmu_trainer_update``.
+
+Anything else (arithmetic on the prediction, convolutive layers) raises ``NotImplementedError`` -- there is no autograd
 fallback.
 
     trainer = BetaMu(m.parameters(), beta=1)
@@ -13,7 +19,7 @@ fallback.
         return V, m()          # or ``return V, m``: hands over the layer and skips materialising H @ W^T
     trainer.step(closure)
 """
-from typing import Dict, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 from torch.optim.optimizer import Optimizer
@@ -45,21 +51,27 @@ class BetaMu(Optimizer):
 
     # ------------------------------------------------------------------
     @staticmethod
-    def _source(pred):
-        """(layer, H, W) behind the closure's prediction, or raise."""
+    def _chain(pred):
+        """(X0, [W1, ..., Wn]) behind the closure's prediction ``X0 @ W1.T @ ... @ Wn.T``, or raise."""
         if isinstance(pred, BaseComponent):            # deferred form: the layer itself
-            layer, H, W = pred, pred.H, pred.W
+            node = (pred, pred.H, pred.W)
         else:
-            src = getattr(pred, '_nmf_source', None)
-            if src is None:
+            node = getattr(pred, '_nmf_source', None)
+            if node is None:
                 raise NotImplementedError(
-                    'BetaMu: the closure must return (target, prediction) where prediction is the direct output of '
-                    'one torchnmf_amd NMF layer (m() or m itself); general autograd graphs are outside this engine')
-            layer, H, W = src
-        if not isinstance(layer, NMF):
-            raise NotImplementedError(f'BetaMu: only NMF layers are supported, got {type(layer).__name__}')
-        assert H is not None and W is not None
-        return layer, H, W
+                    'BetaMu: the closure must return (target, prediction) where prediction is the output of a torchnmf_amd '
+                    'NMF layer or of a chain of them (m(), nn.Sequential(...)(None), or the layer itself); general '
+                    'autograd graphs are outside this engine')
+        Ws: List = []
+        while True:
+            layer, H, W = node
+            if not isinstance(layer, NMF):
+                raise NotImplementedError(f'BetaMu: only NMF layers are supported, got {type(layer).__name__}')
+            assert H is not None and W is not None
+            Ws.append(W)
+            node = getattr(H, '_nmf_source', None)
+            if node is None:
+                return H, Ws[::-1]
 
     def _engine(self, V, H, W, beta, l1, l2) -> DenseMU:
         """DenseMU bound to (V, W, H), rebuilt when any of them is replaced and refreshed when edited in place."""
@@ -78,6 +90,37 @@ class BetaMu(Optimizer):
         assert not bad, "Target should be non-negative."
         self._engines[key] = (eng, versions)
         return eng
+
+    def _chain_step(self, V, X0, Ws, p, beta, l1, l2, ortho):
+        """trainer.py:72-112 for parameter ``p`` of the chain prediction = X0 W1^T ... Wn^T (see the module docstring)."""
+        from . import _capi
+        from .engine import mu_gamma
+        lib = _capi.load()
+        s = torch.cuda.current_stream().cuda_stream
+        R = NMF.reconstruct                                     # A @ B.T, exact-fp32 MFMA kernel
+        xs = [X0.detach().float().contiguous()]
+        for W in Ws:
+            xs.append(R(xs[-1], W))
+        pred = xs[-1]
+        assert V.shape == pred.shape, f'target must be {tuple(pred.shape)}, got {tuple(V.shape)}'
+        gn, gp = torch.empty_like(pred), torch.empty_like(pred)
+        _capi.check(lib.nmfmu_mu_terms(pred.data_ptr(), V.data_ptr(), pred.numel(), float(beta), gn.data_ptr(),
+                                       gp.data_ptr(), s), 'nmfmu_mu_terms')
+
+        def back(G):
+            k = len(Ws)
+            while True:
+                if p is Ws[k - 1]:                               # dW_k = G_k^T X_{k-1}
+                    return R(G.t().contiguous(), xs[k - 1].t().contiguous())
+                G = R(G, Ws[k - 1].detach().t().contiguous())    # G_{k-1} = G_k W_k
+                k -= 1
+                if k == 0:
+                    return G                                     # dX0
+        neg, pos = back(gn), back(gp)
+        assert neg.shape == p.shape
+        _capi.check(lib.nmfmu_trainer_update(p.data.data_ptr(), p.shape[0], p.shape[1], neg.data_ptr(), pos.data_ptr(),
+                                             float(l1), float(l2), float(ortho), mu_gamma(float(beta)), p.grad.data_ptr(),
+                                             s), 'nmfmu_trainer_update')
 
     @torch.no_grad()
     def step(self, closure):
@@ -99,25 +142,29 @@ class BetaMu(Optimizer):
                         continue
                     p.requires_grad = True
                     V, pred = closure()
-                    layer, H, W = self._source(pred)
-                    which = 'W' if p is W else ('H' if p is H else None)
-                    if which is None:                  # p does not feed this prediction (trainer.py:73-75)
+                    X0, Ws = self._chain(pred)
+                    names = [X0] + Ws
+                    if not any(p is q for q in names):    # p does not feed this prediction (trainer.py:73-75)
                         p.requires_grad = False
                         continue
-                    for t, what in ((V, 'BetaMu target'), (W, 'BetaMu W'), (H, 'BetaMu H')):
+                    for t, what in [(V, 'BetaMu target')] + [(q, 'BetaMu factor') for q in names]:
                         _nmf._require_device(t, what)
                     V = V.detach()
                     if V.dtype != torch.float32 or not V.is_contiguous():
                         V = V.float().contiguous()
-                    for q in (W, H):
-                        if not q.data.is_contiguous():
+                    for q in names:
+                        if isinstance(q, torch.nn.Parameter) and not q.data.is_contiguous():
                             q.data = q.data.contiguous()
-                    assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0]), \
-                        f'target must be {(H.shape[0], W.shape[0])}, got {tuple(V.shape)}'
-                    eng = self._engine(V, H, W, beta, l1, l2)
                     if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
                         p.grad = torch.empty_like(p.data)
-                    eng.trainer_step(which, ortho, p.grad)
+                    if len(Ws) == 1:
+                        H, W = X0, Ws[0]
+                        assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0]), \
+                            f'target must be {(H.shape[0], W.shape[0])}, got {tuple(V.shape)}'
+                        eng = self._engine(V, H, W, beta, l1, l2)
+                        eng.trainer_step('W' if p is W else 'H', ortho, p.grad)
+                    else:
+                        self._chain_step(V, X0, Ws, p, beta, l1, l2, ortho)
                     p.requires_grad = False
         finally:
             for group in self.param_groups:

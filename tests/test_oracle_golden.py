@@ -281,3 +281,19 @@ def test_g9_sparse_oracle_generic_beta(beta, tag, args):
     assert n == int(g[f'b{beta}_{tag}_n'])
     assert rel_err(W, g[f'b{beta}_{tag}_W']) < 1e-5 and rel_err(H, g[f'b{beta}_{tag}_H']) < 1e-5
     assert np.allclose(losses[1:], g[f'b{beta}_{tag}_losses'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('beta', [0.5, 1, 2])
+@pytest.mark.parametrize('pen', ['plain', 'pen'])
+def test_g12_betamu_chain_oracle(beta, pen):
+    """BetaMu over nn.Sequential of three NMF layers (tests/test_trainer.py:10-32 of the reference)."""
+    g = load_golden('g12_betamu_chain')
+    assert list(g['param_order']) == ['0.W', '0.H', '1.W']          # torch's order: W before H
+    V, X0 = torch.from_numpy(g['V']), torch.from_numpy(g['H1'])
+    Ws = [torch.from_numpy(g[k]) for k in ('W1', 'W2', 'W3')]
+    for it in range(1, 6):
+        X0, Ws, grads = O.betamu_chain_step(V, X0, Ws, beta, *G7_PEN[pen])
+        if it in (1, 5):
+            for pn, t_ in (('W1', Ws[0]), ('H1', X0), ('W2', Ws[1]), ('W3', Ws[2])):
+                assert rel_err(t_, g[f'b{beta}_{pen}_{pn}_{it}']) < 1e-4
+    assert rel_err(grads['W3'], g[f'b{beta}_{pen}_gradW3']) < 1e-3

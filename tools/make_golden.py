@@ -20,6 +20,7 @@ Sets:
   g9_sparse      NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}: factors, losses, n_iter
   g11_siplca     plca.SIPLCA / SIPLCA2 / SIPLCA3 (shift-invariant PLCA, plca.py:376-606): plain / priors / frozen Z
   g10_plca       plca.PLCA.fit (EM, plca.py:244-304): plain / Dirichlet priors / frozen Z / frozen W
+  g12_betamu_chain  trainer.BetaMu.step on a three-layer nn.Sequential of NMF layers (tests/test_trainer.py:10-32)
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
 """
 import os
@@ -346,11 +347,39 @@ def g11():
     np.savez_compressed(os.path.join(OUT, 'g11_siplca.npz'), **out)
 
 
+def g12():
+    """The reference's own trainer test scenario (tests/test_trainer.py:10-32): nn.Sequential(NMF((100,16),rank=8),
+    NMF(W=(32,16)), NMF(W=(50,32))), m(None) chains the layers; BetaMu updates H1, W1, W2, W3 in turn."""
+    from torchnmf.trainer import BetaMu
+    g = torch.Generator().manual_seed(1012)
+    H1, W1 = torch.randn(100, 8, generator=g).abs(), torch.randn(16, 8, generator=g).abs()
+    W2, W3 = torch.randn(32, 16, generator=g).abs(), torch.randn(50, 32, generator=g).abs()
+    V = torch.rand(100, 50, generator=g) + 2.0 ** -7
+    out = {'V': V.numpy(), 'H1': H1.numpy(), 'W1': W1.numpy(), 'W2': W2.numpy(), 'W3': W3.numpy()}
+    for beta in (0.5, 1, 2):
+        for name, (l1, l2, ortho) in {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}.items():
+            m = torch.nn.Sequential(torchnmf.nmf.NMF(W=W1.clone(), H=H1.clone()), torchnmf.nmf.NMF(W=W2.clone()),
+                                    torchnmf.nmf.NMF(W=W3.clone()))
+            trainer = BetaMu(m.parameters(), beta, l1, l2, ortho)
+
+            def closure():
+                trainer.zero_grad()
+                return V, m(None)
+            for it in range(1, 6):
+                trainer.step(closure)
+                if it in (1, 5):
+                    for pn, p in (('W1', m[0].W), ('H1', m[0].H), ('W2', m[1].W), ('W3', m[2].W)):
+                        out[f'b{beta}_{name}_{pn}_{it}'] = p.detach().numpy().copy()
+            out[f'b{beta}_{name}_gradW3'] = m[2].W.grad.detach().numpy().copy()
+    out['param_order'] = np.array([n for n, _ in torch.nn.Sequential(torchnmf.nmf.NMF((4, 3), rank=2), torchnmf.nmf.NMF(W=(5, 3))).named_parameters()])
+    np.savez_compressed(os.path.join(OUT, 'g12_betamu_chain.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         fn()
         print('wrote', fn.__name__)
     with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
