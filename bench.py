@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--cols', type=int, default=65536, help='columns PER GPU')
     ap.add_argument('--rank', type=int, default=128)
     ap.add_argument('--beta', type=float, default=1.0)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f16'])
     ap.add_argument('--stage', type=int, default=None, help='0 = register staging, 1 = LDS-DMA (default)')
     ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -181,7 +181,7 @@ def main_nmfd(a):
         'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), {title} beta={beta:g}',
         'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
+        'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}[a.precision],
         'data': 'synthetic',
         'config': {'workload': f'{title} beta={beta:g}',
                    'precision': a.precision, 'parallelism': 'single GPU (replicas only)',
@@ -326,7 +326,7 @@ def main_plca(a):
         'metric': f'EM GFLOP/s (algorithmic 6*N*C*R per iteration), PLCA {N}x{Cc} rank-{R}; EM iterations/s alongside',
         'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)',
+        'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}[a.precision],
         'data': 'synthetic',
         'config': {'workload': f'PLCA {N}x{Cc} rank={R} (SURVEY 8 row f4; shape of BASELINE configs[1])',
                    'precision': a.precision, 'parallelism': 'single GPU'},
@@ -455,7 +455,7 @@ def main():
         all_ms = spans.get('w', []) + spans.get('h', [])
         avg_ms = sum(all_ms) / len(all_ms)
         flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
-        elt = 2 if a.precision == 'bf16' else 4
+        elt = 4 if a.precision == 'bf16x3' else 2
         bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -496,7 +496,7 @@ def main():
             'value': round(total_gflops, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms_per_step, 2),
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if a.precision == 'bf16' else 'bf16x3 (split bf16, fp32-grade)', 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}[a.precision], 'data': 'synthetic',
             'config': {'workload': f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
                                    f'H replicated, 1 all-reduce/iter' if world > 1 else
                                    ('trainer.BetaMu.step on ' if betamu else '') +

@@ -40,6 +40,8 @@ extern "C" {
 /* precision of the MFMA operands (accumulation is always fp32, factors are kept in fp32) */
 #define NMFMU_PREC_BF16 0   /* X stored bf16; operands bf16                                   */
 #define NMFMU_PREC_BF16X3 1 /* X stored fp32; operands split hi+lo, 3 MFMAs per product        */
+#define NMFMU_PREC_F16 2    /* X stored fp16; operands fp16 (11 significant bits, same MFMA rate as bf16); values are
+                               clamped to +-65504.  beta == 1, padded rank <= 128 (ping-pong kernel, nmfmu_pp.h) */
 
 /* beta branches of nmf.py:61-74 / metrics.py:78-96 */
 #define NMFMU_BETA_KL 0  /* beta == 1 */

@@ -25,9 +25,11 @@ struct ApplyArgs {
   int trainer;
   float ortho;
   float* grad;          // [rows][rank] or nullptr
+  int f16;              // images in fp16 (clamped to 65504) instead of bf16; no lo planes
 };
 
-int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
+// fmt: 0 = bf16, 1 = fp32, 2 = fp16 (clamped to 65504)
+int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, int fmt, void* xp, int m_pad,
                   int k_pad, uint32_t* flags, int G, hipStream_t s);
 int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s);
 int launch_colsum_finalize(const float* part, int nblk, int r_pad, float* out, hipStream_t s);

@@ -6,18 +6,23 @@
 #include <algorithm>
 
 #include "nmfmu_aux.h"
-#include "nmfmu_fused.h"
+#include "nmfmu_pp.h"
 
 namespace nmfmu {
+
+__device__ __forceinline__ uint32_t pack_img(float a, float b, int f16) {
+  return f16 ? pack_f16(fminf(a, 65504.f), fminf(b, 65504.f)) : pack_bf16(a, b);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // pack_x: V fp32 (row-major, ld) -> fragment-order X (bf16 or fp32), zero padded.  One thread = one 16-byte chunk.
 // Fused with the validation passes of nmf.py:329-336 (any(v < 0 or NaN), min(v)).
 // ------------------------------------------------------------------------------------------------------------
-template <bool FP32, bool TRANSPOSE>
+template <int FMT, bool TRANSPOSE>
 __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
                                                      void* __restrict__ xp, int ktiles, int64_t nchunks,
                                                      uint32_t* flags, int G) {
+  constexpr bool FP32 = FMT == 1;
   constexpr int NQ = FP32 ? 8 : 4;
   constexpr int EPC = FP32 ? 4 : 8;
   const int M = TRANSPOSE ? cols : rows;  // owner axis length
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
       for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(uint32_t, e[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = pack_bf16(e[2 * i], e[2 * i + 1]);
+      for (int i = 0; i < 4; ++i) o[i] = pack_img(e[2 * i], e[2 * i + 1], FMT == 2);
     }
     reinterpret_cast<u32x4*>(xp)[c] = o;
   }
@@ -71,16 +76,19 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
   }
 }
 
-int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, bool fp32, void* xp, int m_pad,
+int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose, int fmt, void* xp, int m_pad,
                   int k_pad, uint32_t* flags, int G, hipStream_t s) {
+  const bool fp32 = fmt == 1;
   const int ktiles = k_pad / kBK;
   const int64_t nchunks = (int64_t)m_pad * k_pad * (fp32 ? 4 : 2) / 16;
   const int grid = (int)std::min<int64_t>((nchunks + 255) / 256, 256 * 32);
 #define L(F, T) hipLaunchKernelGGL((pack_x_kernel<F, T>), dim3(grid), dim3(256), 0, s, v, ld, rows, cols, xp, ktiles, nchunks, flags, G)
-  if (fp32 && transpose) L(true, true);
-  else if (fp32) L(true, false);
-  else if (transpose) L(false, true);
-  else L(false, false);
+  if (fp32 && transpose) L(1, true);
+  else if (fp32) L(1, false);
+  else if (fmt == 2 && transpose) L(2, true);
+  else if (fmt == 2) L(2, false);
+  else if (transpose) L(0, true);
+  else L(0, false);
 #undef L
   return (int)hipGetLastError();
 }
@@ -188,7 +196,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float x0 = src[2 * i], x1 = src[2 * i + 1];
-      const uint32_t h = pack_bf16(x0, x1);
+      const uint32_t h = pack_img(x0, x1, a.f16);
       hi[i] = h;
       lo[i] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
     }
@@ -204,7 +212,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float x0 = tile[(sl * 8 + 2 * i) * LDT + r], x1 = tile[(sl * 8 + 2 * i + 1) * LDT + r];
-      const uint32_t h = pack_bf16(x0, x1);
+      const uint32_t h = pack_img(x0, x1, a.f16);
       hi[i] = h;
       lo[i] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
     }

@@ -3,12 +3,14 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
 #include "../../include/nmfmu.h"
 #include "nmfmu_aux.h"
 #include "nmfmu_fused.h"
+#include "nmfmu_pp.h"
 
 using namespace nmfmu;
 
@@ -17,6 +19,27 @@ namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static bool stage_is_reg(const nmfmu_step* st) { return st->stage == NMFMU_STAGE_REG; }
+
+// Experiment hooks (read once): NMFMU_PP=0 routes beta = 1 / bf16 half-steps back to the four-wave kernels of
+// nmfmu_fused.h; NMFMU_PP_VAR selects a build-time variant of the ping-pong kernel (nmfmu_pp.h, VAR bits).
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+static int pp_enabled() {
+  static const int v = env_int("NMFMU_PP", 1);
+  return v;
+}
+static int pp_var() {
+  static const int v = env_int("NMFMU_PP_VAR", 0);
+  return v;
+}
+// which half-steps the ping-pong kernel serves: beta == 1, one operand plane (bf16 or fp16), padded rank <= 128
+static bool pp_eligible(int r_pad, int precision, float beta) {
+  if (nmfmu_beta_kind(beta) != NMFMU_BETA_KL || r_pad > 128) return false;
+  if (precision == NMFMU_PREC_F16) return true;
+  return precision == NMFMU_PREC_BF16 && pp_enabled();
+}
 
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
                    const float* fuse_kl_den = nullptr) {
@@ -67,6 +90,12 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   }
   const int grid = (st->owner.rows_pad / st->block_rows) * st->nsplit;
   const int stage = st->stage == NMFMU_STAGE_REG ? 0 : 1;
+  if (G == 2 && stage == 1 && st->xp && (mode == kModeMU || mode == kModeLoss) &&
+      pp_eligible(st->r_pad, st->precision, st->beta)) {
+    const int opt = st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16;
+    return launch_pp(st->r_pad, opt, mode, mode == kModeMU ? pp_var() : 0, a, grid, s);
+  }
+  if (st->precision == NMFMU_PREC_F16) return NMFMU_ERR_UNSUPPORTED;   // fp16 operands exist in the ping-pong kernel only
   switch (st->r_pad) {
     case 32: return launch_fused_r32(kind, x3, mode, stage, G, a, grid, s);
     case 64: return launch_fused_r64(kind, x3, mode, stage, G, a, grid, s);
@@ -100,18 +129,18 @@ int nmfmu_supported(int r_pad, int precision) {
   if (r_pad != 32 && r_pad != 64 && r_pad != 128 && r_pad != 256) return 0;
   if (precision == NMFMU_PREC_BF16) return 1;
   if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
+  if (precision == NMFMU_PREC_F16) return r_pad <= 128;     // ping-pong kernel only (beta == 1)
   return 0;
 }
 
 int nmfmu_block_rows(int r_pad, int precision, float beta) {
-  // 128-row tiles (two workgroups per CU, two waves per SIMD) measure faster than the 256-row variant (one wave per
-  // SIMD, every LDS operand read shared by two MFMAs) on MI355X today: 0.154 vs 0.179 ms per half-step at
-  // 4096x65536 r128.  The 256-row kernels stay built and selectable (block_rows = 256) where has_g2() holds.
+  // beta == 1 with one operand plane and padded rank <= 128: the eight-wave ping-pong kernel on 256-row tiles.
+  // Everything else: 128-row tiles (two workgroups per CU) measure faster than the four-wave 256-row variant
+  // (0.154 vs 0.179 ms per half-step at 4096x65536 r128); those stay built and selectable where has_g2() holds.
+  if (pp_eligible(r_pad, precision, beta)) return 256;
 #if NMFMU_SP
-  // the eight-wave software-pipelined kernel works on 256-row tiles (beta == 1, bf16, padded rank 128)
   if (r_pad == 128 && precision == NMFMU_PREC_BF16 && nmfmu_beta_kind(beta) == NMFMU_BETA_KL) return 256;
 #endif
-  (void)r_pad, (void)precision, (void)beta;
   return 128;
 }
 
@@ -128,9 +157,10 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
 }
 
 int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu) {
-  // A half-step whose owner axis alone fills the chip with 128-row workgroups (no contraction split) keeps the
-  // 128-row tile: the MU apply then runs in the epilogue, which measures faster at two workgroups per CU
-  // (0.172 vs 0.178 ms at configs[1]'s W half-step).  Split half-steps take nmfmu_block_rows()'s tile.
+  if (pp_eligible(r_pad, precision, beta)) return 256;   // both half-steps (the apply is fused there as well)
+  // Four-wave kernels: a half-step whose owner axis alone fills the chip with 128-row workgroups (no contraction
+  // split) keeps the 128-row tile: the MU apply then runs in the epilogue, which measures faster at two workgroups
+  // per CU (0.172 vs 0.178 ms at configs[1]'s W half-step).  Split half-steps take nmfmu_block_rows()'s tile.
   const int ns128 = nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, 128, num_cu);
   if (ns128 < 0) return ns128;
   return ns128 == 1 ? 128 : nmfmu_block_rows(r_pad, precision, beta);
@@ -150,8 +180,9 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
   if (!v || !xp || rows <= 0 || cols <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int m = transpose ? cols : rows, k = transpose ? rows : cols;
   if (owner_rows_pad != pad_rows(m) || panel_rows_pad != pad_rows(k)) return NMFMU_ERR_ARG;
-  return launch_pack_x(v, ld, rows, cols, transpose != 0, precision == NMFMU_PREC_BF16X3, xp, owner_rows_pad,
-                       panel_rows_pad, flags, block_rows / 128, S(stream));
+  const int fmt = precision == NMFMU_PREC_BF16X3 ? 1 : (precision == NMFMU_PREC_F16 ? 2 : 0);
+  return launch_pack_x(v, ld, rows, cols, transpose != 0, fmt, xp, owner_rows_pad, panel_rows_pad, flags,
+                       block_rows / 128, S(stream));
 }
 
 static int pack_factor_common(const nmfmu_factor* fac, int rank, int r_pad, int precision, const float* scale,
@@ -167,6 +198,7 @@ static int pack_factor_common(const nmfmu_factor* fac, int rank, int r_pad, int 
   a.rows = fac->rows, a.rank = rank, a.rows_pad = fac->rows_pad;
   a.gamma = 1.f;
   a.scale = scale;
+  a.f16 = precision == NMFMU_PREC_F16;
   return launch_apply(r_pad, a, x3, /*pack_only=*/true, S(stream));
 }
 
@@ -241,6 +273,7 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
   a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   a.trainer = trainer, a.ortho = ortho, a.grad = grad;
+  a.f16 = st->precision == NMFMU_PREC_F16;
   if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
 }

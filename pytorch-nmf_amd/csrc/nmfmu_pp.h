@@ -1,0 +1,558 @@
+// Ping-pong form of the fused beta = 1 MU half-step for gfx950 (MI355X, CDNA4).
+//
+// Same mathematics, data layouts and epilogues as nmfmu::fused_kernel (nmfmu_fused.h; reference seam nmf.py:376-378 /
+// 389-391 + nmf.py:61-74, 122-131), different execution structure.  The four-wave kernel runs every wave through
+// GEMM1 -> elementwise -> GEMM2 in the same phase, so matrix-pipe time and VALU / memory-issue time ADD.  Here a
+// workgroup is EIGHT waves -- two per SIMD (waves i and i+4 share SIMD i) -- and the two halves run the same
+// instruction stream ONE SEGMENT APART:
+//
+//   segment   s = 2t          2t+1          2t+2          2t+3
+//   waves 0-3 M(t)           E(t)          M(t+1)        E(t+1)
+//   waves 4-7 E(t-1)         M(t)          E(t)          M(t+1)
+//
+//   M(t) "matrix segment": G1(t) = S^T tiles of k-tile t (16 MFMA at rank pad 128), then G2(t-1) = numerator update
+//        with the ratios of the previous tile (16 MFMA); fillers are only the LDS operand reads (1 per MFMA).
+//   E(t) "elementwise segment": ratios Gn = X / (S + eps) -> packed 16-bit operands (VALU), the LDS-DMA of the panel
+//        tiles three k-tiles ahead and the X loads two k-tiles ahead (VMEM issue), the first operand reads of the
+//        next M segment.
+//
+// One raw s_barrier separates the segments, so a SIMD's matrix pipe always has exactly one wave feeding it while the
+// partner wave does everything that is slow to issue (MI355X_MICROARCH.md, "Two waves per SIMD").  Nothing is
+// exchanged between the waves: each wave owns 32 owner rows, its S tile, ratios and numerator accumulators stay in
+// its registers exactly as in the four-wave kernel.
+//
+// Memory pipeline (everything arrives by LDS-DMA issued from inline asm, so hipcc neither counts nor drains it):
+//   panel images P1 / P2 : three-slot rings; waves 0-3 issue P1(t+2) and P2(t+1) in their E(t) and wait for them with
+//                          a COUNTED vmcnt at the end of their next M segment -- one barrier before anybody (the
+//                          operand prefetch of E(t+1)) reads them.  Waves 4-7 issue no panel traffic: their segments
+//                          are one barrier later, which would be one barrier too late for waves 0-3.
+//   X                    : two-slot ring of 256 x 64 tiles (fragment order of nmfmu_layout.h, so a wave's share is one
+//                          contiguous 4 KiB piece that only this wave ever reads: no cross-wave hazard, no barrier);
+//                          X(t+2) issued at the end of E(t) once the wave has read X(t).
+//   the only vmcnt in the loop is `vmcnt(4)` at the end of every M segment: it leaves exactly the wave's four youngest
+//   DMAs (its X piece two tiles ahead) in flight.
+//
+// Operand types: bf16 (as nmfmu_fused.h) or fp16 -- same MFMA rate, 11 instead of 8 significant bits, which is what
+// brings the factors within 1e-4 of the fp32 reference at the BASELINE shapes.  In fp16 mode X
+// is stored fp16 and the ratio is ONE v_fma_mix_f32 per element (fp16 source half selected by op_sel); MODE.FP16_OVFL
+// is set so that an overflowing ratio saturates at 65504 instead of becoming inf.
+#pragma once
+#include "nmfmu_fused.h"
+
+namespace nmfmu {
+
+enum OperandType : int { kOpBf16 = 0, kOpF16 = 1 };
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+template <int OPT>
+__device__ __forceinline__ f32x16 mfma_op(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (OPT == kOpF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return mfma_bf16(a, b, c);
+}
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 r = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE; saturates under MODE.FP16_OVFL)
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <int OPT>
+__device__ __forceinline__ uint32_t pack_op(float a, float b) {
+  if constexpr (OPT == kOpF16) return pack_f16(a, b);
+  else return pack_bf16(a, b);
+}
+template <int OPT>
+__device__ __forceinline__ float unpack_lo(uint32_t w) {
+  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[0];
+  else return bf16_lo(w);
+}
+template <int OPT>
+__device__ __forceinline__ float unpack_hi(uint32_t w) {
+  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[1];
+  else return bf16_hi(w);
+}
+
+// VAR bits (build-time experiment switches, selected per launch through FusedArgs-independent dispatch):
+//   1: s_setprio 1 for the matrix segments      2: static s_setprio 1 for the younger half (waves 4-7)
+//   4: LDS-DMA issued after the elementwise work instead of before it
+template <int R_PAD, int OPT, int MODE, int VAR>
+struct PPCfg {
+  static constexpr int BM = 256, WAVES = 8, THREADS = 512;
+  static constexpr int KS = R_PAD / 16;      // k-steps of G1 (contraction over rank)
+  static constexpr int RT = R_PAD / 32;      // 32-wide rank tiles of G2's output
+  static constexpr int ROWB = 2 * R_PAD;     // bytes per P1 row
+  static constexpr int IMG = kBK * ROWB;     // bytes of one image tile
+  static constexpr bool LOSS = MODE == kModeLoss;
+  static constexpr int NSLOT = 3, LEAD = 2;  // panel ring depth; P1 runs LEAD tiles ahead, P2 LEAD - 1
+  static constexpr int XTILE = BM * kBK * 2; // one X tile: 256 rows x 64 columns x 2 bytes = 32 KiB
+  static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = 2 * NSLOT * IMG;
+  static constexpr int LDS_MAIN = X_BASE + 2 * XTILE;
+  static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
+  static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
+  static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
+  static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
+  static constexpr int PF = 4;                               // operand prefetch ring depth
+  static constexpr bool SCALED = OPT == kOpBf16;             // S' = 2^23 (S + eps), seeded with the inline constant 1.0
+  static_assert(NSTEP1 >= PF, "ring deeper than G1");
+};
+
+template <int R_PAD, int OPT, int MODE, int VAR>
+__global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
+  using C = PPCfg<R_PAD, OPT, MODE, VAR>;
+  constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, PF = C::PF;
+  constexpr int NSTEP1 = C::NSTEP1, NSTEP2 = C::NSTEP2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;
+  const int j = lane & 31;   // MFMA column = owner row within the wave's 32
+  const int hl = lane >> 5;  // lane half
+  const int mb = blockIdx.x / a.nsplit;
+  const int ks = blockIdx.x - mb * a.nsplit;
+  const int t0 = ks * a.tiles_per_split;
+  const int t1 = min(t0 + a.tiles_per_split, a.ktiles);
+  const int nt = t1 - t0;
+  const int m0 = mb * C::BM + wave * 32 + j;
+
+  if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: saturate
+
+  // ---- owner fragments (B operand of G1): row m0, rank slice 16*kk + 8*hl .. +7
+  // bf16: the fragments are scaled by 2^23 = 1 / eps (exact), so that the "+ eps" of nmf.py:65 becomes "+ 1.0" -- an
+  // MFMA inline constant -- on S' = 2^23 (S + eps); the ratios and the numerators then carry the factor 2^-23, which
+  // the epilogue removes (exact again).  This frees the sixteen registers a broadcast eps tile would occupy.
+  // fp16 has no exponent range for that: it seeds the accumulators from a register tile of eps.
+  constexpr bool SCALED = C::SCALED;
+  u32x4 q[KS];
+  {
+    const int sw = ((m0 >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    const char* row = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m0 * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      q[kk] = ld16(row + ((kk * 32 + hl * 16) ^ sw));
+      if constexpr (SCALED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[kk][i] = pack_bf16(bf16_lo(q[kk][i]) * 8388608.f, bf16_hi(q[kk][i]) * 8388608.f);
+      }
+    }
+  }
+  // ---- per-lane LDS offsets (same maps as nmfmu_fused.h: row permutation pi for G1, swizzled 16-byte slots).
+  // G1 operand of step (tt, kk): a_base[tt] ^ (kk * 32)  -- the k-step only flips bits 5..7 of the slot offset, which
+  // neither the row part (a multiple of ROWB) nor the ring-slot offset (a multiple of IMG) touches, so ONE register per
+  // S^T tile plus an inline-constant XOR replaces sixteen precomputed addresses.
+  // G2 operand of step (rt, tt, m2): b_base[tt][m2] + rt * 4096 (immediate).
+  int a_base[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int row = 32 * ((j >> 2) & 1) + 16 * tt + (j & 3) + 4 * (j >> 3);
+    const int sw = ((row >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    a_base[tt] = row * ROWB + ((hl * 16) ^ sw);
+  }
+  int b_base[2][2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) b_base[tt][m2] = j * 128 + (((4 * hl + 2 * tt + m2) << 4) ^ (((j >> 1) & 7) << 4));
+  static_assert((KS - 1) * 32 < ROWB, "k-step bits stay inside one P1 row");
+
+  f32x16 acc[C::LOSS ? 1 : RT];
+#pragma unroll
+  for (int rt = 0; rt < (C::LOSS ? 1 : RT); ++rt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+  f32x16 epsv;   // accumulator seed: eps, or the constant 1.0 (which hipcc folds into the MFMA's C operand)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) epsv[e] = SCALED ? 1.0f : kEps;
+  float lacc = 0.f;
+
+  if (nt > 0) {
+    // ---- address generators.  All bases are wave-uniform (SGPR); the per-lane part is a 32-bit offset.
+    const unsigned lds_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const char* xsrc = reinterpret_cast<const char*>(a.xp) + ((size_t)mb * a.ktiles + t0) * (size_t)C::XTILE +
+                       (size_t)wave * 4096;
+    const char* p1src = reinterpret_cast<const char*>(a.p1_hi) + (size_t)t0 * IMG;
+    const char* p2src = reinterpret_cast<const char*>(a.p2_hi) + (size_t)t0 * IMG;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned pvoff = (unsigned)(wave & 3) * 1024u + lane16;   // panel DMA: piece = (wave & 3) + 4 i
+    auto clampt = [&](int t) { return t < nt ? t : nt - 1; };   // tail prefetches re-read the last tile (never used)
+    auto dma1k = [&](const char* src, unsigned voff, unsigned lds_addr) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(voff), "s"(src), "s"(lds_addr)
+                   : "memory", "m0");
+    };
+    // one image tile = NPIECE 1-KiB pieces; issuing wave w (0..3) moves pieces (w + 4 i) mod NPIECE (when NPIECE < 4
+    // the duplicates rewrite the same bytes; they keep every issuing wave's vmcnt arithmetic identical)
+    auto dma_img = [&](const char* src_tile, unsigned lds_off) {
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) {
+        const unsigned pc = (4u * i) % (unsigned)C::NPIECE;       // compile-time part of the piece index
+        const unsigned wpart = C::NPIECE >= 4 ? 0u : 0u;
+        (void)wpart;
+        if constexpr (C::NPIECE >= 4)
+          dma1k(src_tile + pc * 1024u, pvoff, lds_base + lds_off + pc * 1024u + (unsigned)(wave & 3) * 1024u);
+        else
+          dma1k(src_tile, ((unsigned)(wave & 3) % (unsigned)C::NPIECE) * 1024u + lane16,
+                lds_base + lds_off + ((unsigned)(wave & 3) % (unsigned)C::NPIECE) * 1024u);
+      }
+    };
+    // ring slots advance by one per tile: offsets are carried incrementally (no division in the loop)
+    unsigned p1_issue_off = (unsigned)(C::LEAD % C::NSLOT) * IMG;         // slot of P1(t + LEAD) at t = 0
+    unsigned p2_issue_off = (unsigned)((C::LEAD - 1) % C::NSLOT) * IMG;   // slot of P2(t + LEAD - 1) at t = 0
+    auto next_off = [&](unsigned off) { return off == (unsigned)(C::NSLOT - 1) * IMG ? 0u : off + IMG; };
+    auto issue_panel = [&](int t) {   // called in E(t) by waves 0-3: P1(t + LEAD), P2(t + LEAD - 1)
+      dma_img(p1src + (size_t)clampt(t + C::LEAD) * IMG, C::P1_BASE + p1_issue_off);
+      if constexpr (!C::LOSS) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
+    };
+    auto issue_x = [&](int t) {       // this wave's 4 KiB of X(t) -> X ring slot t & 1
+      const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
+      const unsigned dst = lds_base + C::X_BASE + (unsigned)(t & 1) * C::XTILE + (unsigned)wave * 4096u;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) dma1k(src + qq * 1024, lane16, dst + qq * 1024u);
+    };
+    auto barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    uint32_t gn[2][8];
+    f32x16 S[2];
+    u32x4 ring[PF];
+
+    // operand stream of one M segment: entries 0 .. NSTEP1-1 are G1's panel rows (P1 slot of tile t), entries
+    // NSTEP1 .. NSTEP1+NSTEP2-1 G2's transposed panel slices (P2 slot of tile t-1).  `sa` / `sb` are the per-lane bases
+    // with the ring-slot offset already added (loop variant, so nothing here is hoisted out of the tile loop).
+    // They start at the slot of tile 0 (P1) / tile -1 (P2) and are advanced in place by +IMG or -(NSLOT-1)*IMG once per
+    // tile (advance_slots), so the lane-only parts a_base / b_base are dead after this point.
+    int sa[2] = {a_base[0] + C::P1_BASE, a_base[1] + C::P1_BASE};
+    int sb[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] = b_base[tt][m2] + C::P2_BASE + (C::NSLOT - 1) * IMG;
+    int rd1 = 0, rd2 = (C::NSLOT - 1) * IMG;   // current slot offsets of sa / sb (uniform)
+    auto advance_slots = [&]() {   // sa -> P1 slot of the next tile, sb -> P2 slot of the tile before it
+      const int d1 = rd1 == (C::NSLOT - 1) * IMG ? -(C::NSLOT - 1) * IMG : IMG;
+      const int d2 = rd2 == (C::NSLOT - 1) * IMG ? -(C::NSLOT - 1) * IMG : IMG;
+      rd1 += d1, rd2 += d2;
+      sa[0] += d1, sa[1] += d1;
+      if constexpr (!C::LOSS) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] += d2;
+      }
+    };
+    // The M segment is written instruction by instruction (asm volatile keeps the order): hipcc's scheduler re-orders a
+    // builtin MFMA / ds_read stream and degrades the counted LDS waits to lgkmcnt(0).  Entry e of the operand stream
+    // lives in ring[e % PF]; LDS returns in order, so "entry e has landed" = at most min(PF-1, NS-1-e) younger reads
+    // outstanding.
+    auto rd = [&](u32x4& dst, int addr, auto offc) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+    };
+    auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read of stream entry e
+      constexpr int e0 = decltype(ec)::value;
+      constexpr bool g1 = decltype(g1c)::value;
+      if constexpr (g1 && e0 < NSTEP1) {
+        rd(dst, sa[e0 & 1] ^ ((e0 >> 1) * 32), std::integral_constant<int, 0>{});
+      } else {
+        constexpr int e = e0 - (g1 ? NSTEP1 : 0);
+        constexpr int rt = e % RT, c = e / RT;
+        rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
+      }
+    };
+    auto prefetch = [&](auto g1c) {   // first PF operands of the next M segment; issued in the preceding E segment
+      static_for<PF>([&](auto pc) { opnd(ring[decltype(pc)::value], pc, g1c); });
+    };
+    auto mma = [&](f32x16& d, const u32x4& x, const u32x4& y) {
+      if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
+    };
+    // M(t): G1(t) if g1, then G2(t-1) if g2; ends with the counted wait for the panel DMA of the previous E segment
+    auto matrix_segment = [&](auto g1c, auto g2c) {
+      constexpr bool g1 = decltype(g1c)::value, g2 = decltype(g2c)::value && !C::LOSS;
+      constexpr int N1 = g1 ? NSTEP1 : 0, N2 = g2 ? NSTEP2 : 0, NS = N1 + N2;
+      if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
+      static_for<NS>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr int younger = (NS - 1 - e) < (PF - 1) ? (NS - 1 - e) : (PF - 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        u32x4& op = ring[e % PF];
+        if constexpr (e < N1) {
+          constexpr int tt = e & 1, kk = e >> 1;
+          if constexpr (kk == 0) {   // accumulator seed: the inline constant 1.0 (bf16, scaled) or the eps tile
+            if constexpr (SCALED)
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=v"(S[tt]) : "v"(op), "v"(q[0]));
+            else
+              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
+          } else {
+            mma(S[tt], op, q[kk]);
+          }
+        } else {
+          constexpr int s2 = e - N1;
+          constexpr int rt = s2 % RT, c = s2 / RT, tt = c >> 1, m2 = c & 1;
+          const u32x4 nh = {gn[tt][4 * m2], gn[tt][4 * m2 + 1], gn[tt][4 * m2 + 2], gn[tt][4 * m2 + 3]};
+          mma(acc[rt], nh, op);
+        }
+        if constexpr (e + PF < NS) opnd(ring[e % PF], std::integral_constant<int, e + PF>{}, g1c);
+      });
+      if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    // E(t): ratios of tile t from S and X(t); operand prefetch for the next M segment, panel DMA (waves 0-3) and this
+    // wave's X piece two tiles ahead
+    auto elementwise_segment = [&](int t, auto nextc) {
+      constexpr bool next_has_g1 = decltype(nextc)::value;
+      u32x4 x[4];
+      {
+        const char* xl = smem + C::X_BASE + (t & 1) * C::XTILE + wave * 4096 + lane * 16;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) x[qq] = ld16(xl + qq * 1024);
+      }
+      advance_slots();
+      if constexpr (next_has_g1) prefetch(std::true_type{});
+      else if constexpr (!C::LOSS) prefetch(std::false_type{});
+      if constexpr (!(VAR & 4)) {
+        if (!half) issue_panel(t);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        if constexpr (C::LOSS) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
+            const float x0 = unpack_lo<OPT>(w), x1 = unpack_hi<OPT>(w);
+            const int k0 = (t0 + t) * kBK + 32 * hl + 16 * tt + 2 * d;
+            const bool rowok = m0 < a.M;
+            constexpr float un = SCALED ? 1.1920928955078125e-07f : 1.f;
+            lacc += (rowok && k0 < a.K) ? loss_elem<kKL>(S[tt][2 * d] * un, x0, 1.f) : 0.f;
+            lacc += (rowok && k0 + 1 < a.K) ? loss_elem<kKL>(S[tt][2 * d + 1] * un, x1, 1.f) : 0.f;
+          }
+        } else if constexpr (OPT == kOpF16) {
+          // four elements per statement: 4 x v_rcp_f32, 4 x v_fma_mix_f32 (fp16 half of the X word x fp32
+          // reciprocal), 2 x v_cvt_pk_f16_f32.  Written as one asm block so that every reciprocal is at least one
+          // instruction away from its consumer (trans -> VALU forwarding hazard) without hipcc's padding.
+#pragma unroll
+          for (int d = 0; d < 8; d += 2) {
+            const uint32_t w0 = x[2 * tt + (d >> 2)][d & 3], w1 = x[2 * tt + (d >> 2)][(d & 3) + 1];
+            float r0, r1, r2, r3;
+            uint32_t g0, g1;
+            asm("v_rcp_f32 %2, %6\n\t"
+                "v_rcp_f32 %3, %7\n\t"
+                "v_rcp_f32 %4, %8\n\t"
+                "v_rcp_f32 %5, %9\n\t"
+                "v_fma_mix_f32 %2, %10, %2, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %3, %10, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %4, %11, %4, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %5, %11, %5, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                "v_cvt_pk_f16_f32 %1, %4, %5"
+                : "=&v"(g0), "=&v"(g1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(w0),
+                  "v"(w1));
+            gn[tt][d] = g0;
+            gn[tt][d + 1] = g1;
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
+            const float n0 = bf16_lo(w) * __builtin_amdgcn_rcpf(S[tt][2 * d]);
+            const float n1 = bf16_hi(w) * __builtin_amdgcn_rcpf(S[tt][2 * d + 1]);
+            gn[tt][d] = pack_bf16(n0, n1);
+          }
+        }
+      }
+      if constexpr (VAR & 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!half) issue_panel(t);
+      }
+      p1_issue_off = next_off(p1_issue_off);
+      p2_issue_off = next_off(p2_issue_off);
+      __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
+      issue_x(t + 2);                      // ... before its slot is refilled
+    };
+
+    // ---- prologue: P1(0), P1(1), P2(0), X(0), X(1); everything landed before the first barrier
+    if (!half) {
+#pragma unroll
+      for (int i = 0; i < C::LEAD; ++i) dma_img(p1src + (size_t)clampt(i) * IMG, C::P1_BASE + i * IMG);
+      if constexpr (!C::LOSS) {
+#pragma unroll
+        for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
+      }
+    }
+    issue_x(0);
+    issue_x(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (VAR & 2) {
+      if (half) __builtin_amdgcn_s_setprio(1);
+    }
+    barrier();
+    prefetch(std::true_type{});
+    if (half) barrier();                       // waves 4-7 run one segment behind
+    matrix_segment(std::true_type{}, std::false_type{});
+    // (the last tile is peeled: one join of two differently-shaped M segments inside the loop would cost a register
+    // copy of every accumulator per tile)
+    for (int t = 0; t + 1 < nt; ++t) {
+      barrier();
+      elementwise_segment(t, std::true_type{});
+      barrier();
+      matrix_segment(std::true_type{}, std::true_type{});
+    }
+    barrier();
+    elementwise_segment(nt - 1, std::false_type{});
+    barrier();
+    matrix_segment(std::false_type{}, std::true_type{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read of the accumulators (asm MFMAs are not padded)
+    if (!half) barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches: nothing may land in LDS after this
+    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
+  }
+  __syncthreads();               // LDS is reused by the epilogue
+
+  // The epilogue re-derives its lane coordinates from a laundered copy of the thread id: otherwise hipcc hoists the
+  // epilogue's address arithmetic above the main loop and keeps it live across it (the loop has no registers to spare).
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, j_e = lane_e & 31, hl_e = lane_e >> 5;
+  // ---------------- epilogue (same register -> element map as nmfmu_fused.h: accumulator register e of lane_e (j_e, hl_e)
+  // is row (e&3) + 8*(e>>2) + 4*hl_e, column 32*rt + j_e)
+  if constexpr (C::LOSS) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lacc += __shfl_xor(lacc, o, 64);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane_e == 0) red[wave] = lacc;
+    __syncthreads();
+    if (tid_e == 0)
+      a.loss_part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  } else {
+    if constexpr (SCALED) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][e] *= 8388608.f;
+    }
+    const int mrow0 = mb * C::BM + wave * 32;   // first owner row of this wave
+    if (a.fuse_apply) {
+      // ---- nmf.py:78-92 in the epilogue (nsplit == 1: the workgroup owns complete rows); re-emits the owner's images
+      constexpr int LDT = R_PAD;
+      float* tile = reinterpret_cast<float*>(smem) + wave * (32 * LDT);
+      float den[RT], csum[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        den[rt] = a.kl_den[rt * 32 + j_e];
+        csum[rt] = 0.f;
+      }
+      static_for<RT>([&](auto rtc) {
+        constexpr int rt = decltype(rtc)::value;
+        const int r = rt * 32 + j_e;
+        float fold[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl_e;
+          fold[e] = (row < a.M && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl_e;
+          float fv = fold[e];
+          if (row < a.M && r < a.rank) {
+            const float neg = fmaxf(acc[rt][e], 0.f) + kEps;
+            float pos = den[rt];
+            if (a.l1 > 0.f) pos += a.l1;
+            if (a.l2 > 0.f) pos += a.l2 * fv;
+            float mult = neg / pos;
+            if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+            fv *= mult;
+            a.f[(size_t)row * a.rank + r] = fv;
+          }
+          fold[e] = fv;
+          csum[rt] += fv;
+          tile[((e & 3) + 8 * (e >> 2) + 4 * hl_e) * LDT + r] = fv;
+        }
+        // transposed image: 4 consecutive owner rows of column r = 8 bytes
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const uint32_t h0 = pack_op<OPT>(fold[4 * q4], fold[4 * q4 + 1]);
+          const uint32_t h1 = pack_op<OPT>(fold[4 * q4 + 2], fold[4 * q4 + 3]);
+          const int64_t off = p2_offset(mrow0 + 8 * q4 + 4 * hl_e, r, R_PAD);
+          *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.o2_hi) + off) = make_uint2(h0, h1);
+        }
+      });
+      __syncthreads();
+      // row-major image from the LDS tile: 32 rows x R_PAD/8 sixteen-byte slots per wave
+      constexpr int SP = R_PAD / 8;
+#pragma unroll
+      for (int i = 0; i < (32 * SP) / 64; ++i) {
+        const int chunk = i * 64 + lane_e, rl = chunk / SP, slot = chunk % SP;
+        const float* src = tile + rl * LDT + slot * 8;
+        u32x4 hi;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(src[2 * qq], src[2 * qq + 1]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(mrow0 + rl, slot * 8, R_PAD)) = hi;
+      }
+      __syncthreads();
+      // partial column sums of this workgroup's rows: lane_e halves, then the waves (fixed order)
+      float* red = reinterpret_cast<float*>(smem);  // [WAVES][R_PAD]
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float tot = csum[rt] + __shfl_xor(csum[rt], 32, 64);
+        if (hl_e == 0) red[wave * R_PAD + rt * 32 + j_e] = tot;
+      }
+      __syncthreads();
+      for (int r = tid_e; r < R_PAD; r += C::THREADS) {
+        float tot = (red[r] + red[R_PAD + r]) + (red[2 * R_PAD + r] + red[3 * R_PAD + r]);
+        tot += (red[4 * R_PAD + r] + red[5 * R_PAD + r]) + (red[6 * R_PAD + r] + red[7 * R_PAD + r]);
+        a.colsum_part[(size_t)mb * R_PAD + r] = tot;
+      }
+    } else {
+      const size_t slab = ((size_t)ks * a.M_pad + (size_t)mrow0) * R_PAD;
+      static_for<RT>([&](auto rtc) {
+        constexpr int rt = decltype(rtc)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * hl_e;
+          a.slab_num[slab + (size_t)row * R_PAD + rt * 32 + j_e] = acc[rt][e];
+        }
+      });
+    }
+  }
+}
+
+// per-device "attribute set" memo (one host thread may drive several devices)
+inline bool* attr_flag(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return &flags[dev];
+}
+
+template <int R_PAD, int OPT, int MODE, int VAR>
+int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
+  using C = PPCfg<R_PAD, OPT, MODE, VAR>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
+  auto kern = pp_kernel<R_PAD, OPT, MODE, VAR>;
+  static bool done[64] = {};
+  bool* flag = attr_flag(done);
+  if (!*flag) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    *flag = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, a);
+  return (int)hipGetLastError();
+}
+
+// Host-side launcher (nmfmu_inst_pp.hip).  opt = OperandType, mode = kModeMU | kModeLoss, var = experiment bits.
+int launch_pp(int r_pad, int opt, int mode, int var, const FusedArgs& a, int grid, hipStream_t s);
+bool pp_available(int r_pad, int opt, int mode);
+
+}  // namespace nmfmu

@@ -17,11 +17,11 @@ LIB_PATH = os.environ.get('NMFMU_LIB') or os.path.join(os.path.dirname(os.path.a
 OK = 0
 ERR_UNSUPPORTED = -2
 ERR_ARG = -3
-PREC_BF16, PREC_BF16X3 = 0, 1
+PREC_BF16, PREC_BF16X3, PREC_F16 = 0, 1, 2
 STAGE_REG, STAGE_DMA = 0, 1
 BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
 
-PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
+PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16}
 
 
 class NmfmuError(RuntimeError):

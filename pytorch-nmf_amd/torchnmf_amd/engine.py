@@ -240,6 +240,9 @@ class DenseMU:
         self.precision = _capi.PRECISIONS[precision]
         if not self.be.supported(self.r_pad, self.precision):
             raise NotImplementedError(f'precision {precision!r} is not available for rank {R} (padded {self.r_pad})')
+        if precision == 'f16' and not self.kl:
+            raise NotImplementedError("precision 'f16' (fp16 operands, ping-pong kernel) is built for beta == 1 only; "
+                                      "use 'bf16x3' (fp32-grade) or 'bf16' for other beta")
         if stage is None:
             stage = _capi.STAGE_DMA
         gamma = mu_gamma(self.beta)

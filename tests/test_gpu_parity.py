@@ -68,7 +68,7 @@ def test_probe_lds_dma_is_lane_linear(dev):
 # ----------------------------------------------------------------------------------------------------------
 # packing layouts
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('prec', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['bf16', 'bf16x3', 'f16'])
 @pytest.mark.parametrize('transpose', [False, True])
 @pytest.mark.parametrize('block_rows', [128, 256])
 def test_pack_x_layout_and_flags(dev, prec, transpose, block_rows):
@@ -85,7 +85,7 @@ def test_pack_x_layout_and_flags(dev, prec, transpose, block_rows):
     xp = be.pack_x(V.to(dev), transpose, _capi.PRECISIONS[prec], block_rows, m_pad, k_pad, flags)
     torch.cuda.synchronize()
     fp32 = prec == 'bf16x3'
-    got = (xp.view(torch.float32) if fp32 else xp.view(torch.bfloat16).float()).cpu().numpy()
+    got = (xp.view(torch.float32) if fp32 else xp.view(torch.float16 if prec == 'f16' else torch.bfloat16).float()).cpu().numpy()
     X = (V.t() if transpose else V).numpy()
     want = np.zeros(m_pad * k_pad, dtype=np.float32)
     mm, kk = np.meshgrid(np.arange(M), np.arange(K), indexing='ij')
@@ -190,6 +190,95 @@ def test_half_steps_bf16(dev, beta, stage, block_rows):
     Hr = O.nmf_h_step(V, Wr, H0, beta, gam)
     assert rel_err(W1, Wr) < 5e-3 and rel_err(H1, Hr) < 5e-3, (rel_err(W1, Wr), rel_err(H1, Hr))
     assert l0 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(H0, W0), V, beta)), rel=2e-3)
+
+
+@pytest.mark.parametrize('rank', [5, 40, 100])
+def test_pack_factor_images_f16(dev, rank):
+    """fp16 images (precision 'f16'): same P1 / P2 layouts, values rounded to fp16 (RNE) and clamped to 65504."""
+    from test_layout_emulation import p1_offset, p2_offset
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import FactorBuf, HipBackend
+    be = HipBackend()
+    g = torch.Generator().manual_seed(rank)
+    F = torch.rand(130, rank, generator=g)
+    F[0, 0], F[1, 0], F[2, 0] = 1e5, 3e-6, 0.0        # clamps to 65504, fp16 subnormal, zero
+    r_pad = be.pad_rank(rank)
+    fb = FactorBuf(F.to(dev).contiguous(), r_pad, _capi.PREC_F16, be)
+    be.pack_factor(fb, rank, r_pad, _capi.PREC_F16)
+    torch.cuda.synchronize()
+    want = F.clamp(max=65504.0).half().float()
+    p1 = fb.p1_hi.view(torch.float16).float().cpu().numpy()
+    p2 = fb.p2_hi.view(torch.float16).float().cpu().numpy()
+    w1 = np.zeros_like(p1); w2 = np.zeros_like(p1)
+    for row in range(130):
+        for r in range(rank):
+            w1[p1_offset(row, r, r_pad)] = want[row, r]
+            w2[p2_offset(row, r, r_pad)] = want[row, r]
+    np.testing.assert_array_equal(p1, w1)
+    np.testing.assert_array_equal(p2, w2)
+
+
+@pytest.mark.parametrize('shape', [(384, 1100, 64), (520, 2300, 100), (200, 330, 24), (300, 700, 128)])
+@pytest.mark.parametrize('regs', [(0.0, 0.0), (0.05, 0.05)])
+def test_half_steps_f16(dev, shape, regs):
+    """precision='f16' (fp16 operands in the ping-pong kernel): one iteration against the fp32 oracle.  One rounding
+    to 11 significant bits per operand: a few 1e-5 per half-step."""
+    from oracle import mu_oracle as O
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + R)
+    V = torch.rand(N, C, generator=g)
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, 1, 'f16', 1, alpha=sum(regs), l1r=0.5)
+    Wr = O.nmf_w_step(V, W0, H0, 1, 1.0, *regs)
+    Hr = O.nmf_h_step(V, Wr, H0, 1, 1.0, *regs)
+    ew, eh = rel_err(W1, Wr), rel_err(H1, Hr)
+    print(f'f16 one iteration {shape}: relW={ew:.2e} relH={eh:.2e}')
+    assert ew < 2e-4 and eh < 2e-4, (ew, eh)
+    assert l0 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(H0, W0), V, 1)), rel=2e-4)
+    assert l1 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, 1)), rel=2e-4)
+
+
+def test_f16_range_handling(dev):
+    """fp16 operands: values below the fp16 normal range degrade gracefully (subnormals), ratios above 65504 saturate
+    (MODE.FP16_OVFL) instead of turning into inf / NaN, exact zeros stay exact."""
+    from oracle import mu_oracle as O
+    g = torch.Generator().manual_seed(3)
+    N, C, R = 300, 520, 32
+    V = torch.rand(N, C, generator=g)
+    V[:, :40] *= 1e-6                      # a block of tiny targets (fp16 subnormal / flushed)
+    V[5, :] = 0.0
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    H0[7, :] = 1e-7                        # S ~ 1e-6 on that row while V ~ 0.5: ratio ~ 5e5 > 65504
+    W0[:, 3] = 0.0                         # a dead component
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, 1, 'f16', 1)
+    assert torch.isfinite(W1).all() and torch.isfinite(H1).all()
+    assert float(W1[:, 3].abs().max()) == 0.0
+    Wr = O.nmf_w_step(V, W0, H0, 1, 1.0)
+    Hr = O.nmf_h_step(V, Wr, H0, 1, 1.0)
+    keep = torch.ones(N, dtype=torch.bool); keep[7] = False
+    # away from the saturating row the update is the reference's
+    assert rel_err(H1[keep], Hr[keep]) < 1e-3, rel_err(H1[keep], Hr[keep])
+
+
+def test_fit_f16_meets_parity_bar(dev):
+    """north_star's bar (1e-4 relative on the factors after N iterations) in the single-plane fp16 mode at a size where
+    the per-step rounding errors average down: 2048 x 4096, rank 64, 50 iterations."""
+    from torchnmf_amd.nmf import NMF
+    from oracle import mu_oracle as O
+    g = torch.Generator().manual_seed(21)
+    N, C, R = 2048, 4096, 64
+    V = torch.rand(N, C, generator=g).bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), 1, NO_STOP, 50, precision='f16')
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 50)
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    print(f'f16 fit 2048x4096 r64, 50 iterations: relW={ew:.2e} relH={eh:.2e}')
+    assert n == nr == 50
+    assert ew < TOL and eh < TOL, (ew, eh)
 
 
 @pytest.mark.parametrize('cols,nsplit', [(256, 1), (320, 1), (576, 3), (1100, 2), (2300, 8), (4100, 3)])
