@@ -342,6 +342,11 @@ int nmfmu_timer_destroy(void* timer);
 int nmfmu_probe_mfma(const uint16_t* a /*32x16 bf16 row-major*/, const uint16_t* b /*16x32*/, float* d /*32x32*/,
                      void* stream);
 int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords /* multiple of 1024 */, void* stream);
+/* Diagnostic hook of the ping-pong kernel (nmfmu_pp.h): with a device buffer of >= 2 * 256 * 6 uint64 registered and
+ * NMFMU_PP_VAR bit 128 set, workgroup 0 records s_memtime stamps of every segment of waves 0 and 4
+ * ([half][tile][M start, M end, after barrier, E end, after barrier, spare]).  buf = NULL unregisters.  Not used by
+ * the product path (tools/pp_timeline.py). */
+int nmfmu_debug_set_buffer(void* buf);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ static int pp_enabled() {
   static const int v = env_int("NMFMU_PP", 1);
   return v;
 }
+static void* g_pp_debug = nullptr;   // nmfmu_debug_set_buffer
 static int pp_var() {
   static const int v = env_int("NMFMU_PP_VAR", 0);
   return v;
@@ -93,7 +94,13 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   if (G == 2 && stage == 1 && st->xp && (mode == kModeMU || mode == kModeLoss) &&
       pp_eligible(st->r_pad, st->precision, st->beta)) {
     const int opt = st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16;
-    return launch_pp(st->r_pad, opt, mode, mode == kModeMU ? pp_var() : 0, a, grid, s);
+    const int var = mode == kModeMU ? pp_var() : 0;
+    if (!(var & 256)) a.tiles_per_split = (a.tiles_per_split + 1) & ~1;   // register-X tile loop is unrolled by two
+    if (var & 128) {
+      if (!g_pp_debug) return NMFMU_ERR_ARG;
+      a.loss_part = static_cast<float*>(g_pp_debug);   // (unused by the MU mode otherwise)
+    }
+    return launch_pp(st->r_pad, opt, mode, var, a, grid, s);
   }
   if (st->precision == NMFMU_PREC_F16) return NMFMU_ERR_UNSUPPORTED;   // fp16 operands exist in the ping-pong kernel only
   switch (st->r_pad) {
@@ -148,6 +155,8 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
   if (owner_rows_pad <= 0 || panel_rows_pad <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int mblocks = owner_rows_pad / block_rows;
   const int ktiles = panel_rows_pad / kBK;
+  static const int forced = env_int("NMFMU_FORCE_NSPLIT", 0);   // experiment hook
+  if (forced > 0) return std::min(forced, std::max(1, ktiles));
   // 128-row tiles run two workgroups per CU (both wave slots of every SIMD); 256-row tiles run one.
   const int target = (block_rows == 128 ? 2 : 1) * std::max(num_cu, 1);
   int ns = (target + mblocks - 1) / mblocks;
@@ -359,6 +368,11 @@ int nmfmu_timer_destroy(void* timer) {
   if (!t) return NMFMU_ERR_ARG;
   for (auto& e : t->ev) hipEventDestroy(e);
   delete t;
+  return NMFMU_OK;
+}
+
+int nmfmu_debug_set_buffer(void* buf) {
+  g_pp_debug = buf;
   return NMFMU_OK;
 }
 

@@ -16,13 +16,16 @@ static int launch_pp_r(int opt, int mode, int var, const FusedArgs& a, int grid,
   NMFMU_PP_CASE(kOpF16, kModeMU, 0)
   NMFMU_PP_CASE(kOpBf16, kModeLoss, 0)
   NMFMU_PP_CASE(kOpF16, kModeLoss, 0)
-  if constexpr (R_PAD == 128) {   // experiment variants of the headline instance only
+  if constexpr (R_PAD == 128) {   // experiment variants of the headline instance only (NMFMU_PP_VAR, see nmfmu_pp.h)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 1)
-    NMFMU_PP_CASE(kOpBf16, kModeMU, 2)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 4)
-    NMFMU_PP_CASE(kOpF16, kModeMU, 1)
-    NMFMU_PP_CASE(kOpF16, kModeMU, 2)
-    NMFMU_PP_CASE(kOpF16, kModeMU, 4)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 256)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 512)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 128)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 152)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 160)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 184)
+    NMFMU_PP_CASE(kOpF16, kModeMU, 128)
   }
 #undef NMFMU_PP_CASE
   if (var != 0) return launch_pp_r<R_PAD>(opt, mode, 0, a, grid, s);   // variant not built for this shape

@@ -78,6 +78,14 @@ __device__ __forceinline__ float unpack_hi(uint32_t w) {
 // VAR bits (build-time experiment switches, selected per launch through FusedArgs-independent dispatch):
 //   1: s_setprio 1 for the matrix segments      2: static s_setprio 1 for the younger half (waves 4-7)
 //   4: LDS-DMA issued after the elementwise work instead of before it
+// ablations (wrong results, timing only):  8: no X DMA in the loop   16: no panel DMA in the loop
+//   32: no elementwise arithmetic (the ratio words are the raw X words)   64: no MFMAs
+// 128: s_memtime stamps of every segment of waves 0 and 4 of workgroup 0 into FusedArgs::loss_part
+// 256: X tiles go through a two-slot LDS ring (LDS-DMA) instead of straight into registers (global_load_dwordx4, two
+//      buffers, two tiles ahead): 32 KiB more LDS-DMA writes and LDS reads per tile, measured 5 % slower
+// 512: operand prefetch ring 8 deep instead of 4
+// 8192: numerator accumulators in AGPRs ("a" operands of the MFMAs) -- measured 1-2 % slower, not instantiated
+// 1024 / 2048 (timing only): the panel DMA / the X loads are issued twice -- marginal cost of one VMEM instruction
 template <int R_PAD, int OPT, int MODE, int VAR>
 struct PPCfg {
   static constexpr int BM = 256, WAVES = 8, THREADS = 512;
@@ -88,15 +96,16 @@ struct PPCfg {
   static constexpr bool LOSS = MODE == kModeLoss;
   static constexpr int NSLOT = 3, LEAD = 2;  // panel ring depth; P1 runs LEAD tiles ahead, P2 LEAD - 1
   static constexpr int XTILE = BM * kBK * 2; // one X tile: 256 rows x 64 columns x 2 bytes = 32 KiB
+  static constexpr bool XREG = (VAR & 256) == 0;  // X straight into registers (two buffers); bit 256: LDS ring instead
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = 2 * NSLOT * IMG;
-  static constexpr int LDS_MAIN = X_BASE + 2 * XTILE;
+  static constexpr int LDS_MAIN = X_BASE + (XREG ? 0 : 2 * XTILE);
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
   static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
   static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
   static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
-  static constexpr int PF = 4;                               // operand prefetch ring depth
-  static constexpr bool SCALED = OPT == kOpBf16;             // S' = 2^23 (S + eps), seeded with the inline constant 1.0
+  static constexpr int PF = (VAR & 512) ? 8 : 4;             // operand prefetch ring depth
+  static constexpr bool SCALED = OPT == kOpBf16 && !(VAR & 4096);   // S' = 2^23 (S + eps), seeded with the inline constant 1.0
   static_assert(NSTEP1 >= PF, "ring deeper than G1");
 };
 
@@ -165,9 +174,13 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   for (int rt = 0; rt < (C::LOSS ? 1 : RT); ++rt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
-  f32x16 epsv;   // accumulator seed: eps, or the constant 1.0 (which hipcc folds into the MFMA's C operand)
+  // accumulator seed of the fp16 kernels: a register tile of eps.  It is laundered through an empty asm so that hipcc
+  // keeps it resident instead of re-materialising it with v_mov right in front of the (asm, hence unpadded) MFMA that
+  // reads it as its C operand -- a VALU write -> XDL SrcC read hazard that made S' = S_new + stale S_old.
+  f32x16 epsv;
 #pragma unroll
   for (int e = 0; e < 16; ++e) epsv[e] = SCALED ? 1.0f : kEps;
+  if constexpr (!SCALED) asm volatile("" : "+v"(epsv));
   float lacc = 0.f;
 
   if (nt > 0) {
@@ -216,10 +229,44 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) dma1k(src + qq * 1024, lane16, dst + qq * 1024u);
     };
+    // register path (XREG): this wave's four 1-KiB pieces of X(t), one 16-byte chunk per lane each, loaded by asm so
+    // that hipcc neither counts nor waits for them; wait_x() is the counted wait that makes a buffer readable
+    const char* xsrc_l = xsrc;   // (wave-uniform)
+    auto load_x = [&](int t, u32x4(&x)[4]) {
+      const char* src = xsrc_l + (size_t)clampt(t) * (size_t)C::XTILE;
+      asm volatile(
+          "s_nop 4\n\t"
+          "global_load_dwordx4 %0, %4, %5 nt\n\t"
+          "global_load_dwordx4 %1, %4, %5 offset:1024 nt\n\t"
+          "global_load_dwordx4 %2, %4, %5 offset:2048 nt\n\t"
+          "global_load_dwordx4 %3, %4, %5 offset:3072 nt"
+          : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+          : "v"(lane16), "s"(src)
+          : "memory");
+    };
+    auto wait_x = [&](u32x4(&x)[4]) {
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+    };
     auto barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+    };
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.loss_part);
+    // VAR & 128: two stamps per wave 0 / wave 4 of workgroup 0 -- shader clock and the constant 100 MHz clock at the
+    // start (slot 0) and at the end (slot 1) of the tile loop: cycles per tile and the core frequency, unperturbed
+    auto stamp = [&](int slot) {
+      if constexpr ((VAR & 128) != 0) {
+        if (blockIdx.x == 0 && (wave & 3) == 0) {
+          const unsigned long long c = __builtin_amdgcn_s_memtime();
+          const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+          if (lane == 0) {
+            dbg[(half * 2 + slot) * 4 + 0] = c;
+            dbg[(half * 2 + slot) * 4 + 1] = r;
+            dbg[(half * 2 + slot) * 4 + 2] = (unsigned long long)nt;
+          }
+        }
+      }
     };
 
     uint32_t gn[2][8];
@@ -275,11 +322,19 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
     };
+    auto mma_acc = [&](f32x16& d, const u32x4& x, const u32x4& y) {   // G2: accumulators optionally in AGPRs
+      if constexpr ((VAR & 8192) != 0) {
+        if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(x), "v"(y));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(x), "v"(y));
+      } else {
+        mma(d, x, y);
+      }
+    };
     // M(t): G1(t) if g1, then G2(t-1) if g2; ends with the counted wait for the panel DMA of the previous E segment
     auto matrix_segment = [&](auto g1c, auto g2c) {
       constexpr bool g1 = decltype(g1c)::value, g2 = decltype(g2c)::value && !C::LOSS;
       constexpr int N1 = g1 ? NSTEP1 : 0, N2 = g2 ? NSTEP2 : 0, NS = N1 + N2;
-      if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
+      if constexpr (VAR & 1) asm volatile("s_setprio 3");
       static_for<NS>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         constexpr int younger = (NS - 1 - e) < (PF - 1) ? (NS - 1 - e) : (PF - 1);
@@ -289,29 +344,38 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           constexpr int tt = e & 1, kk = e >> 1;
           if constexpr (kk == 0) {   // accumulator seed: the inline constant 1.0 (bf16, scaled) or the eps tile
             if constexpr (SCALED)
-              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=v"(S[tt]) : "v"(op), "v"(q[0]));
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=&v"(S[tt]) : "v"(op), "v"(q[0]));
             else
-              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
+              if constexpr (OPT == kOpF16)
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
+              else
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
           } else {
-            mma(S[tt], op, q[kk]);
+            if constexpr (!(VAR & 64)) mma(S[tt], op, q[kk]);
           }
         } else {
           constexpr int s2 = e - N1;
           constexpr int rt = s2 % RT, c = s2 / RT, tt = c >> 1, m2 = c & 1;
           const u32x4 nh = {gn[tt][4 * m2], gn[tt][4 * m2 + 1], gn[tt][4 * m2 + 2], gn[tt][4 * m2 + 3]};
-          mma(acc[rt], nh, op);
+          if constexpr (!(VAR & 64)) mma_acc(acc[rt], nh, op);
         }
         if constexpr (e + PF < NS) opnd(ring[e % PF], std::integral_constant<int, e + PF>{}, g1c);
       });
-      if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (VAR & 1) asm volatile("s_setprio 0");
+      // asm MFMAs are not padded by hipcc: when no G2 follows G1, the S tiles are read by the VALU right after the
+      // barrier -- cover the XDL write -> VALU read distance (18 wait states for a 16-pass MFMA) here
+      if constexpr (g1 && N2 == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      if constexpr (VAR & (8 | 16 | 1024 | 2048)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (!C::XREG) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
     // E(t): ratios of tile t from S and X(t); operand prefetch for the next M segment, panel DMA (waves 0-3) and this
     // wave's X piece two tiles ahead
-    auto elementwise_segment = [&](int t, auto nextc) {
+    auto elementwise_segment = [&](int t, auto nextc, u32x4(&x)[4], auto tailc) {
       constexpr bool next_has_g1 = decltype(nextc)::value;
-      u32x4 x[4];
-      {
+      // XREG tail (the last two tiles): nothing is prefetched past the end -- an asm load whose result is never read
+      // would land in registers hipcc has already handed to something else
+      constexpr bool tail = decltype(tailc)::value;
+      if constexpr (!C::XREG) {
         const char* xl = smem + C::X_BASE + (t & 1) * C::XTILE + wave * 4096 + lane * 16;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) x[qq] = ld16(xl + qq * 1024);
@@ -319,12 +383,22 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       advance_slots();
       if constexpr (next_has_g1) prefetch(std::true_type{});
       else if constexpr (!C::LOSS) prefetch(std::false_type{});
-      if constexpr (!(VAR & 4)) {
-        if (!half) issue_panel(t);
+      if constexpr (!(VAR & 4) && !(VAR & 16)) {
+        if constexpr (!tail) {
+          if (!half) issue_panel(t);
+          if constexpr ((VAR & 1024) != 0) {
+            if (!half) issue_panel(t);
+          }
+        } else if constexpr (next_has_g1 && !C::LOSS) {   // tile nt-2: only P2(nt-1) is still needed
+          if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
+        }
       }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        if constexpr (C::LOSS) {
+        if constexpr ((VAR & 32) != 0) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) gn[tt][d] = x[2 * tt + (d >> 2)][d & 3];
+        } else if constexpr (C::LOSS) {
 #pragma unroll
           for (int d = 0; d < 8; ++d) {
             const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
@@ -370,14 +444,22 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           }
         }
       }
-      if constexpr (VAR & 4) {
+      if constexpr ((VAR & 4) && !(VAR & 16)) {
         __builtin_amdgcn_sched_barrier(0);
-        if (!half) issue_panel(t);
+        if constexpr (!tail) {
+          if (!half) issue_panel(t);
+        } else if constexpr (next_has_g1 && !C::LOSS) {
+          if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
+        }
       }
       p1_issue_off = next_off(p1_issue_off);
       p2_issue_off = next_off(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
-      issue_x(t + 2);                      // ... before its slot is refilled
+      if constexpr (!(VAR & 8) && !tail) {        // ... before its slot / register buffer is refilled
+        if constexpr (C::XREG) load_x(t + 2, x);
+        else issue_x(t + 2);
+        if constexpr ((VAR & 2048) != 0 && C::XREG) load_x(t + 2, x);
+      }
     };
 
     // ---- prologue: P1(0), P1(1), P2(0), X(0), X(1); everything landed before the first barrier
@@ -389,9 +471,17 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
       }
     }
-    issue_x(0);
-    issue_x(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x4 xA[4], xB[4];   // XREG: X(even tiles) / X(odd tiles); otherwise xA is the per-segment scratch copy
+    if constexpr (C::XREG) {
+      load_x(0, xA);
+      load_x(1, xB);
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
+    } else {
+      issue_x(0);
+      issue_x(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if constexpr (VAR & 2) {
       if (half) __builtin_amdgcn_s_setprio(1);
     }
@@ -399,18 +489,45 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     prefetch(std::true_type{});
     if (half) barrier();                       // waves 4-7 run one segment behind
     matrix_segment(std::true_type{}, std::false_type{});
-    // (the last tile is peeled: one join of two differently-shaped M segments inside the loop would cost a register
-    // copy of every accumulator per tile)
-    for (int t = 0; t + 1 < nt; ++t) {
+    stamp(0);
+    // one tile = barrier, E(t), barrier, M(t+1).  `xc` holds X(t); with XREG the wait that ends M(t+1) names the
+    // buffer the NEXT elementwise segment reads.  The last tile is peeled (a join of two differently shaped M
+    // segments inside the loop would cost a register copy of every accumulator per tile).
+    auto tile_full = [&](int t, u32x4(&xc)[4], u32x4(&xn)[4], auto tailc) {
+      constexpr bool tail = decltype(tailc)::value;
       barrier();
-      elementwise_segment(t, std::true_type{});
+      elementwise_segment(t, std::true_type{}, xc, tailc);
       barrier();
       matrix_segment(std::true_type{}, std::true_type{});
+      if constexpr (C::XREG && !(VAR & (8 | 16 | 1024 | 2048))) {
+        if constexpr (tail)   // nothing younger than X(t+1) except tail panel pieces: drain
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+        else
+          wait_x(xn);
+      }
+    };
+    auto tile_last = [&](int t, u32x4(&xc)[4], auto tailc) {
+      barrier();
+      elementwise_segment(t, std::false_type{}, xc, tailc);
+      barrier();
+      matrix_segment(std::false_type{}, std::true_type{});
+    };
+    if constexpr (C::XREG) {
+      // static register buffers => the tile loop is unrolled by two; the host gives every workgroup an EVEN number of
+      // tiles (tiles_per_split is rounded up to even, the padded contraction length is a multiple of 256), so there is
+      // one straight-line tail and no join of differently shaped paths
+      int t = 0;
+      for (; t + 2 < nt; t += 2) {
+        tile_full(t, xA, xB, std::false_type{});
+        tile_full(t + 1, xB, xA, std::false_type{});
+      }
+      tile_full(t, xA, xB, std::true_type{});
+      tile_last(t + 1, xB, std::true_type{});
+    } else {
+      for (int t = 0; t + 1 < nt; ++t) tile_full(t, xA, xA, std::false_type{});
+      tile_last(nt - 1, xA, std::false_type{});
     }
-    barrier();
-    elementwise_segment(nt - 1, std::false_type{});
-    barrier();
-    matrix_segment(std::false_type{}, std::true_type{});
+    stamp(1);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read of the accumulators (asm MFMAs are not padded)
     if (!half) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches: nothing may land in LDS after this

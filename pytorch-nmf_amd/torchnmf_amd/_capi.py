@@ -138,6 +138,7 @@ SIGNATURES = {
     'nmfmu_timer_destroy': (C.c_int, [C.c_void_p]),
     'nmfmu_probe_mfma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_probe_lds_dma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_debug_set_buffer': (C.c_int, [C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,45 @@
+"""Cycles per tile and core frequency of the ping-pong kernel's tile loop (nmfmu_pp.h with NMFMU_PP_VAR bit 128):
+waves 0 and 4 of workgroup 0 stamp the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at the
+start and at the end of the loop.  Usage (GPU box): NMFMU_PP_VAR=384 python tools/pp_timeline.py bf16"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd')):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+assert int(os.environ.get('NMFMU_PP_VAR', '0')) & 128, 'set NMFMU_PP_VAR with bit 128'
+from torchnmf_amd import _capi
+from torchnmf_amd.engine import DenseMU
+
+dev = torch.device('cuda', 0)
+N, Cc, R = 4096, int(os.environ.get('PP_COLS', '65536')), 128
+g = torch.Generator(device=dev).manual_seed(0)
+V = torch.rand(N, Cc, device=dev, generator=g).bfloat16().float()
+W = torch.randn(Cc, R, device=dev, generator=g).abs_()
+H = torch.randn(N, R, device=dev, generator=g).abs_()
+lib = _capi.load()
+buf = torch.zeros(64, dtype=torch.int64, device=dev)
+_capi.check(lib.nmfmu_debug_set_buffer(buf.data_ptr()), 'debug')
+prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+eng = DenseMU(V, W, H, 1.0, precision=prec)
+for _ in range(30):
+    eng.w_step(); eng.h_step()
+for which in os.environ.get('PP_STEPS', 'h,w').split(','):
+    res = []
+    for rep in range(5):
+        for _ in range(3):
+            eng.w_step(); eng.h_step()
+        (eng.h_step if which == 'h' else eng.w_step)()
+        torch.cuda.synchronize()
+        st = buf.cpu().numpy()[:16].reshape(4, 4)
+        nt = int(st[0, 2])
+        cyc = int(st[1, 0] - st[0, 0]); ref = int(st[1, 1] - st[0, 1])
+        res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0))
+    r = np.array(res)
+    print(f'{prec} VAR={os.environ.get("NMFMU_PP_VAR")} {which}-step cols={Cc}: {nt} tiles/WG, cycles/tile {np.median(r[:, 0]):.0f}, '
+          f'core clock {np.median(r[:, 1]):.0f} MHz, {np.median(r[:, 2]):.1f} ns/tile  '
+          f'=> tile loop {np.median(r[:, 2]) * nt / 1e3:.1f} us')
+_capi.check(lib.nmfmu_debug_set_buffer(None), 'debug')
