@@ -826,17 +826,25 @@ int launch_fused_r64(int beta_kind, int x3, int mode, int stage, int g, const Fu
 int launch_fused_r128(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
 int launch_fused_r256(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s);
 
+// Per-device "attribute set" memo (one host thread may drive several devices)
+inline bool* attr_flag(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return &flags[dev];
+}
+
 template <int R_PAD, int BETA, bool X3, int MODE, int STAGE, int G>
 int launch_one(const FusedArgs& a, int grid, hipStream_t s) {
   using C = FusedCfg<R_PAD, BETA, X3, MODE, G>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
   auto kern = fused_kernel<R_PAD, BETA, X3, MODE, STAGE, G>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool done[64] = {};   // the dynamic-LDS attribute is per device: a single-process multi-device host sets it on each
+  bool* flag = attr_flag(done);
+  if (!*flag) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    *flag = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, a);
   return (int)hipGetLastError();

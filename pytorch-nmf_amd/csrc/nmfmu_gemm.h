@@ -263,12 +263,13 @@ template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3>;
   auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
+  bool* flag = attr_flag(done);
+  if (!*flag) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    *flag = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.n_pad / 128, a.m_pad / 128), dim3(256), C::LDS_BYTES, s, a);
   return (int)hipGetLastError();

@@ -644,13 +644,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   }
 }
 
-// per-device "attribute set" memo (one host thread may drive several devices)
-inline bool* attr_flag(bool (&flags)[64]) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  return &flags[dev];
-}
-
 template <int R_PAD, int OPT, int MODE, int VAR>
 int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
   using C = PPCfg<R_PAD, OPT, MODE, VAR>;

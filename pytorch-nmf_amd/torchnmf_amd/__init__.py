@@ -4,7 +4,8 @@
     m = NMF(V.shape, rank=128).cuda()
     n_iter = m.fit(V.cuda(), beta=1)
 
-Only the dense beta-divergence MU hot path of yoyololicon/pytorch-NMF is implemented.
+The beta-divergence MU hot path of yoyololicon/pytorch-NMF (dense and sparse-COO ``NMF``, ``NMFD``, ``NMF2D`` / ``NMF3D``,
+``trainer.BetaMu`` on layer chains, ``PLCA`` / ``SIPLCA*``) on hand-written HIP kernels; see DESIGN.md for what is out of scope.
 """
 name = 'torchnmf_amd'
 __version__ = '0.1.0'

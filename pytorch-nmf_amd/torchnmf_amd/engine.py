@@ -12,6 +12,7 @@ all-reduces one packed fp32 buffer ``[numerator | denominator]`` per iteration.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -219,8 +220,14 @@ class DenseMU:
     (nmf.py:92).  With ``group`` set, ``V`` / ``W`` are this rank's column shard.
     """
 
+    # 'auto' may pick the single-plane fp16 mode only where it meets the 1e-4 parity bar (DESIGN.md section 4): both
+    # contraction lengths long enough for the per-step rounding errors to average down, and data inside fp16's range
+    F16_MIN_DIM = 2048
+    F16_MAX_ABS = 3.0e4
+    F16_MIN_MEAN = 2.0 ** -10
+
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
-                 update_W=True, update_H=True, block_rows=None):
+                 update_W=True, update_H=True, block_rows=None, allow_f16=False):
         self.be = backend if backend is not None else DEFAULT_BACKEND_FACTORY()
         self.group = group
         self.beta = float(beta)
@@ -234,6 +241,14 @@ class DenseMU:
         self.r_pad = self.be.pad_rank(R)
         if precision in (None, 'auto'):
             precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
+            if (allow_f16 and self.kl and group is None and min(N, Cc) >= self.F16_MIN_DIM
+                    and hasattr(_capi, 'PREC_F16') and self.be.supported(self.r_pad, _capi.PREC_F16)
+                    and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0'):
+                # one pass over V, W, H and one host sync (fit() syncs on the validation flags anyway)
+                stats = torch.stack([V.max(), V.mean(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
+                vmax, vmean, wmax, hmax, wmean, hmean = stats
+                if (max(vmax, wmax, hmax) <= self.F16_MAX_ABS and min(vmean, wmean, hmean) >= self.F16_MIN_MEAN):
+                    precision = 'f16'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
         self.precision_name = precision
@@ -343,7 +358,11 @@ class DenseMU:
             tail.copy_(self.fW.colsum)
         else:
             self.be.slab_reduce(st, num, tail)
+        if self.timer is not None:
+            self.timer.mark('ar<')
         dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+        if self.timer is not None:
+            self.timer.mark('ar>')
         if self.kl:
             self.be.mu_apply(st, num, None, 1, tail)
         else:

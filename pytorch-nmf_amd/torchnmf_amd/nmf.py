@@ -9,8 +9,9 @@ point runs hand-written HIP kernels on the module's ROCm device through the C
 ABI of ``include/nmfmu.h``; there is no CPU path (a CPU-resident module raises
 on ``forward`` / ``fit``).
 
-Out of scope for this engine: sparse targets,
-``sparse_fit``, NMF2D/NMF3D, autograd through ``forward``.
+``NMF2D`` / ``NMF3D`` (nmf.py:782-942) and sparse-COO targets of ``NMF.fit`` (nmf.py:351-398, 602-638) run on
+the same engines.  Out of scope: ``sparse_fit`` (Hoyer-projected gradient) and autograd through
+``forward``.
 """
 from __future__ import annotations
 
@@ -24,7 +25,15 @@ from torch import Tensor, nn
 from . import _capi
 from .constants import eps  # noqa: F401  (re-exported like the reference)
 
-__all__ = ['BaseComponent', 'NMF', 'NMFD']
+__all__ = ['BaseComponent', 'NMF', 'NMFD', 'NMF2D', 'NMF3D']      # torchnmf/nmf.py:16-18
+
+
+def _sqrt2(div: float) -> float:
+    """``sqrt(2 * divergence)`` of nmf.py:362 / 402.  A divergence that fp32 rounding pushed slightly below zero gives
+    NaN, as ``Tensor.sqrt`` does in the reference (a Python float power would return a complex number and make the
+    ``< tol`` comparison raise)."""
+    d = 2.0 * div
+    return d ** 0.5 if d >= 0 else float('nan')
 
 
 def _new_factor(spec, trainable: bool, label: str):
@@ -111,9 +120,11 @@ class BaseComponent(nn.Module):
         ``(previous - loss) / loss_init < tol``.  Returns the number of iterations.
 
         Extra keyword-only arguments (not in the reference):
-          precision      'bf16x3' (default where available: split-bf16 MFMA, matches the fp32 reference to
-                         ~1e-5; above rank 128 on the GEMM engine), 'bf16' (fastest; V and operands rounded to
-                         bf16), or None/'auto' (= 'bf16x3').
+          precision      None / 'auto' (default): the fastest mode that meets the reference's 1e-4 bar -- 'f16'
+                         (fp16 operands, bf16's MFMA rate) for beta == 1, rank <= 128, both dimensions >= 2048
+                         and data inside fp16's range, otherwise 'bf16x3' (split-bf16 MFMA, matches the fp32
+                         reference to ~1e-5; above rank 128 on the GEMM engine).  Explicit: 'f16', 'bf16x3',
+                         'bf16' (V and operands rounded to bf16: objective within 1e-4, factors ~1e-3).
                          The environment variable TORCHNMF_AMD_PRECISION overrides the default.
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
@@ -151,7 +162,7 @@ class BaseComponent(nn.Module):
             raise ValueError("When beta <= 0 and V contains zeros, the training process may diverge. "
                              "Please add small values to V, or use a positive beta value.")
 
-        loss_init = (2.0 * eng.divergence()) ** 0.5   # nmf.py:355-363
+        loss_init = _sqrt2(eng.divergence())   # nmf.py:355-363
         previous = loss_init
         pbar = None
         if verbose:
@@ -176,7 +187,7 @@ class BaseComponent(nn.Module):
                         from .engine import capture_iteration
                         graph = capture_iteration(iteration, process_group)
                 if n_iter % 10 == 9:
-                    loss = (2.0 * eng.divergence()) ** 0.5
+                    loss = _sqrt2(eng.divergence())
                     if pbar is not None:
                         pbar.set_postfix(loss=loss)
                         pbar.update(10)
@@ -205,15 +216,16 @@ class NMF(BaseComponent):
         """``H @ W.T`` (nmf.py:691-693) by an exact-fp32 MFMA kernel on the device."""
         _require_device(H, 'reconstruct')
         _require_device(W, 'reconstruct')
-        assert H.dim() == 2 and W.dim() == 2 and H.shape[1] == W.shape[1]
+        assert H.dim() >= 2 and W.dim() == 2 and H.shape[-1] == W.shape[1]
         lib = _capi.load()
-        Hc = H.detach().float().contiguous()
+        lead = tuple(H.shape[:-1])                       # F.linear accepts leading batch dimensions (nmf.py:693)
+        Hc = H.detach().float().reshape(-1, H.shape[-1]).contiguous()
         Wc = W.detach().float().contiguous()
         out = torch.empty(Hc.shape[0], Wc.shape[0], dtype=torch.float32, device=H.device)
         _capi.check(lib.nmfmu_reconstruct(Hc.data_ptr(), Hc.shape[0], Wc.data_ptr(), Wc.shape[0], Hc.shape[1],
                                           out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream),
                     'nmfmu_reconstruct')
-        return out
+        return out.reshape(lead + (Wc.shape[0],))
 
     def _make_engine(self, V, beta, l1, l2, precision, group):
         from .engine import DenseMU
@@ -238,7 +250,7 @@ class NMF(BaseComponent):
             return WideRankMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
                               update_W=self.W.requires_grad, update_H=self.H.requires_grad)
         return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
-                       update_W=self.W.requires_grad, update_H=self.H.requires_grad)
+                       update_W=self.W.requires_grad, update_H=self.H.requires_grad, allow_f16=True)
 
 
 class NMFD(BaseComponent):
@@ -263,6 +275,9 @@ class NMFD(BaseComponent):
         from .nmfd_engine import ConvMU
         if group is not None:
             raise NotImplementedError('NMFD is not sharded (replicas only): sharding L needs a (T-1)-column halo')
+        for p in (self.W, self.H):                      # the engine works on the parameters' storage in place
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
         return ConvMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
                       update_W=self.W.requires_grad, update_H=self.H.requires_grad)
 

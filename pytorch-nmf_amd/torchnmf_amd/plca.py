@@ -19,7 +19,7 @@ from torch import Tensor, nn
 from . import _capi
 from .constants import eps as _EPS
 from .engine import DEFAULT_BACKEND_FACTORY, FactorBuf, StepBuf, _ptr
-from .nmf import _require_device
+from .nmf import _require_device, _sqrt2
 
 __all__ = ['PLCA', 'SIPLCA', 'SIPLCA2', 'SIPLCA3', 'BaseComponent']
 
@@ -127,7 +127,7 @@ class BaseComponent(nn.Module):
                 p.data = p.data.contiguous()
         em = self._make_em(Vn, precision)
         nrm = float(norm.item())
-        loss_init = previous = (2.0 * nrm * em.divergence()) ** 0.5      # kl_div(WZH * norm, V), plca.py:245-246
+        loss_init = previous = _sqrt2(nrm * em.divergence())      # kl_div(WZH * norm, V), plca.py:245-246
         pbar = None
         if verbose:
             from tqdm import tqdm
@@ -137,7 +137,7 @@ class BaseComponent(nn.Module):
             for n_iter in range(max_iter):
                 em.em_step(W.requires_grad, H.requires_grad, Z.requires_grad, W_alpha, H_alpha, Z_alpha)
                 if n_iter % 10 == 9:
-                    loss = (2.0 * nrm * em.divergence()) ** 0.5
+                    loss = _sqrt2(nrm * em.divergence())
                     if pbar is not None:
                         pbar.set_postfix(loss=loss)
                         pbar.update(10)
@@ -379,6 +379,9 @@ def _conv_reconstruct(H: Tensor, W: Tensor, Z: Tensor) -> Tensor:
 class _ShiftInvariant(BaseComponent):
     def _make_em(self, Vn, precision):
         assert Vn.dim() == self.W.dim() and Vn.shape[0] == self.H.shape[0] and Vn.shape[1] == self.W.shape[0]
+        for q in (self.W, self.H, self.Z):              # the EM engine works on the parameters' storage in place
+            if not q.data.is_contiguous():
+                q.data = q.data.contiguous()
         return _ConvPlcaEM(Vn, self.W.data, self.H.data, self.Z.data, precision)
 
     @staticmethod

@@ -28,7 +28,17 @@ from .engine import DenseMU
 from . import nmf as _nmf
 from .nmf import NMF, BaseComponent
 
-__all__ = ['BetaMu']
+__all__ = ['BetaMu', 'SparsityProj']
+
+
+class SparsityProj(Optimizer):
+    """Placeholder for the reference's Hoyer-projected gradient optimizer (torchnmf/trainer.py:124-226).  It is a
+    different algorithm (serial projection loop) outside the MU hot path this engine implements (SURVEY.md section 2);
+    importing the name works, constructing it says so."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError('trainer.SparsityProj (Hoyer-projected gradient, trainer.py:124-226) is outside the MU '
+                                  'hot path torchnmf_amd implements; use the reference package for sparse_fit')
 
 
 class BetaMu(Optimizer):
@@ -73,22 +83,34 @@ class BetaMu(Optimizer):
             if node is None:
                 return H, Ws[::-1]
 
-    def _engine(self, V, H, W, beta, l1, l2) -> DenseMU:
-        """DenseMU bound to (V, W, H), rebuilt when any of them is replaced and refreshed when edited in place."""
-        key = (V.data_ptr(), tuple(V.shape), W.data_ptr(), H.data_ptr(), float(beta), float(l1), float(l2))
-        hit = self._engines.get(key)
-        versions = [V._version, W._version, H._version]
-        if hit is not None and hit[1][0] == versions[0]:
-            eng, seen = hit
+    def _engine(self, V_user, V, converted, H, W, beta, l1, l2) -> DenseMU:
+        """DenseMU bound to (target, W, H), rebuilt when any of them is replaced and refreshed when W / H are edited in
+        place.  ``V_user`` is the tensor the closure returned, ``V`` its detached fp32 contiguous form (``converted`` says
+        whether that needed a copy).  The cache entry holds a reference to ``V_user`` and is keyed on that object's identity
+        and ``_version`` -- never on the address of a converted temporary, whose storage the caching allocator hands out
+        again -- and a target that had to be converted is packed afresh on every step (its source may have been edited
+        in place without bumping anything we can see).  One engine per (target, W, H, beta, l1, l2): param groups with
+        different hyper-parameters keep their own packed target instead of evicting each other."""
+        key = (id(V_user), tuple(V.shape), W.data_ptr(), H.data_ptr(), float(beta), float(l1), float(l2))
+        hit = None if converted else self._engines.get(key)
+        versions = [V_user._version, W._version, H._version]
+        if hit is not None and hit[2] is V_user and hit[1][0] == versions[0]:
+            eng, seen, _ = hit
             if seen[1:] != versions[1:]:               # someone else edited W / H since our last update
                 eng.refresh_images()
                 seen[1:] = versions[1:]
             return eng
-        self._engines.clear()                          # one live binding: packed V is as large as V
+        # drop bindings of other targets / other factor storage (a packed V is as large as V); same-target bindings of
+        # other hyper-parameter sets stay
+        for k in [k for k, v in self._engines.items() if v[2] is not V_user or k[2:4] != key[2:4]]:
+            del self._engines[k]
         eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=self._precision)
         bad, _ = eng.target_flags()
         assert not bad, "Target should be non-negative."
-        self._engines[key] = (eng, versions)
+        if not converted:
+            self._engines[key] = (eng, versions, V_user)
+        else:
+            self._last_uncached = eng                  # (bench / tests look the live engine up)
         return eng
 
     def _chain_step(self, V, X0, Ws, p, beta, l1, l2, ortho):
@@ -149,8 +171,10 @@ class BetaMu(Optimizer):
                         continue
                     for t, what in [(V, 'BetaMu target')] + [(q, 'BetaMu factor') for q in names]:
                         _nmf._require_device(t, what)
+                    V_user = V
                     V = V.detach()
-                    if V.dtype != torch.float32 or not V.is_contiguous():
+                    converted = V.dtype != torch.float32 or not V.is_contiguous()
+                    if converted:
                         V = V.float().contiguous()
                     for q in names:
                         if isinstance(q, torch.nn.Parameter) and not q.data.is_contiguous():
@@ -161,7 +185,7 @@ class BetaMu(Optimizer):
                         H, W = X0, Ws[0]
                         assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0]), \
                             f'target must be {(H.shape[0], W.shape[0])}, got {tuple(V.shape)}'
-                        eng = self._engine(V, H, W, beta, l1, l2)
+                        eng = self._engine(V_user, V, converted, H, W, beta, l1, l2)
                         eng.trainer_step('W' if p is W else 'H', ortho, p.grad)
                     else:
                         self._chain_step(V, X0, Ws, p, beta, l1, l2, ortho)
