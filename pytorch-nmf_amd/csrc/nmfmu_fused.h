@@ -229,7 +229,7 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int m = m0 + 32 * g;
-    const int sw = ((m >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    const int sw = P1Swz<R_PAD>::of(m) << 4;
     const char* rowh = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m * ROWB;
     const char* rowl = reinterpret_cast<const char*>(a.a1_lo) + (size_t)m * ROWB;
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__((FusedCfg<R_PAD, BETA, X3, MODE, GT>::THREADS)
   for (int tt = 0; tt < 2; ++tt) {
     const int row = 32 * ((j >> 2) & 1) + 16 * tt + (j & 3) + 4 * (j >> 3);
     a_row[tt] = row * ROWB;
-    a_sw[tt] = ((row >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    a_sw[tt] = P1Swz<R_PAD>::of(row) << 4;
   }
   // GEMM2 B operand: rank column 32*rt + j, contraction slice 32*hl + 16*tt + 8*m2 .. +7
   const int b_row = j * 128;

@@ -22,6 +22,9 @@ static int launch_pp_r(int opt, int mode, int var, const FusedArgs& a, int grid,
     NMFMU_PP_CASE(kOpBf16, kModeMU, 256)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 512)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 128)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 16384)
+    NMFMU_PP_CASE(kOpF16, kModeMU, 16384)
+    NMFMU_PP_CASE(kOpBf16, kModeMU, 16512)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 152)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 160)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 184)

@@ -53,20 +53,23 @@ constexpr int kRowPad = 256;  // every factor's row count is padded to this (cov
 constexpr int kBK = 64;   // contraction columns per tile
 constexpr int kWaves = 4;
 
-// swizzle of P1: physical slot = slot ^ swz1(row)
+// swizzle of P1: physical 16-byte slot = slot ^ p1_swz(row).  The swizzle value is a bijection of the row bits above
+// "rows per 256-byte LDS bank line" (1 / 2 / 4 rows per line at padded rank >= 128 / 64 / 32), which is what makes the
+// ds_read_b128 operand reads of the first GEMM (16 lanes = 16 rows, one logical slot) conflict free.  Its TOP bits come
+// from the LOWEST of those row bits: the transposing reads of the second GEMM (ds_read_b64_tr_b16, nmfmu_pp.h) fetch
+// four consecutive rows x 64 bytes per 32-lane pass, and four consecutive rows must land in four different bank
+// quarters.  (Padded rank 256 is not served by that path and keeps the plain row & 15.)
+NMFMU_HD int p1_swz(int row, int r_pad) {
+  const int sp = r_pad / 8;                                              // 16-byte slots per row
+  if (sp >= 32) return row & 15;
+  if (sp == 16) return ((row & 3) << 2) | ((row >> 2) & 3);
+  if (sp == 8) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  return (row >> 2) & 3;                                                 // sp == 4
+}
 template <int R_PAD>
 struct P1Swz {
-  static constexpr int SP = R_PAD / 8;                                  // 16-byte slots per row
-  static constexpr int SHIFT = SP >= 16 ? 0 : (SP == 8 ? 1 : 2);        // rows sharing one 256-B bank row
-  static constexpr int MASK = SP >= 16 ? 15 : SP - 1;
+  static NMFMU_HD int of(int row) { return p1_swz(row, R_PAD); }
 };
-
-NMFMU_HD int p1_swz(int row, int r_pad) {
-  const int sp = r_pad / 8;
-  const int shift = sp >= 16 ? 0 : (sp == 8 ? 1 : 2);
-  const int mask = sp >= 16 ? 15 : sp - 1;
-  return (row >> shift) & mask;
-}
 
 // byte offset of element (row, r) inside a P1 plane
 NMFMU_HD int64_t p1_offset(int64_t row, int r, int r_pad) {

@@ -84,6 +84,7 @@ __device__ __forceinline__ float unpack_hi(uint32_t w) {
 // 256: X tiles go through a two-slot LDS ring (LDS-DMA) instead of straight into registers (global_load_dwordx4, two
 //      buffers, two tiles ahead): 32 KiB more LDS-DMA writes and LDS reads per tile, measured 5 % slower
 // 512: operand prefetch ring 8 deep instead of 4
+// 16384: single panel image -- G2's operands by ds_read_b64_tr_b16 from the row-major tile (see PPCfg::TR)
 // 8192: numerator accumulators in AGPRs ("a" operands of the MFMAs) -- measured 1-2 % slower, not instantiated
 // 1024 / 2048 (timing only): the panel DMA / the X loads are issued twice -- marginal cost of one VMEM instruction
 template <int R_PAD, int OPT, int MODE, int VAR>
@@ -94,10 +95,19 @@ struct PPCfg {
   static constexpr int ROWB = 2 * R_PAD;     // bytes per P1 row
   static constexpr int IMG = kBK * ROWB;     // bytes of one image tile
   static constexpr bool LOSS = MODE == kModeLoss;
-  static constexpr int NSLOT = 3, LEAD = 2;  // panel ring depth; P1 runs LEAD tiles ahead, P2 LEAD - 1
+  // TR (experimental, VAR bit 16384, padded rank 128 only): ONE panel image.  G2's k-contiguous operands are gathered
+  // from the row-major P1 tile with the transposing read ds_read_b64_tr_b16 (two per MFMA) instead of coming from a
+  // second, transposed image: half the panel LDS-DMA per tile and 64 KiB of LDS instead of 96.  Parity-green and
+  // bank-conflict free, but NOT faster on MI355X (profiles/r02_clock.md: 3 073 instead of 2 680 cycles per tile at a
+  // 7 % higher clock; W half-step 0.164 vs 0.155 ms): the extra 16 LDS reads and 32 address XORs per tile cost what
+  // the halved panel stream saves.  The two-image path stays the default.
+  static constexpr bool TR = (VAR & 16384) != 0 && !LOSS;
+  static constexpr int LEAD = 2;             // P1 runs LEAD tiles ahead, P2 LEAD - 1
+  static constexpr int NSLOT = TR ? 4 : 3;   // P1 ring depth (TR: tile t-1 is still read by G2 while t+2 arrives)
+  static constexpr int NSLOT2 = TR ? 0 : 3;  // P2 ring depth
   static constexpr int XTILE = BM * kBK * 2; // one X tile: 256 rows x 64 columns x 2 bytes = 32 KiB
   static constexpr bool XREG = (VAR & 256) == 0;  // X straight into registers (two buffers); bit 256: LDS ring instead
-  static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = 2 * NSLOT * IMG;
+  static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = (NSLOT + NSLOT2) * IMG;
   static constexpr int LDS_MAIN = X_BASE + (XREG ? 0 : 2 * XTILE);
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
   static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
@@ -139,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   constexpr bool SCALED = C::SCALED;
   u32x4 q[KS];
   {
-    const int sw = ((m0 >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    const int sw = P1Swz<R_PAD>::of(m0) << 4;
     const char* row = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m0 * ROWB;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int row = 32 * ((j >> 2) & 1) + 16 * tt + (j & 3) + 4 * (j >> 3);
-    const int sw = ((row >> P1Swz<R_PAD>::SHIFT) & P1Swz<R_PAD>::MASK) << 4;
+    const int sw = P1Swz<R_PAD>::of(row) << 4;
     a_base[tt] = row * ROWB + ((hl * 16) ^ sw);
   }
   int b_base[2][2];
@@ -168,6 +178,26 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) b_base[tt][m2] = j * 128 + (((4 * hl + 2 * tt + m2) << 4) ^ (((j >> 1) & 7) << 4));
   static_assert((KS - 1) * 32 < ROWB, "k-step bits stay inside one P1 row");
+  // TR: ds_read_b64_tr_b16 works on groups of 16 lanes; lane 4a+b of a group receives element b of the 8-byte chunks
+  // addressed by lanes a, a+4, a+8, a+12 (probed on gfx950: tools/ubench/tr_probe.hip).  With source lane s = a + 4i
+  // pointing at (panel row k0 + i, ranks 4 (c0 + a) .. +3) the group reads a [4 rows] x [16 ranks] block and lane l
+  // ends up with rank 4 c0 + l for rows k0 .. k0+3: two such reads (rows +0..3 and +4..7) are the MFMA B operand of
+  // G2, whose lane (j, hl) needs the 8 contraction rows 32 hl + 16 tt + 8 m2 + (0..7) of rank 32 rt + j.
+  // t_base[tt][m2][h]: byte offset of this lane's chunk for rank tile 0; rank tile rt = XOR with rt * 64 (slot bits 2-3).
+  int t_base[2][2][2];
+  if constexpr (C::TR) {
+    const int grp = lane >> 4, s16 = lane & 15;
+    const int cslot = 2 * (grp & 1) + ((s16 & 3) >> 1);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2);
+          t_base[tt][m2][h] = row * ROWB + ((cslot ^ P1Swz<R_PAD>::of(row)) << 4) + 8 * (s16 & 1);
+        }
+  }
 
   f32x16 acc[C::LOSS ? 1 : RT];
 #pragma unroll
@@ -217,11 +247,13 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     };
     // ring slots advance by one per tile: offsets are carried incrementally (no division in the loop)
     unsigned p1_issue_off = (unsigned)(C::LEAD % C::NSLOT) * IMG;         // slot of P1(t + LEAD) at t = 0
-    unsigned p2_issue_off = (unsigned)((C::LEAD - 1) % C::NSLOT) * IMG;   // slot of P2(t + LEAD - 1) at t = 0
+    constexpr int NS2 = C::NSLOT2 > 0 ? C::NSLOT2 : 1;
+    unsigned p2_issue_off = (unsigned)((C::LEAD - 1) % NS2) * IMG;        // slot of P2(t + LEAD - 1) at t = 0
     auto next_off = [&](unsigned off) { return off == (unsigned)(C::NSLOT - 1) * IMG ? 0u : off + IMG; };
+    auto next_off2 = [&](unsigned off) { return off == (unsigned)(NS2 - 1) * IMG ? 0u : off + IMG; };
     auto issue_panel = [&](int t) {   // called in E(t) by waves 0-3: P1(t + LEAD), P2(t + LEAD - 1)
       dma_img(p1src + (size_t)clampt(t + C::LEAD) * IMG, C::P1_BASE + p1_issue_off);
-      if constexpr (!C::LOSS) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
+      if constexpr (!C::LOSS && !C::TR) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
     };
     auto issue_x = [&](int t) {       // this wave's 4 KiB of X(t) -> X ring slot t & 1
       const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
@@ -279,32 +311,56 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     // They start at the slot of tile 0 (P1) / tile -1 (P2) and are advanced in place by +IMG or -(NSLOT-1)*IMG once per
     // tile (advance_slots), so the lane-only parts a_base / b_base are dead after this point.
     int sa[2] = {a_base[0] + C::P1_BASE, a_base[1] + C::P1_BASE};
-    int sb[2][2];
+    int sb[2][2];        // !TR: P2 slot of tile t-1
+    int tb[2][2][2];     //  TR: P1 slot of tile t-1
+    constexpr int BACK = C::TR ? (C::NSLOT - 1) * IMG : (NS2 - 1) * IMG;   // slot of "tile -1" at the start
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] = b_base[tt][m2] + C::P2_BASE + (C::NSLOT - 1) * IMG;
-    int rd1 = 0, rd2 = (C::NSLOT - 1) * IMG;   // current slot offsets of sa / sb (uniform)
-    auto advance_slots = [&]() {   // sa -> P1 slot of the next tile, sb -> P2 slot of the tile before it
-      const int d1 = rd1 == (C::NSLOT - 1) * IMG ? -(C::NSLOT - 1) * IMG : IMG;
-      const int d2 = rd2 == (C::NSLOT - 1) * IMG ? -(C::NSLOT - 1) * IMG : IMG;
+      for (int m2 = 0; m2 < 2; ++m2) {
+        sb[tt][m2] = b_base[tt][m2] + C::P2_BASE + BACK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tb[tt][m2][h] = t_base[tt][m2][h] + C::P1_BASE + BACK;
+      }
+    int rd1 = 0, rd2 = BACK;   // current slot offsets of sa / (sb | tb) (uniform)
+    auto advance_slots = [&]() {   // sa -> P1 slot of the next tile, sb / tb -> slot of the tile before it
+      constexpr int LAST1 = (C::NSLOT - 1) * IMG, LAST2 = C::TR ? LAST1 : (NS2 - 1) * IMG;
+      const int d1 = rd1 == LAST1 ? -LAST1 : IMG;
+      const int d2 = rd2 == LAST2 ? -LAST2 : IMG;
       rd1 += d1, rd2 += d2;
       sa[0] += d1, sa[1] += d1;
       if constexpr (!C::LOSS) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] += d2;
+          for (int m2 = 0; m2 < 2; ++m2) {
+            if constexpr (C::TR) {
+              tb[tt][m2][0] += d2, tb[tt][m2][1] += d2;
+            } else {
+              sb[tt][m2] += d2;
+            }
+          }
       }
     };
     // The M segment is written instruction by instruction (asm volatile keeps the order): hipcc's scheduler re-orders a
     // builtin MFMA / ds_read stream and degrades the counted LDS waits to lgkmcnt(0).  Entry e of the operand stream
     // lives in ring[e % PF]; LDS returns in order, so "entry e has landed" = at most min(PF-1, NS-1-e) younger reads
     // outstanding.
+    // TR mode: every LDS read is an ordinary (compiler-visible) load, so that hipcc assembles the 128-bit operand from
+    // the two 64-bit transposing reads without copies and counts lgkmcnt itself; the MFMAs stay asm volatile, which
+    // keeps loads and MFMAs in program order.
+    using s16x4 = __attribute__((ext_vector_type(4))) short;
+    using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+    const unsigned smem_u = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto rd = [&](u32x4& dst, int addr, auto offc) {
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+      if constexpr (C::TR) dst = ld16(smem + addr + decltype(offc)::value);
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
     };
-    auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read of stream entry e
+    auto rd_tr = [&](int addr) -> u32x2 {
+      auto* p = (__attribute__((address_space(3))) s16x4*)(size_t)(smem_u + (unsigned)addr);
+      return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(p));
+    };
+    auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read(s) of stream entry e
       constexpr int e0 = decltype(ec)::value;
       constexpr bool g1 = decltype(g1c)::value;
       if constexpr (g1 && e0 < NSTEP1) {
@@ -312,7 +368,12 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       } else {
         constexpr int e = e0 - (g1 ? NSTEP1 : 0);
         constexpr int rt = e % RT, c = e / RT;
-        rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
+        if constexpr (C::TR) {
+          const u32x2 lo = rd_tr(tb[c >> 1][c & 1][0] ^ (rt * 64)), hi = rd_tr(tb[c >> 1][c & 1][1] ^ (rt * 64));
+          dst = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+          rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
+        }
       }
     };
     auto prefetch = [&](auto g1c) {   // first PF operands of the next M segment; issued in the preceding E segment
@@ -338,7 +399,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       static_for<NS>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         constexpr int younger = (NS - 1 - e) < (PF - 1) ? (NS - 1 - e) : (PF - 1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        if constexpr (!C::TR) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
         u32x4& op = ring[e % PF];
         if constexpr (e < N1) {
           constexpr int tt = e & 1, kk = e >> 1;
@@ -389,7 +450,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           if constexpr ((VAR & 1024) != 0) {
             if (!half) issue_panel(t);
           }
-        } else if constexpr (next_has_g1 && !C::LOSS) {   // tile nt-2: only P2(nt-1) is still needed
+        } else if constexpr (next_has_g1 && !C::LOSS && !C::TR) {   // tile nt-2: only P2(nt-1) is still needed
           if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
         }
       }
@@ -448,12 +509,12 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!tail) {
           if (!half) issue_panel(t);
-        } else if constexpr (next_has_g1 && !C::LOSS) {
+        } else if constexpr (next_has_g1 && !C::LOSS && !C::TR) {
           if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
         }
       }
       p1_issue_off = next_off(p1_issue_off);
-      p2_issue_off = next_off(p2_issue_off);
+      p2_issue_off = next_off2(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
       if constexpr (!(VAR & 8) && !tail) {        // ... before its slot / register buffer is refilled
         if constexpr (C::XREG) load_x(t + 2, x);
@@ -466,7 +527,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     if (!half) {
 #pragma unroll
       for (int i = 0; i < C::LEAD; ++i) dma_img(p1src + (size_t)clampt(i) * IMG, C::P1_BASE + i * IMG);
-      if constexpr (!C::LOSS) {
+      if constexpr (!C::LOSS && !C::TR) {
 #pragma unroll
         for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
       }

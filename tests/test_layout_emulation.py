@@ -16,9 +16,13 @@ EPS = np.float64(2.0 ** -23)
 # ---- layouts (mirror of csrc/nmfmu_layout.h) ---------------------------------------------------------------
 def p1_swz(row, r_pad):
     sp = r_pad // 8
-    shift = 0 if sp >= 16 else (1 if sp == 8 else 2)
-    mask = 15 if sp >= 16 else sp - 1
-    return (row >> shift) & mask
+    if sp >= 32:
+        return row & 15
+    if sp == 16:
+        return ((row & 3) << 2) | ((row >> 2) & 3)
+    if sp == 8:
+        return (((row >> 1) & 1) << 2) | ((row >> 2) & 3)
+    return (row >> 2) & 3
 
 
 def p1_offset(row, r, r_pad):  # in bf16 elements
@@ -203,3 +207,52 @@ def test_lds_reads_are_bank_conflict_free(r_pad):
                     addr = j * 128 + (((4 * hl + 2 * tt + m2) << 4) ^ (((j >> 1) & 7) << 4))
                     slots.add((addr % 256) // 16)
                 assert len(slots) == 16, ('P2', tt, m2)
+
+
+# ---- single panel image: the second GEMM's operands by ds_read_b64_tr_b16 (nmfmu_pp.h, PPCfg::TR) --------------------
+def _tr_read(img, addr):
+    """ds_read_b64_tr_b16 as probed on gfx950 (tools/ubench/tr_probe.hip): within each group of 16 lanes, lane 4a+b
+    receives element b of the four 8-byte chunks addressed by lanes a, a+4, a+8, a+12.  img: uint16 array (LDS image),
+    addr: 64 byte addresses -> (64, 4) elements."""
+    out = np.zeros((64, 4), dtype=img.dtype)
+    for lane in range(64):
+        g, l16 = lane >> 4, lane & 15
+        a, b = l16 >> 2, l16 & 3
+        for i in range(4):
+            src = 16 * g + a + 4 * i
+            out[lane, i] = img[addr[src] // 2 + b]
+    return out
+
+
+@pytest.mark.parametrize('r_pad', [32, 64, 128])
+def test_transposing_reads_gather_the_g2_operand_conflict_free(r_pad):
+    """For every (tt, m2, h, rt): the kernel's per-lane addresses make lane (j, hl) receive panel rows
+    32 hl + 16 tt + 8 m2 + 4 h + (0..3) of rank 32 rt + j from the swizzled row-major tile, and each 32-lane pass touches
+    every LDS bank exactly once (four rows x 64 bytes in four different bank quarters)."""
+    rowb = 2 * r_pad
+    tile = np.zeros(64 * r_pad, dtype=np.uint16)          # one 64-row P1 tile; value = row * 256 + rank (unique)
+    for row in range(64):
+        for r in range(r_pad):
+            tile[p1_offset(row, r, r_pad)] = row * 256 + r
+    for tt in range(2):
+        for m2 in range(2):
+            for h in range(2):
+                for rt in range(r_pad // 32):
+                    addr = []
+                    for lane in range(64):
+                        grp, s16 = lane >> 4, lane & 15
+                        cslot = 2 * (grp & 1) + ((s16 & 3) >> 1)
+                        row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2)
+                        base = row * rowb + ((cslot ^ p1_swz(row, r_pad)) << 4) + 8 * (s16 & 1)
+                        addr.append(base ^ (rt * 64))
+                    got = _tr_read(tile, addr)
+                    for lane in range(64):
+                        j, hl = lane & 31, lane >> 5
+                        for i in range(4):
+                            want = (32 * hl + 16 * tt + 8 * m2 + 4 * h + i) * 256 + 32 * rt + j
+                            assert got[lane, i] == want, (r_pad, tt, m2, h, rt, lane, i)
+                    for half in range(2):
+                        banks = []
+                        for lane in range(32 * half, 32 * half + 32):
+                            banks += [(addr[lane] // 4) % 64, (addr[lane] // 4 + 1) % 64]
+                        assert len(set(banks)) == 64, ('bank conflict', r_pad, tt, m2, h, rt, half)
