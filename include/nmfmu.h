@@ -138,6 +138,19 @@ int nmfmu_den_partial(const nmfmu_step* st, void* stream);
  * 2 = only what follows it (lets a caller bracket the dominant kernel with events). */
 int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream);
 
+/* The same half-step for beta == 1 WITHOUT the column-sum finalize launches between half-steps (nmf.py:122-131's
+ * H.sum / W.sum): the denominators arrive as `kl_nparts` partial column sums [kl_nparts][r_pad] of the panel -- the
+ * colsum_part buffer the panel's own last update (or nmfmu_pack_factor) left behind -- and every consuming workgroup
+ * reduces them itself in a fixed order; the owner's new partials are left in st->owner.colsum_part
+ * (nmfmu_colsum_nparts(st) of them; st->owner.colsum is NOT refreshed -- nmfmu_colsum_finalize does that on demand).
+ * nmfmu_parts_supported(st): 1 when the step runs on the ping-pong kernel (beta == 1, bf16 / fp16, padded rank <= 128,
+ * 256-row tiles).  nmfmu_pack_nparts(rows_pad): partial count nmfmu_pack_factor leaves. */
+int nmfmu_parts_supported(const nmfmu_step* st);
+int nmfmu_colsum_nparts(const nmfmu_step* st);
+int nmfmu_pack_nparts(int rows_pad);
+int nmfmu_colsum_finalize(const nmfmu_factor* fac, int nparts, int r_pad, void* stream);
+int nmfmu_mu_step_parts(const nmfmu_step* st, const float* kl_part, int kl_nparts, int phase, void* stream);
+
 /* nmfmu_slab_reduce: num_out = sum_s slab_num[s] (and den_out likewise unless NULL).  Used by the column-sharded
  * multi-GPU path so that one all-reduce carries [owner.rows_pad x r_pad] floats. */
 int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream);

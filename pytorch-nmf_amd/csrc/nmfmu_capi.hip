@@ -43,7 +43,7 @@ static bool pp_eligible(int r_pad, int precision, float beta) {
 }
 
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
-                   const float* fuse_kl_den = nullptr) {
+                   const float* fuse_kl_den = nullptr, const float* fuse_kl_part = nullptr, int fuse_kl_nparts = 0) {
   if (!st || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
   if (!st->xp && mode == kModeMU) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
@@ -72,11 +72,13 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   a.tiles_per_split = (a.ktiles + st->nsplit - 1) / st->nsplit;
   a.beta = st->beta;
   a.fuse_apply = 0;
-  if (fuse_kl_den) {  // beta == 1, nsplit == 1: apply in the epilogue
+  a.kl_part = nullptr, a.kl_nparts = 0;
+  if (fuse_kl_den || fuse_kl_part) {  // beta == 1, nsplit == 1: apply in the epilogue
     a.fuse_apply = 1;
     a.rank = st->rank;
     a.f = st->owner.f;
     a.kl_den = fuse_kl_den;
+    a.kl_part = fuse_kl_part, a.kl_nparts = fuse_kl_nparts;
     a.o1_hi = static_cast<uint16_t*>(st->owner.p1_hi), a.o1_lo = static_cast<uint16_t*>(st->owner.p1_lo);
     a.o2_hi = static_cast<uint16_t*>(st->owner.p2_hi), a.o2_lo = static_cast<uint16_t*>(st->owner.p2_lo);
     a.colsum_part = st->owner.colsum_part;
@@ -103,6 +105,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     return launch_pp(st->r_pad, opt, mode, var, a, grid, s);
   }
   if (st->precision == NMFMU_PREC_F16) return NMFMU_ERR_UNSUPPORTED;   // fp16 operands exist in the ping-pong kernel only
+  if (a.kl_part) return NMFMU_ERR_UNSUPPORTED;                          // so do partial-sum denominators
   switch (st->r_pad) {
     case 32: return launch_fused_r32(kind, x3, mode, stage, G, a, grid, s);
     case 64: return launch_fused_r64(kind, x3, mode, stage, G, a, grid, s);
@@ -253,6 +256,43 @@ int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* st
   return e;
 }
 
+static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
+                        int trainer, float ortho, float* grad, void* stream, const float* kl_part, int kl_nparts,
+                        int skip_finalize);
+
+int nmfmu_parts_supported(const nmfmu_step* st) {
+  if (!st) return 0;
+  return st->block_rows == 256 && st->stage == NMFMU_STAGE_DMA && pp_eligible(st->r_pad, st->precision, st->beta) ? 1 : 0;
+}
+
+int nmfmu_colsum_nparts(const nmfmu_step* st) {
+  if (!st || (st->block_rows != 128 && st->block_rows != 256)) return NMFMU_ERR_ARG;
+  // fused apply (nsplit == 1): one partial per workgroup tile; otherwise one per apply-kernel stripe
+  return st->nsplit == 1 ? st->owner.rows_pad / st->block_rows : st->owner.rows_pad / apply_stripe_rows(st->owner.rows_pad);
+}
+
+int nmfmu_pack_nparts(int rows_pad) { return rows_pad <= 0 ? NMFMU_ERR_ARG : rows_pad / apply_stripe_rows(rows_pad); }
+
+int nmfmu_colsum_finalize(const nmfmu_factor* fac, int nparts, int r_pad, void* stream) {
+  if (!fac || !fac->colsum || !fac->colsum_part || nparts <= 0) return NMFMU_ERR_ARG;
+  return launch_colsum_finalize(fac->colsum_part, nparts, r_pad, fac->colsum, S(stream));
+}
+
+int nmfmu_mu_step_parts(const nmfmu_step* st, const float* kl_part, int kl_nparts, int phase, void* stream) {
+  if (!st || phase < 0 || phase > 2 || !kl_part || kl_nparts <= 0) return NMFMU_ERR_ARG;
+  if (!nmfmu_parts_supported(st)) return NMFMU_ERR_UNSUPPORTED;
+  const bool fuse = st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum_part;
+  int e = 0;
+  if (phase != 2) {
+    e = fuse ? fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream), nullptr, kl_part, kl_nparts)
+             : nmfmu_mu_partial(st, stream);
+    if (e) return e;
+  }
+  if (phase != 1 && !fuse)
+    e = apply_common(st, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, stream, kl_part, kl_nparts, /*skip_finalize=*/1);
+  return e;
+}
+
 int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream) {
   if (!st || !num_out || !st->slab_num) return NMFMU_ERR_ARG;
   const int64_t plane = (int64_t)st->owner.rows_pad * st->r_pad;
@@ -266,7 +306,8 @@ int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void
 }
 
 static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
-                        int trainer, float ortho, float* grad, void* stream) {
+                        int trainer, float ortho, float* grad, void* stream, const float* kl_part,
+                        int kl_nparts, int skip_finalize) {
   if (!st || !st->owner.f) return NMFMU_ERR_ARG;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   ApplyArgs a{};
@@ -275,8 +316,9 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.den = num ? den : st->slab_den;
   a.nslab = num ? nslab : st->nsplit;
   a.kl_den = kl ? kl_den : nullptr;
+  a.kl_part = kl ? kl_part : nullptr, a.kl_nparts = kl_nparts, a.skip_finalize = skip_finalize;
   if (!a.num || a.nslab < 1) return NMFMU_ERR_ARG;
-  if (kl ? !a.kl_den : !a.den) return NMFMU_ERR_ARG;
+  if (kl ? (!a.kl_den && !a.kl_part) : !a.den) return NMFMU_ERR_ARG;
   a.p1_hi = st->owner.p1_hi, a.p1_lo = st->owner.p1_lo, a.p2_hi = st->owner.p2_hi, a.p2_lo = st->owner.p2_lo;
   a.colsum_part = st->owner.colsum_part, a.colsum = st->owner.colsum;
   a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
@@ -289,13 +331,13 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
 
 int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                    void* stream) {
-  return apply_common(st, num, den, nslab, kl_den, 0, 0.f, nullptr, stream);
+  return apply_common(st, num, den, nslab, kl_den, 0, 0.f, nullptr, stream, nullptr, 0, 0);
 }
 
 int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                         float ortho, float* grad, void* stream) {
   if (!(ortho >= 0.f)) return NMFMU_ERR_ARG;
-  return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream);
+  return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream, nullptr, 0, 0);
 }
 
 int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit) {

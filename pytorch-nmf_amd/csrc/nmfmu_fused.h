@@ -100,6 +100,8 @@ struct FusedArgs {
   int rank;               // logical rank (row pitch of f)
   float* f;               // owner fp32 master [M][rank]
   const float* kl_den;    // [R_PAD] column sums of the panel
+  const float* kl_part;   // or: [kl_nparts][R_PAD] partial column sums, reduced by every workgroup itself (nmfmu_pp.h)
+  int kl_nparts;
   uint16_t* o1_hi;        // owner images to refresh (same buffers a1_* were read from)
   uint16_t* o1_lo;
   uint16_t* o2_hi;

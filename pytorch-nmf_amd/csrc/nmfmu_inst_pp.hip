@@ -19,7 +19,6 @@ static int launch_pp_r(int opt, int mode, int var, const FusedArgs& a, int grid,
   if constexpr (R_PAD == 128) {   // experiment variants of the headline instance only (NMFMU_PP_VAR, see nmfmu_pp.h)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 1)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 4)
-    NMFMU_PP_CASE(kOpBf16, kModeMU, 256)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 512)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 128)
     NMFMU_PP_CASE(kOpBf16, kModeMU, 16384)

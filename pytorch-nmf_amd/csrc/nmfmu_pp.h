@@ -82,7 +82,8 @@ __device__ __forceinline__ float unpack_hi(uint32_t w) {
 //   32: no elementwise arithmetic (the ratio words are the raw X words)   64: no MFMAs
 // 128: s_memtime stamps of every segment of waves 0 and 4 of workgroup 0 into FusedArgs::loss_part
 // 256: X tiles go through a two-slot LDS ring (LDS-DMA) instead of straight into registers (global_load_dwordx4, two
-//      buffers, two tiles ahead): 32 KiB more LDS-DMA writes and LDS reads per tile, measured 5 % slower
+//      buffers, two tiles ahead): 32 KiB more LDS-DMA writes and LDS reads per tile, measured 5 % slower (no longer
+//      instantiated: its 160 KiB of LDS leave no room for the column-sum scratch)
 // 512: operand prefetch ring 8 deep instead of 4
 // 16384: single panel image -- G2's operands by ds_read_b64_tr_b16 from the row-major tile (see PPCfg::TR)
 // 8192: numerator accumulators in AGPRs ("a" operands of the MFMAs) -- measured 1-2 % slower, not instantiated
@@ -110,7 +111,10 @@ struct PPCfg {
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = (NSLOT + NSLOT2) * IMG;
   static constexpr int LDS_MAIN = X_BASE + (XREG ? 0 : 2 * XTILE);
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
-  static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  // panel column sums (partials mode): [R_PAD] floats + [4][R_PAD] scratch, parked behind the rings during the loop
+  static constexpr int KL_OFF = LDS_MAIN;
+  static constexpr int LDS_KL = LOSS ? 0 : 5 * R_PAD * 4;
+  static constexpr int LDS_BYTES = (LDS_MAIN + LDS_KL) > LDS_EPI ? (LDS_MAIN + LDS_KL) : LDS_EPI;
   static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
   static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
   static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
@@ -532,6 +536,29 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
       }
     }
+    // partials mode: the panel's column sums (nmf.py:122-131) arrive as kl_nparts per-stripe partial sums; every
+    // workgroup reduces them itself -- here, in the shadow of the first tiles' DMA latency.  Four interleaved streams
+    // per column, eight loads in flight per thread, combined in a fixed order (identical bits in every workgroup).
+    if constexpr (!C::LOSS) {
+      if (a.fuse_apply && a.kl_part) {
+        float* kls = reinterpret_cast<float*>(smem + C::KL_OFF);   // [R_PAD] sums, then [4][R_PAD] stream sums
+        for (int idx = tid; idx < 4 * R_PAD; idx += C::THREADS) {
+          const int qq = idx / R_PAD, r = idx - qq * R_PAD;
+          const float* src = a.kl_part + (size_t)qq * R_PAD + r;
+          float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          int pp = qq;
+          for (; pp + 28 < a.kl_nparts; pp += 32, src += 32 * R_PAD) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)u * 4 * R_PAD];
+          }
+          for (; pp < a.kl_nparts; pp += 4, src += 4 * R_PAD) s8[0] += src[0];
+          kls[R_PAD + idx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        }
+        __syncthreads();
+        for (int r = tid; r < R_PAD; r += C::THREADS)
+          kls[r] = (kls[R_PAD + r] + kls[2 * R_PAD + r]) + (kls[3 * R_PAD + r] + kls[4 * R_PAD + r]);
+      }
+    }
     u32x4 xA[4], xB[4];   // XREG: X(even tiles) / X(odd tiles); otherwise xA is the per-segment scratch copy
     if constexpr (C::XREG) {
       load_x(0, xA);
@@ -624,11 +651,18 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       constexpr int LDT = R_PAD;
       float* tile = reinterpret_cast<float*>(smem) + wave * (32 * LDT);
       float den[RT], csum[RT];
+      if (a.kl_part) {
+        // reduced in the prologue (kl_sums above) into LDS beyond the rings; read before the staging tile is written
+        const float* kls = reinterpret_cast<const float*>(smem + C::KL_OFF);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        den[rt] = a.kl_den[rt * 32 + j_e];
-        csum[rt] = 0.f;
+        for (int rt = 0; rt < RT; ++rt) den[rt] = kls[rt * 32 + j_e];
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) den[rt] = a.kl_den[rt * 32 + j_e];
       }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) csum[rt] = 0.f;
       static_for<RT>([&](auto rtc) {
         constexpr int rt = decltype(rtc)::value;
         const int r = rt * 32 + j_e;

@@ -77,6 +77,11 @@ SIGNATURES = {
     'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_den_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_mu_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_parts_supported': (C.c_int, [C.POINTER(Step)]),
+    'nmfmu_colsum_nparts': (C.c_int, [C.POINTER(Step)]),
+    'nmfmu_pack_nparts': (C.c_int, [C.c_int]),
+    'nmfmu_colsum_finalize': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_void_p]),
+    'nmfmu_mu_step_parts': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_mu_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_trainer_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
