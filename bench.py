@@ -473,7 +473,7 @@ def main():
         # (recording inside the timed region costs ~2 % and folds the dispatch gap in front of each kernel into its
         # span; these spans agree with the rocprofv3 kernel-trace durations)
         if want_roofline:
-            eng.timer = KernelTimer(4 * a.steps + 8)
+            eng.timer = KernelTimer(6 * a.steps + 8)
             ar_ms = []
             for _ in range(a.steps):
                 step()

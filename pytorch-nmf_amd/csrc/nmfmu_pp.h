@@ -144,6 +144,24 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   const int m0 = mb * C::BM + wave * 32 + j;
 
   if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: saturate
+  // VAR & 128: stamps of wave 0 / wave 4 of workgroup 0 -- shader clock and the constant 100 MHz clock at kernel entry
+  // (slot 2), at the start (0) and the end (1) of the tile loop and at kernel exit (3): cycles per tile, the core
+  // frequency, and what the prologue / epilogue cost, unperturbed (nothing inside the loop)
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.loss_part);
+  auto stamp = [&](int slot) {
+    if constexpr ((VAR & 128) != 0 && MODE == kModeMU) {
+      if (blockIdx.x == 0 && (wave & 3) == 0) {
+        const unsigned long long c = __builtin_amdgcn_s_memtime();
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+          dbg[(half * 4 + slot) * 4 + 0] = c;
+          dbg[(half * 4 + slot) * 4 + 1] = r;
+          dbg[(half * 4 + slot) * 4 + 2] = (unsigned long long)nt;
+        }
+      }
+    }
+  };
+  stamp(2);
 
   // ---- owner fragments (B operand of G1): row m0, rank slice 16*kk + 8*hl .. +7
   // bf16: the fragments are scaled by 2^23 = 1 / eps (exact), so that the "+ eps" of nmf.py:65 becomes "+ 1.0" -- an
@@ -287,22 +305,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-    };
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.loss_part);
-    // VAR & 128: two stamps per wave 0 / wave 4 of workgroup 0 -- shader clock and the constant 100 MHz clock at the
-    // start (slot 0) and at the end (slot 1) of the tile loop: cycles per tile and the core frequency, unperturbed
-    auto stamp = [&](int slot) {
-      if constexpr ((VAR & 128) != 0) {
-        if (blockIdx.x == 0 && (wave & 3) == 0) {
-          const unsigned long long c = __builtin_amdgcn_s_memtime();
-          const unsigned long long r = __builtin_amdgcn_s_memrealtime();
-          if (lane == 0) {
-            dbg[(half * 2 + slot) * 4 + 0] = c;
-            dbg[(half * 2 + slot) * 4 + 1] = r;
-            dbg[(half * 2 + slot) * 4 + 2] = (unsigned long long)nt;
-          }
-        }
-      }
     };
 
     uint32_t gn[2][8];
@@ -736,6 +738,10 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         }
       });
     }
+  }
+  if constexpr ((VAR & 128) != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
+    stamp(3);
   }
 }
 

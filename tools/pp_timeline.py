@@ -22,6 +22,9 @@ W = torch.randn(Cc, R, device=dev, generator=g).abs_()
 H = torch.randn(N, R, device=dev, generator=g).abs_()
 lib = _capi.load()
 buf = torch.zeros(64, dtype=torch.int64, device=dev)
+import ctypes
+tm = ctypes.c_void_p()
+from torchnmf_amd.engine import KernelTimer
 _capi.check(lib.nmfmu_debug_set_buffer(buf.data_ptr()), 'debug')
 prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 eng = DenseMU(V, W, H, 1.0, precision=prec)
@@ -34,12 +37,14 @@ for which in os.environ.get('PP_STEPS', 'h,w').split(','):
             eng.w_step(); eng.h_step()
         (eng.h_step if which == 'h' else eng.w_step)()
         torch.cuda.synchronize()
-        st = buf.cpu().numpy()[:16].reshape(4, 4)
+        st = buf.cpu().numpy()[:32].reshape(2, 4, 4)[0]
         nt = int(st[0, 2])
         cyc = int(st[1, 0] - st[0, 0]); ref = int(st[1, 1] - st[0, 1])
-        res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0))
+        res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0, (st[0, 1] - st[2, 1]) * 0.01, (st[3, 1] - st[1, 1]) * 0.01,
+                    (st[3, 1] - st[2, 1]) * 0.01))
     r = np.array(res)
     print(f'{prec} VAR={os.environ.get("NMFMU_PP_VAR")} {which}-step cols={Cc}: {nt} tiles/WG, cycles/tile {np.median(r[:, 0]):.0f}, '
           f'core clock {np.median(r[:, 1]):.0f} MHz, {np.median(r[:, 2]):.1f} ns/tile  '
-          f'=> tile loop {np.median(r[:, 2]) * nt / 1e3:.1f} us')
+          f'=> tile loop {np.median(r[:, 2]) * nt / 1e3:.1f} us; prologue {np.median(r[:, 3]):.1f} us, epilogue {np.median(r[:, 4]):.1f} us, '
+          f'workgroup 0 entry->exit {np.median(r[:, 5]):.1f} us')
 _capi.check(lib.nmfmu_debug_set_buffer(None), 'debug')
