@@ -651,75 +651,103 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     if (a.fuse_apply) {
       // ---- nmf.py:78-92 in the epilogue (nsplit == 1: the workgroup owns complete rows); re-emits the owner's images
       constexpr int LDT = R_PAD;
+      constexpr int SP = R_PAD / 8;            // sixteen-byte image slots (8 ranks) per row
+      constexpr int NCH = (32 * SP) / 64;      // (row, slot) chunks per lane
       float* tile = reinterpret_cast<float*>(smem) + wave * (32 * LDT);
-      float den[RT], csum[RT];
-      if (a.kl_part) {
-        // reduced in the prologue (kl_sums above) into LDS beyond the rings; read before the staging tile is written
-        const float* kls = reinterpret_cast<const float*>(smem + C::KL_OFF);
+      // every lane keeps one slot (8 consecutive ranks) for the whole pass: 16-byte master loads / stores, one
+      // 16-byte row-major image store per chunk, denominators and column sums of those 8 ranks in registers
+      const int slot_e = lane_e % SP, rl0 = lane_e / SP;
+      float den8[8], csum8[8];
+      {
+        const float* dsrc = a.kl_part ? reinterpret_cast<const float*>(smem + C::KL_OFF) : a.kl_den;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) den[rt] = kls[rt * 32 + j_e];
-        __syncthreads();
-      } else {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) den[rt] = a.kl_den[rt * 32 + j_e];
+        for (int k = 0; k < 8; ++k) { den8[k] = dsrc[slot_e * 8 + k]; csum8[k] = 0.f; }
+        // (beta == 1 partials were reduced in the prologue into LDS beyond the rings; read before the tile is written)
+        if (a.kl_part) __syncthreads();
       }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) csum[rt] = 0.f;
+      // numerators -> the wave's staging tile [32][R_PAD]
       static_for<RT>([&](auto rtc) {
         constexpr int rt = decltype(rtc)::value;
-        const int r = rt * 32 + j_e;
-        float fold[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl_e;
-          fold[e] = (row < a.M && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl_e;
-          float fv = fold[e];
-          if (row < a.M && r < a.rank) {
-            const float neg = fmaxf(acc[rt][e], 0.f) + kEps;
-            float pos = den[rt];
-            if (a.l1 > 0.f) pos += a.l1;
-            if (a.l2 > 0.f) pos += a.l2 * fv;
-            float mult = neg / pos;
-            if (a.gamma != 1.f) mult = powf(mult, a.gamma);
-            fv *= mult;
-            a.f[(size_t)row * a.rank + r] = fv;
-          }
-          fold[e] = fv;
-          csum[rt] += fv;
-          tile[((e & 3) + 8 * (e >> 2) + 4 * hl_e) * LDT + r] = fv;
-        }
-        // transposed image: 4 consecutive owner rows of column r = 8 bytes
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const uint32_t h0 = pack_op<OPT>(fold[4 * q4], fold[4 * q4 + 1]);
-          const uint32_t h1 = pack_op<OPT>(fold[4 * q4 + 2], fold[4 * q4 + 3]);
-          const int64_t off = p2_offset(mrow0 + 8 * q4 + 4 * hl_e, r, R_PAD);
-          *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.o2_hi) + off) = make_uint2(h0, h1);
-        }
+        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hl_e) * LDT + rt * 32 + j_e] = acc[rt][e];
       });
       __syncthreads();
-      // row-major image from the LDS tile: 32 rows x R_PAD/8 sixteen-byte slots per wave
-      constexpr int SP = R_PAD / 8;
+      const bool vec = (a.rank & 3) == 0;
+#pragma unroll 2
+      for (int i = 0; i < NCH; ++i) {
+        const int rl = i * (64 / SP) + rl0, row = mrow0 + rl, r0 = slot_e * 8;
+        float* trow = tile + rl * LDT + r0;
+        float* frow = a.f + (size_t)row * a.rank + r0;
+        float fv[8], nm[8];
+        *reinterpret_cast<float4*>(nm) = *reinterpret_cast<const float4*>(trow);
+        *reinterpret_cast<float4*>(nm + 4) = *reinterpret_cast<const float4*>(trow + 4);
 #pragma unroll
-      for (int i = 0; i < (32 * SP) / 64; ++i) {
-        const int chunk = i * 64 + lane_e, rl = chunk / SP, slot = chunk % SP;
-        const float* src = tile + rl * LDT + slot * 8;
+        for (int h = 0; h < 2; ++h) {
+          const bool in = row < a.M && r0 + 4 * h < a.rank;
+          if (in && vec) {
+            *reinterpret_cast<float4*>(fv + 4 * h) = *reinterpret_cast<const float4*>(frow + 4 * h);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[4 * h + k] = (in && r0 + 4 * h + k < a.rank) ? frow[4 * h + k] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float neg = fmaxf(nm[k], 0.f) + kEps;
+          float pos = den8[k];
+          if (a.l1 > 0.f) pos += a.l1;
+          if (a.l2 > 0.f) pos += a.l2 * fv[k];
+          float mult = neg / pos;
+          if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+          // padding rows / ranks stay exactly 0 (their denominators may be 0: 0 * inf)
+          fv[k] = (row < a.M && r0 + k < a.rank) ? fv[k] * mult : 0.f;
+          csum8[k] += fv[k];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool in = row < a.M && r0 + 4 * h < a.rank;
+          if (in && vec) {
+            *reinterpret_cast<float4*>(frow + 4 * h) = *reinterpret_cast<const float4*>(fv + 4 * h);
+          } else if (in) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (r0 + 4 * h + k < a.rank) frow[4 * h + k] = fv[4 * h + k];
+          }
+        }
+        *reinterpret_cast<float4*>(trow) = *reinterpret_cast<const float4*>(fv);
+        *reinterpret_cast<float4*>(trow + 4) = *reinterpret_cast<const float4*>(fv + 4);
         u32x4 hi;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(src[2 * qq], src[2 * qq + 1]);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(mrow0 + rl, slot * 8, R_PAD)) = hi;
+        for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(fv[2 * qq], fv[2 * qq + 1]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(row, r0, R_PAD)) = hi;
       }
       __syncthreads();
-      // partial column sums of this workgroup's rows: lane_e halves, then the waves (fixed order)
+      // transposed image from the updated tile: 8 consecutive owner rows of one rank = one sixteen-byte slot
+#pragma unroll
+      for (int ii = 0; ii < R_PAD / 64 + (R_PAD < 64 ? 1 : 0); ++ii) {
+        const int r = ii * 64 + lane_e;
+        if (r < R_PAD) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float* src = tile + (g * 8) * LDT + r;
+            u32x4 hi;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(src[(2 * qq) * LDT], src[(2 * qq + 1) * LDT]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o2_hi) + p2_offset(mrow0 + g * 8, r, R_PAD)) = hi;
+          }
+        }
+      }
+      __syncthreads();
+      // partial column sums of this workgroup's rows: the lanes sharing a slot, then the waves (fixed order)
       float* red = reinterpret_cast<float*>(smem);  // [WAVES][R_PAD]
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const float tot = csum[rt] + __shfl_xor(csum[rt], 32, 64);
-        if (hl_e == 0) red[wave * R_PAD + rt * 32 + j_e] = tot;
+      for (int k = 0; k < 8; ++k) {
+        float tot = csum8[k];
+        if constexpr (SP <= 32) tot += __shfl_xor(tot, 32, 64);
+        if constexpr (SP <= 16) tot += __shfl_xor(tot, 16, 64);
+        if constexpr (SP <= 8) tot += __shfl_xor(tot, 8, 64);
+        if constexpr (SP <= 4) tot += __shfl_xor(tot, 4, 64);
+        if (lane_e < SP) red[wave * R_PAD + slot_e * 8 + k] = tot;
       }
       __syncthreads();
       for (int r = tid_e; r < R_PAD; r += C::THREADS) {
