@@ -168,9 +168,21 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
       }
       if constexpr (!PACK_ONLY) {
         const size_t e = (size_t)row * R_PAD + r;
-        float4 n4 = *reinterpret_cast<const float4*>(a.num + e);
-        for (int s = 1; s < a.nslab; ++s) {
-          const float4 v = *reinterpret_cast<const float4*>(a.num + s * plane + e);
+        // k-split partials: eight independent loads in flight per lane (the slabs are read exactly once: HBM latency,
+        // not bandwidth, bounds a dependent chain), combined in a fixed order
+        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s0 = 0;
+        for (; s0 + 8 <= a.nslab; s0 += 8) {
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          f32x4_t v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(a.num + (size_t)(s0 + u) * plane + e));
+#pragma unroll
+          for (int u = 0; u < 8; ++u) n4.x += v[u].x, n4.y += v[u].y, n4.z += v[u].z, n4.w += v[u].w;
+        }
+        for (; s0 < a.nslab; ++s0) {
+          const float4 v = *reinterpret_cast<const float4*>(a.num + (size_t)s0 * plane + e);
           n4.x += v.x, n4.y += v.y, n4.z += v.z, n4.w += v.w;
         }
         float neg[4] = {n4.x, n4.y, n4.z, n4.w};

@@ -159,6 +159,17 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           dbg[(half * 4 + slot) * 4 + 2] = (unsigned long long)nt;
         }
       }
+      // every workgroup: the 100 MHz clock at the four points ([64 + 5 * wg + slot]) and where it ran ([.. + 4]:
+      // XCC_ID << 32 | HW_ID) -- launch ramp and the spread of the workgroups' finishing times
+      if (wave == 0) {
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+          dbg[64 + 5 * blockIdx.x + slot] = r;
+          if (slot == 2)
+            dbg[64 + 5 * blockIdx.x + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                                           (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+        }
+      }
     }
   };
   stamp(2);
@@ -169,19 +180,23 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   // the epilogue removes (exact again).  This frees the sixteen registers a broadcast eps tile would occupy.
   // fp16 has no exponent range for that: it seeds the accumulators from a register tile of eps.
   constexpr bool SCALED = C::SCALED;
+  // (loaded in the prologue below, after the first panel tiles' DMA and the first X loads have been issued: one
+  // cold-miss latency for all three instead of two in a row)
   u32x4 q[KS];
-  {
+  auto load_owner = [&]() {
     const int sw = P1Swz<R_PAD>::of(m0) << 4;
     const char* row = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m0 * ROWB;
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      q[kk] = ld16(row + ((kk * 32 + hl * 16) ^ sw));
-      if constexpr (SCALED) {
+    for (int kk = 0; kk < KS; ++kk) q[kk] = ld16(row + ((kk * 32 + hl * 16) ^ sw));
+  };
+  auto scale_owner = [&]() {
+    if constexpr (SCALED) {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[kk][i] = pack_bf16(bf16_lo(q[kk][i]) * 8388608.f, bf16_hi(q[kk][i]) * 8388608.f);
-      }
     }
-  }
+  };
   // ---- per-lane LDS offsets (same maps as nmfmu_fused.h: row permutation pi for G1, swizzled 16-byte slots).
   // G1 operand of step (tt, kk): a_base[tt] ^ (kk * 32)  -- the k-step only flips bits 5..7 of the slot offset, which
   // neither the row part (a multiple of ROWB) nor the ring-slot offset (a multiple of IMG) touches, so ONE register per
@@ -565,13 +580,16 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     if constexpr (C::XREG) {
       load_x(0, xA);
       load_x(1, xB);
+      load_owner();
       asm volatile("s_waitcnt vmcnt(0)"
                    : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
     } else {
       issue_x(0);
       issue_x(1);
+      load_owner();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    scale_owner();
     if constexpr (VAR & 2) {
       if (half) __builtin_amdgcn_s_setprio(1);
     }

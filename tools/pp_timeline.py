@@ -21,7 +21,7 @@ V = torch.rand(N, Cc, device=dev, generator=g).bfloat16().float()
 W = torch.randn(Cc, R, device=dev, generator=g).abs_()
 H = torch.randn(N, R, device=dev, generator=g).abs_()
 lib = _capi.load()
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+buf = torch.zeros(64 + 5 * 4096, dtype=torch.int64, device=dev)
 import ctypes
 tm = ctypes.c_void_p()
 from torchnmf_amd.engine import KernelTimer
@@ -43,6 +43,17 @@ for which in os.environ.get('PP_STEPS', 'h,w').split(','):
         res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0, (st[0, 1] - st[2, 1]) * 0.01, (st[3, 1] - st[1, 1]) * 0.01,
                     (st[3, 1] - st[2, 1]) * 0.01))
     r = np.array(res)
+    # all workgroups of the last launch: entry / loop start / loop end / exit relative to the earliest entry
+    grid = (eng.step_h if which == 'h' else eng.step_w)
+    nwg = (grid.owner.rows_pad // grid.block_rows) * grid.nsplit
+    wg = buf.cpu().numpy()[64:64 + 5 * nwg].reshape(nwg, 5)
+    tt = (wg[:, [2, 0, 1, 3]] - wg[:, 2].min()) * 0.01
+    xcc = (wg[:, 4] >> 32) & 0xf
+    q = lambda x: ' / '.join(f'{v:.1f}' for v in np.percentile(x, [0, 50, 90, 100]))
+    print(f'   all {nwg} workgroups (us; min / median / p90 / max): entry {q(tt[:, 0])}; loop start {q(tt[:, 1])}; loop end {q(tt[:, 2])}; '
+          f'exit {q(tt[:, 3])}; loop length {q(tt[:, 2] - tt[:, 1])}; epilogue {q(tt[:, 3] - tt[:, 2])}')
+    print('   per XCC: median loop length ' + ', '.join(f'{int(x)}:{np.median((tt[:, 2] - tt[:, 1])[xcc == x]):.1f}' for x in np.unique(xcc)) +
+          ' | max exit ' + ', '.join(f'{int(x)}:{tt[xcc == x, 3].max():.1f}' for x in np.unique(xcc)))
     print(f'{prec} VAR={os.environ.get("NMFMU_PP_VAR")} {which}-step cols={Cc}: {nt} tiles/WG, cycles/tile {np.median(r[:, 0]):.0f}, '
           f'core clock {np.median(r[:, 1]):.0f} MHz, {np.median(r[:, 2]):.1f} ns/tile  '
           f'=> tile loop {np.median(r[:, 2]) * nt / 1e3:.1f} us; prologue {np.median(r[:, 3]):.1f} us, epilogue {np.median(r[:, 4]):.1f} us, '
