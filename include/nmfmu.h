@@ -216,6 +216,10 @@ int nmfmu_reconstruct(const float* owner, int m, const float* panel, int k, int 
 #define NMFMU_EPI_RATIO 0 /* D = A B^T (+eps); Gn = f(D, x) [and Gp, beta != 1] stored as bf16 planes (nmf.py:61-74)   */
 #define NMFMU_EPI_F32 1   /* D stored as fp32                                                                         */
 #define NMFMU_EPI_LOSS 2  /* beta_div(D, x) partial per workgroup into out[(m_pad/128) * (n_pad/128)] (metrics.py)    */
+#define NMFMU_EPI_FOLD 3  /* D = Y[(r,t)][(b,l)] (H numerator before the col2im sum, nmf.py:77/82 conv backward wrt the
+                             input) is not stored; out receives the diagonal sums of every 128 x 128 tile
+                             (nmfmu_fold_part_bytes) for nmfmu_conv_fold_parts_apply_h.  Planes only; t_batch .. t_lh
+                             describe H; needs taps >= 128 and Lh + taps - 1 >= 128 (nmfmu_fold_parts_supported)       */
 
 typedef struct nmfmu_gemm_desc {
   const void* a_hi; /* [m_pad][k_pad] bf16 */
@@ -286,6 +290,12 @@ int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const fl
  * nmf.py:78-92 for H (batch, rank, lh) in place. */
 int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, const float* y_num, const float* y_den,
                             const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream);
+/* The same update from the per-tile diagonal sums of NMFMU_EPI_FOLD GEMMs (p_num / p_den) instead of Y: saves writing
+ * and re-reading 4 * R*T * B*L bytes per GEMM.  Deterministic (fixed gather order). */
+size_t nmfmu_fold_part_bytes(int m_pad, int n_pad);
+int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps);
+int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
+                                  const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream);
 
 /* NMF2D / NMF3D (nmf.py:782-942): the same two steps with ndim = 2 or 3 shift axes (lh[ndim], taps[ndim] outermost
  * first; ndim = 1 is NMFD).  Flattened, (b,l) has batch * prod(lh + taps - 1) rows and (r,t) rank * prod(taps) columns;

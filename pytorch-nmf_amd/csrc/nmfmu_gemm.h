@@ -8,6 +8,9 @@
 //   EPI_RATIO  D = S:  Gn = f(S, X) (and Gp for beta != 1) written as bf16 (hi[, lo]) planes, row-major [m][n]
 //   EPI_F32    D written as fp32 row-major
 //   EPI_LOSS   beta-divergence of D against X, one partial per workgroup
+//   EPI_FOLD   D = Y[(r,t)][(b,l)] is never stored: the tile's diagonal sums (l - t constant) go out instead, 1 KiB per
+//              (r, b) segment of the tile; nmfmu_conv_fold_parts_apply_h gathers them (the col2im sum of the conv1d
+//              backward pass wrt H without the 4 * R*T * B*L bytes write + read of Y)
 //
 // Both operands are bf16 planes (hi[, lo]) with k contiguous, zero padded to multiples of 128 in every dimension.
 // 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles), BK = 64, LDS double buffered by
@@ -22,7 +25,8 @@
 
 namespace nmfmu {
 
-enum GemmEpi : int { kEpiRatio = 0, kEpiF32 = 1, kEpiLoss = 2 };
+enum GemmEpi : int { kEpiRatio = 0, kEpiF32 = 1, kEpiLoss = 2, kEpiFold = 3 };
+constexpr int kFoldLd = 129;   // LDS pitch (floats) of the EPI_FOLD tile
 
 struct GemmArgs {
   const uint16_t* a_hi;  // [m_pad][k_pad]
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = (EPI != kEpiF32 && BETA != kEuc) ? kEps : 0.f;
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = ((EPI == kEpiRatio || EPI == kEpiLoss) && BETA != kEuc) ? kEps : 0.f;
 
   const int a_rowoff = (wm * 64 + j) * 128;  // + mi * 4096
   const int b_rowoff = (wn * 64 + j) * 128;
@@ -218,6 +222,58 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
   }
 
   // ---------------- epilogue: accumulator e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column j
+  if constexpr (EPI == kEpiFold) {
+    // rows m = r T + t, columns n = b L + l; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)] runs along the diagonals
+    // n - m = j + (b L - r T).  With T, L >= 128 a tile holds at most two r and two b: four (r, b) segments, 255
+    // diagonals each.  The tile goes through LDS (the staging buffers, every wave is past the last barrier; rows padded
+    // to 129 floats: the lanes of a wave walk their diagonals from different rows, and with a 128-float pitch the short
+    // diagonals of one wave would all sit in one bank), thread dd sums diagonal dd = nl - ml + 127 top to bottom, split
+    // by segment.  Entries whose j falls outside
+    // [0, Lh) land on diagonals the gather never reads; padding rows / columns are exact zeros.
+    float* tl = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          tl[(wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl) * kFoldLd + wn * 64 + ni * 32 + j] = acc[mi][ni][e];
+    __syncthreads();
+    const int L = a.tLh + a.tT - 1;
+    const int rb = (bm * 128 / a.tT + 1) * a.tT - bm * 128;   // first tile row of the second r (>= 128: none)
+    const int nb = (bn * 128 / L + 1) * L - bn * 128;         // first tile column of the second b
+    const int dd = tid;
+    if (dd < 255) {
+      // every (second r?, second b?) segment of a diagonal is one contiguous run of rows: the r switch is at row rb,
+      // the b switch at row nb - (dd - 127); straight sums over up to four runs, four independent partial sums each
+      const int lo = max(0, 127 - dd), hi1 = min(127, 254 - dd) + 1;
+      const int rsw = min(max(rb, lo), hi1), bsw = min(max(nb - dd + 127, lo), hi1);
+      const float* pd = tl + dd - 127;
+      auto run = [&](int r0, int r1) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        int ml = r0;
+        for (; ml + 16 <= r1; ml += 16) {   // sixteen LDS reads in flight (the reads, not the adds, bound this loop)
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = pd[(ml + u) * (kFoldLd + 1)];
+#pragma unroll
+          for (int u = 0; u < 16; u += 4) p0 += v[u], p1 += v[u + 1], p2 += v[u + 2], p3 += v[u + 3];
+        }
+        for (; ml + 4 <= r1; ml += 4) {
+          p0 += pd[ml * (kFoldLd + 1)], p1 += pd[(ml + 1) * (kFoldLd + 1)], p2 += pd[(ml + 2) * (kFoldLd + 1)], p3 += pd[(ml + 3) * (kFoldLd + 1)];
+        }
+        for (; ml < r1; ++ml) p0 += pd[ml * (kFoldLd + 1)];
+        return (p0 + p1) + (p2 + p3);
+      };
+      const float s0 = run(lo, min(rsw, bsw));        // first r, first b
+      const float s1 = run(max(lo, bsw), rsw);        // first r, second b
+      const float s2 = run(rsw, max(rsw, bsw));       // second r, first b   (rows [rsw, bsw))
+      const float s3 = run(max(rsw, bsw), hi1);       // second r, second b
+      float* po = a.out + ((size_t)(bm * gridDim.x + bn) * 4) * 256 + dd;
+      po[0] = s0, po[256] = s1, po[512] = s2, po[768] = s3;
+    }
+    return;
+  }
   float lacc = 0.f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -262,16 +318,17 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
 template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3>;
+  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < 128 * kFoldLd * 4) ? 128 * kFoldLd * 4 : C::LDS_BYTES;
   auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       C::LDS_BYTES);
+                                       kLds);
     if (e != hipSuccess) return (int)e;
     *flag = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_pad / 128, a.m_pad / 128), dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_pad / 128, a.m_pad / 128), dim3(256), kLds, s, a);
   return (int)hipGetLastError();
 }
 

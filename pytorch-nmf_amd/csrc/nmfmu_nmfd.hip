@@ -29,6 +29,8 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, const GemmArgs& a, hipS
     return x3 ? launch_gemm_one<true, kEpiF32, kEuc>(a, s) : launch_gemm_one<false, kEpiF32, kEuc>(a, s);
   if (epi == kEpiF32 && ops == kOpsBHuT)
     return x3 ? launch_gemm_one<true, kEpiF32, kEuc, kOpsBHuT>(a, s) : launch_gemm_one<false, kEpiF32, kEuc, kOpsBHuT>(a, s);
+  if (epi == kEpiFold && ops == kOpsPlanes)
+    return x3 ? launch_gemm_one<true, kEpiFold, kEuc>(a, s) : launch_gemm_one<false, kEpiFold, kEuc>(a, s);
 #undef GB
 #undef G1
   return -2;
@@ -297,6 +299,40 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
   }
 }
 
+// The same update from the diagonal sums an EPI_FOLD GEMM left behind (nmfmu_gemm.h): part[(tm, tn)][seg][dd], 128 x 128
+// tiles of Y, seg = 2 * (second r of the tile row) + (second b of the tile column), dd = (n - m) - 128 (tn - tm) + 127.
+// A (b, r, j) collects one value per tile its diagonal crosses: <= ceil(T/128)+1 tile rows x <= 2 tile columns, always
+// in the same order.  One thread per j: consecutive threads read consecutive dd.
+__global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __restrict__ H, int B, int R, int Lh, int T,
+                                                                      const float* __restrict__ pnum,
+                                                                      const float* __restrict__ pden,
+                                                                      const float* __restrict__ kl_den, int tiles_n,
+                                                                      float l1, float l2, float gamma) {
+  const int L = Lh + T - 1;
+  const int jblocks = (Lh + 255) / 256;
+  const int jb = blockIdx.x % jblocks, r = (blockIdx.x / jblocks) % R, b = blockIdx.x / (jblocks * R);
+  const int jx = jb * 256 + threadIdx.x;
+  if (jx >= Lh) return;
+  const int m_lo = r * T, m_hi = m_lo + T;
+  const int diag = jx + b * L - m_lo;        // n - m of every element of this sum
+  float neg = 0.f, pos = 0.f;
+  for (int tm = m_lo / 128; tm <= (m_hi - 1) / 128; ++tm) {
+    const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
+    const int rbit = r > (tm * 128) / T ? 2 : 0;
+    const int na = b * L + jx + ta, nz = b * L + jx + tb - 1;
+    for (int tn = na / 128; tn <= nz / 128; ++tn) {
+      const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
+      const int dd = diag - 128 * (tn - tm) + 127;
+      const size_t i = ((size_t)(tm * tiles_n + tn) * 4 + seg) * 256 + dd;
+      neg += pnum[i];
+      if (!kl_den) pos += pden[i];
+    }
+  }
+  if (kl_den) pos = kl_den[r];
+  const size_t i = ((size_t)b * R + r) * Lh + jx;
+  H[i] = mu_update(H[i], neg, pos, kl_den != nullptr, l1, l2, gamma);
+}
+
 // H (B, R, Lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)], Y fp32 [rp_pad][bl_pad].
 // Block = 64 consecutive j x 4 tap groups (coalesced 256-byte reads along j); the four partial sums are combined
 // through LDS in a fixed order.
@@ -452,6 +488,12 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     if (!a.out) return NMFMU_ERR_ARG;
   } else if (epilogue == NMFMU_EPI_LOSS) {
     if (!a.x || !a.out) return NMFMU_ERR_ARG;
+  } else if (epilogue == NMFMU_EPI_FOLD) {
+    // rows (r,t), columns (b,l) of the H numerator GEMM; out = nmfmu_fold_part_bytes(m_pad, n_pad)
+    if (!a.out || d->ops != NMFMU_OPS_PLANES) return NMFMU_ERR_ARG;
+    if (!nmfmu_fold_parts_supported(d->t_batch, d->t_rank, d->t_lh, d->t_taps)) return NMFMU_ERR_UNSUPPORTED;
+    a.tB = d->t_batch, a.tR = d->t_rank, a.tT = d->t_taps, a.tLh = d->t_lh;
+    if (d->m_pad < a.tR * a.tT || (int64_t)d->n_pad < (int64_t)a.tB * (a.tLh + a.tT - 1)) return NMFMU_ERR_ARG;
   } else {
     return NMFMU_ERR_ARG;
   }
@@ -559,6 +601,22 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
   const int grid = batch * rank * ((lh + 63) / 64);
   hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
                      y_num, y_den, kl_den, bl_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+size_t nmfmu_fold_part_bytes(int m_pad, int n_pad) { return (size_t)(m_pad / 128) * (n_pad / 128) * 4 * 256 * sizeof(float); }
+
+int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps) {
+  return batch > 0 && rank > 0 && lh > 0 && taps >= 128 && lh + taps - 1 >= 128;
+}
+
+int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
+                                  const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream) {
+  if (!h || !p_num || (!p_den && !kl_den) || bl_pad % 128 || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
+  if (!nmfmu_fold_parts_supported(batch, rank, lh, taps)) return NMFMU_ERR_UNSUPPORTED;
+  const int grid = batch * rank * ((lh + 255) / 256);
+  hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps, p_num,
+                     p_den, kl_den, bl_pad / 128, l1, l2, gamma);
   return (int)hipGetLastError();
 }
 

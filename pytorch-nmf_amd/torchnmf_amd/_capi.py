@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
 
 
 ABI_VERSION = 2   # include/nmfmu.h: NMFMU_ABI_VERSION
-EPI_RATIO, EPI_F32, EPI_LOSS = 0, 1, 2
+EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/nmfmu.h declares
@@ -137,6 +137,10 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_conv_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_fold_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'nmfmu_fold_parts_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nmfmu_conv_fold_parts_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_timer_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'nmfmu_timer_record': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_timer_elapsed_ms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

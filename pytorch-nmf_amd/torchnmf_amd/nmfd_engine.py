@@ -53,7 +53,8 @@ class _Table:
 class ConvMU:
     """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
 
-    def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True):
+    def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True, own_loop=True):
+        # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM) needs the plain Y buffer
         self.lib = _capi.load()
         if not torch.cuda.is_available():
             raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
@@ -117,8 +118,13 @@ class ConvMU:
         self.gpt = None if self.kl else _Planes(blp, cp, x3, dev)
         self.num_w = torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         self.den_w = None if self.kl else torch.empty(cp * rpp, dtype=torch.float32, device=dev)
-        self.y = torch.empty(rpp * blp, dtype=torch.float32, device=dev)
-        self.y_den = None if self.kl else torch.empty(rpp * blp, dtype=torch.float32, device=dev)
+        # H numerator Y[(r,t)][(b,l)] before the col2im sum: with >= 128 taps the GEMM hands over per-tile diagonal sums
+        # (NMFMU_EPI_FOLD, 4 KiB per tile) instead of storing Y (4 R T B L bytes, 105 MB at configs[3])
+        self.fold_parts = (own_loop and nd == 1 and bool(self.lib.nmfmu_fold_parts_supported(B, R, Lh, T)) and
+                           os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0')
+        ny = self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4 if self.fold_parts else rpp * blp
+        self.y = torch.empty(ny, dtype=torch.float32, device=dev)
+        self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
@@ -145,6 +151,14 @@ class ConvMU:
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
 
+    def _rank_sums(self, src, outer, inner, out):
+        """beta == 1 denominators (nmf.py:122-131): sum over everything but the rank axis.  (Running these two small
+        kernels on a side stream beside the next GEMM was measured: no gain -- the event fork / join costs what the
+        overlap saves.)"""
+        if self.kl:
+            _capi.check(self.lib.nmfmu_rank_sums(src.data_ptr(), outer, self.R, inner, self.sum_part.data_ptr(),
+                                                 out.data_ptr(), _stream()), 'nmfmu_rank_sums')
+
     def _pack_w(self, update: bool = False):
         """W -> Wm / WmT planes (one kernel); with ``update`` the MU apply of nmf.py:78-92 runs in the same pass."""
         _capi.check(self.lib.nmfmu_conv_apply_pack_w(
@@ -152,8 +166,7 @@ class ConvMU:
             _ptr(self.den_w) if update else None, self.sum_h.data_ptr() if (update and self.kl) else None, self.c_pad,
             self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
             _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w')
-        _capi.check(self.lib.nmfmu_rank_sums(self.W.data_ptr(), self.C, self.R, self.T, self.sum_part.data_ptr(),
-                                             self.sum_w.data_ptr(), _stream()), 'nmfmu_rank_sums')
+        self._rank_sums(self.W, self.C, self.T, self.sum_w)
 
     def _pack_h(self):
         if self.implicit:
@@ -162,8 +175,7 @@ class ConvMU:
                         'nmfmu_conv_tables')
         else:
             self._unfold()
-        _capi.check(self.lib.nmfmu_rank_sums(self.H.data_ptr(), self.B, self.R, self.Lh, self.sum_part.data_ptr(),
-                                             self.sum_h.data_ptr(), _stream()), 'nmfmu_rank_sums')
+        self._rank_sums(self.H, self.B, self.Lh, self.sum_h)
 
     def _unfold(self):
         if self.nd == 1:
@@ -196,11 +208,17 @@ class ConvMU:
     def h_step(self):
         """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
         self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt)
-        self._gemm(self.wmt, self.gnt, _capi.EPI_F32, out=self.y)
+        epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
+        self._gemm(self.wmt, self.gnt, epi, out=self.y)
         if not self.kl:
-            self._gemm(self.wmt, self.gpt, _capi.EPI_F32, out=self.y_den)
+            self._gemm(self.wmt, self.gpt, epi, out=self.y_den)
         kl_den = self.sum_w.data_ptr() if self.kl else None
-        if self.nd == 1:
+        if self.fold_parts:
+            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
+                                                               self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,
+                                                               self.l1, self.l2, self.gamma, _stream()),
+                        'nmfmu_conv_fold_parts_apply_h')
+        elif self.nd == 1:
             _capi.check(self.lib.nmfmu_conv_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
                                                          self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,
                                                          self.l1, self.l2, self.gamma, _stream()),

@@ -295,7 +295,7 @@ class _ConvPlcaEM:
         from .nmfd_engine import ConvMU, _Planes
         import ctypes as C
         self.C = C
-        self.eng = e = ConvMU(Vn, W, H, 1.0, precision=precision)
+        self.eng = e = ConvMU(Vn, W, H, 1.0, precision=precision, own_loop=False)
         self.lib = e.lib
         self.W, self.H, self.Z = W, H, Z
         x3 = e.precision == _capi.PREC_BF16X3

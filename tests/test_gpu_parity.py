@@ -573,6 +573,38 @@ def test_nmfd_implicit_toeplitz_operands(dev, shape, beta, monkeypatch):
     assert rel_err(res['0'][0], Wr) < TOL and rel_err(res['0'][1], Hr) < TOL
 
 
+@pytest.mark.parametrize('shape', [(1, 40, 520, 3, 136), (2, 33, 335, 2, 130), (1, 70, 600, 2, 400), (3, 20, 300, 1, 128)])
+@pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (1, 'bf16')])
+def test_nmfd_fold_from_tile_diagonal_sums(dev, shape, beta, prec, monkeypatch):
+    """With >= 128 taps the H numerator GEMM does not store Y[(r,t)][(b,l)]: its epilogue emits the diagonal sums of
+    every 128 x 128 tile (NMFMU_EPI_FOLD) and nmfmu_conv_fold_parts_apply_h gathers them.  Same products, another
+    summation order: must agree with the store-then-fold path to fp32 rounding, and with the oracle.  Shapes put rank
+    boundaries (T = 130, 136, 400) and batch boundaries (L = 335, 300) inside tiles, B*L and R*T off the tile grid."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_FOLD_PARTS', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, 0.01, 0.02, precision=prec)
+        assert eng.fold_parts == (mode == '1')
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), eng.divergence())
+    assert rel_err(res['0'][0], res['1'][0]) < 2e-6 and rel_err(res['0'][1], res['1'][1]) < 2e-6
+    assert (res['0'][1] - res['1'][1]).abs().max() <= 1e-5 * res['0'][1].abs().max()
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5)
+    if prec == 'bf16x3':
+        Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
+        assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
+
+
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
