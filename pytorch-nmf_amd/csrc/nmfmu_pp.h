@@ -173,6 +173,14 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     }
   };
   stamp(2);
+  auto pstamp = [&](int k) {   // VAR & 128: where the prologue's time goes (workgroup 0, wave 0; 100 MHz clock)
+    if constexpr ((VAR & 128) != 0 && MODE == kModeMU) {
+      if (blockIdx.x == 0 && wave == 0) {
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) dbg[40 + k] = r;
+      }
+    }
+  };
 
   // ---- owner fragments (B operand of G1): row m0, rank slice 16*kk + 8*hl .. +7
   // bf16: the fragments are scaled by 2^23 = 1 / eps (exact), so that the "+ eps" of nmf.py:65 becomes "+ 1.0" -- an
@@ -545,6 +553,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     };
 
     // ---- prologue: P1(0), P1(1), P2(0), X(0), X(1); everything landed before the first barrier
+    pstamp(0);
     if (!half) {
 #pragma unroll
       for (int i = 0; i < C::LEAD; ++i) dma_img(p1src + (size_t)clampt(i) * IMG, C::P1_BASE + i * IMG);
@@ -589,11 +598,13 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       load_owner();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    pstamp(1);
     scale_owner();
     if constexpr (VAR & 2) {
       if (half) __builtin_amdgcn_s_setprio(1);
     }
     barrier();
+    pstamp(2);
     prefetch(std::true_type{});
     if (half) barrier();                       // waves 4-7 run one segment behind
     matrix_segment(std::true_type{}, std::false_type{});

@@ -43,6 +43,9 @@ for which in os.environ.get('PP_STEPS', 'h,w').split(','):
         res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0, (st[0, 1] - st[2, 1]) * 0.01, (st[3, 1] - st[1, 1]) * 0.01,
                     (st[3, 1] - st[2, 1]) * 0.01))
     r = np.array(res)
+    pr = buf.cpu().numpy()
+    print(f'   prologue of workgroup 0 (us after entry): loads issued from {(pr[40] - st[2, 1]) * 0.01:.2f}, landed {(pr[41] - st[2, 1]) * 0.01:.2f}, '
+          f'first barrier passed {(pr[42] - st[2, 1]) * 0.01:.2f}, loop starts {(st[0, 1] - st[2, 1]) * 0.01:.2f}')
     # all workgroups of the last launch: entry / loop start / loop end / exit relative to the earliest entry
     grid = (eng.step_h if which == 'h' else eng.step_w)
     nwg = (grid.owner.rows_pad // grid.block_rows) * grid.nsplit
