@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 2 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries */
+#define NMFMU_ABI_VERSION 3 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+                               3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, nmfmu_mu_step_parts, NMFMU_PREC_F16 */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -240,7 +241,11 @@ typedef struct nmfmu_gemm_desc {
    * Hu[(b,l)][(r,t)] = H[b][r][l-t] (T times larger than H), an operand may be fetched chunk by chunk from a
    * window table that is only 8x H.  ops selects which operand is implicit; its hi / lo pointers then address the table. */
   int32_t ops;              /* NMFMU_OPS_* */
-  int32_t t_batch, t_rank, t_taps, t_lh; /* B, R, T, Lh of H (implicit operands only) */
+  int32_t t_batch, t_rank, t_taps, t_lh; /* B, R, T, Lh of H (implicit operands and NMFMU_EPI_FOLD) */
+  /* Workgroup tile: 0 or 128 = 128 x 128 (every combination); 256 = 256 x 256, half the operand traffic per MFMA
+   * (m_pad and n_pad multiples of 256; BF16 only; RATIO / LOSS at beta == 1, F32, FOLD -- nmfmu_gemm_tile256_supported,
+   * else NMFMU_ERR_UNSUPPORTED). */
+  int32_t tile_rows;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
@@ -258,6 +263,7 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
                       void* fwd_lo, void* stream);
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
+int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops);
 
 /* Strided 2-D gather of an fp32 tensor into a zero-padded row-major matrix (fp32 copy and/or bf16 hi[,lo] planes):
  *   dst[row][col] = src[(row / row_inner) * row_outer_stride + (row % row_inner) * row_inner_stride

@@ -13,8 +13,8 @@
 //              backward pass wrt H without the 4 * R*T * B*L bytes write + read of Y)
 //
 // Both operands are bf16 planes (hi[, lo]) with k contiguous, zero padded to multiples of 128 in every dimension.
-// 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles), BK = 64, LDS double buffered by
-// LDS-DMA.  The 128-byte LDS rows are XOR-swizzled on the DMA *source* side (linear LDS destination) and on the
+// 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles) -- or 256x256, 8 waves (4x2, 64x128 each) --
+// BK = 64, LDS double buffered by LDS-DMA.  The 128-byte LDS rows are XOR-swizzled on the DMA *source* side (linear LDS destination) and on the
 // ds_read side, which makes every ds_read_b128 conflict free (same analysis as the P2 image of nmfmu_layout.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,28 +50,45 @@ struct GemmArgs {
 // which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
 enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3 };
 
-template <bool X3>
+// Workgroup tile shapes.  WM x WN waves, each MI x NI MFMA 32x32 blocks.
+//   small: 128 x 128, 256 threads, two workgroups per CU -- every shape, both precisions
+//   big:   256 x 256, 512 threads, one workgroup per CU   -- half the operand bytes per MFMA (64 KiB of LDS-DMA and
+//          192 KiB of fragment reads for 256 MFMAs instead of 64 + 128 KiB for 128): the small tile has the LDS-DMA path,
+//          the LDS reads and the matrix pipe all nominally saturated
+template <int WM_, int WN_, int MI_, int NI_>
+struct GemmShape {
+  static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+  static constexpr int BM = WM * MI * 32, BN = WN * NI * 32, THREADS = 64 * WM * WN;
+};
+using GemmSmall = GemmShape<2, 2, 2, 2>;
+using GemmBig = GemmShape<4, 2, 2, 4>;
+
+template <bool X3, class SH>
 struct GemmCfg {
-  static constexpr int BM = 128, BN = 128, BK = 64;
-  static constexpr int TILE = BM * BK * 2;          // bytes of one operand-plane tile (16 KiB)
+  static constexpr int BM = SH::BM, BN = SH::BN, BK = 64;
+  static constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;   // bytes of one operand-plane tile
   static constexpr int NPL = X3 ? 2 : 1;
-  static constexpr int STAGE = 2 * NPL * TILE;      // A planes then B planes
+  static constexpr int STAGE = NPL * (A_TILE + B_TILE);               // A planes then B planes
   static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int PA = BM * 8 / SH::THREADS, PB = BN * 8 / SH::THREADS;   // DMA passes per plane tile
+  static_assert(PA * SH::THREADS == BM * 8 && PB * SH::THREADS == BN * 8, "whole DMA passes");
+  static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
 };
 
-template <bool X3, int EPI, int BETA, int OPS>
-__global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
-  using C = GemmCfg<X3>;
+template <bool X3, int EPI, int BETA, int OPS, class SH>
+__global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
+  using C = GemmCfg<X3, SH>;
+  constexpr int MI = SH::MI, NI = SH::NI, THREADS = SH::THREADS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hl = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / SH::WN, wn = wave % SH::WN;
   const int bm = blockIdx.y, bn = blockIdx.x;
   const int ktiles = a.k_pad / C::BK;
   const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
 
-  // DMA source pointers: thread handles chunk c = p*256 + tid of a tile: row = c >> 3, LDS slot = c & 7,
+  // DMA source pointers: thread handles chunk c = p*THREADS + tid of a tile: row = c >> 3, LDS slot = c & 7,
   // source slot = slot ^ ((row >> 1) & 7)
   const char* src[2 * C::NPL];
   {
@@ -81,33 +98,36 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl)
-        src[op * C::NPL + pl] = bases[op * 2 + pl] + (size_t)(op == 0 ? bm : bn) * 128 * ldk;
+        src[op * C::NPL + pl] = bases[op * 2 + pl] + (size_t)(op == 0 ? bm * C::BM : bn * C::BN) * ldk;
   }
   const char* tab[2] = {nullptr, nullptr};   // window table planes of the implicit operand
   if constexpr (OPS != kOpsPlanes) {
     tab[0] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_hi : a.b_hi);
     tab[1] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_lo : a.b_lo);
   }
-  const int row_t = tid >> 3;                                   // + 32 * p
-  const int sslot = (tid & 7) ^ ((row_t >> 1) & 7);             // (row >> 1) & 7 is the same for every pass (32 | 16)
+  const int row_t = tid >> 3;                                   // + (THREADS / 8) * p
+  const int sslot = (tid & 7) ^ ((row_t >> 1) & 7);             // (row >> 1) & 7 is the same for every pass (16 | THREADS/8)
   const size_t thr_off = (size_t)row_t * ldk + sslot * 16;
 
   // ---- implicit Toeplitz operand (see nmfmu_conv_tables for the table layout).
-  // Its LDS tile is CHUNK-MAJOR, [8 k-chunks][128 rows] x 16 B, and the DMA lanes run along the rows: chunk
-  // c = p*256 + tid  ->  k-chunk c >> 7, row c & 127.  Consecutive rows of one k-chunk are consecutive table entries,
-  // so a wave instruction reads one contiguous KiB (lanes along k instead touch four cache lines per lane quad and
-  // measured 30 % slower), and the fragment reads (lane j = row) are contiguous too: no swizzle needed.
+  // Its LDS tile is CHUNK-MAJOR, [8 k-chunks][ROWS rows] x 16 B, and the DMA lanes run along the rows: chunk
+  // c = p*THREADS + tid  ->  k-chunk c / ROWS, row c % ROWS.  Consecutive rows of one k-chunk are consecutive table
+  // entries, so a wave instruction reads one contiguous KiB (lanes along k instead touch four cache lines per lane quad
+  // and measured 30 % slower), and the fragment reads (lane j = row) are contiguous too: no swizzle needed.
   constexpr int TOP = OPS == kOpsAHu ? 0 : 1;                 // which operand is implicit
+  constexpr int TROWS = TOP == 0 ? C::BM : C::BN;             // rows of the implicit operand's tile
+  constexpr int TP = TOP == 0 ? C::PA : C::PB;
+  static_assert(OPS == kOpsPlanes || THREADS == 2 * TROWS, "two k-chunks of the implicit operand per DMA pass");
   constexpr bool kHuRows = OPS == kOpsBHu || OPS == kOpsAHu;  // rows (b,l), k = (r,t); else rows (r,t), k = (b,l)
-  int trow = -1;      // chunk-index contribution of this thread's row (the same in all four passes), -1 = padding row
+  int trow = -1;      // chunk-index contribution of this thread's row (the same in all passes), -1 = padding row
   int tL = 0, tJJ = 0, tT8 = 0;
-  // k position of the thread's chunk in pass p (k-chunk 2p + (wave >> 1) of the k-tile), advanced by one k-tile per
+  // k position of the thread's chunk in pass p (k-chunk 2p + tid / TROWS of the k-tile), advanced by one k-tile per
   // stage_issue call, which come strictly in k order (no integer division in the loop):
   //   rows-(b,l) operand: k = r T + 8 tc  -> (kq, kr) = (r, tc);   rows-(r,t) operand: k = b L + l0 -> (kq, kr) = (b, l0)
   int kq[4] = {0, 0, 0, 0}, kr[4] = {0, 0, 0, 0};
   if constexpr (OPS != kOpsPlanes) {
     tL = a.tLh + a.tT - 1, tJJ = a.tLh + 2 * a.tT - 2, tT8 = a.tT / 8;
-    const int row = (TOP == 0 ? bm : bn) * 128 + (tid & 127);
+    const int row = (TOP == 0 ? bm : bn) * TROWS + (tid % TROWS);
     if constexpr (kHuRows) {   // row = b L + l  ->  (b R) JJ + l + (T - 1)
       const int b = row / tL, l = row - b * tL;
       trow = b < a.tB ? b * a.tR * tJJ + l + a.tT - 1 : -1;
@@ -117,7 +137,7 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kc = 2 * p + (tid >> 7);
+      const int kc = 2 * p + (tid / TROWS);
       if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
@@ -139,33 +159,41 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
       }
     }
   };
+  // LDS offset of plane pl of operand op inside a stage
+  auto tile_off = [](int op, int pl) { return op == 0 ? pl * C::A_TILE : C::NPL * C::A_TILE + pl * C::B_TILE; };
 
   auto stage_issue = [&](int kt, int buf) {
 #pragma unroll
-    for (int im = 0; im < 2 * C::NPL; ++im) {
-      const bool implicit = OPS != kOpsPlanes && (im / C::NPL) == TOP;
-      const char* s0 = src[im] + thr_off + (size_t)kt * (C::BK * 2);
+    for (int op = 0; op < 2; ++op)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        char* dst = smem + buf * C::STAGE + im * C::TILE + p * 4096 + wave * 1024;
-        const char* g = implicit ? tab[im % C::NPL] + (size_t)toep_index(p) * 16 : s0 + (size_t)p * 32 * ldk;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+      for (int pl = 0; pl < C::NPL; ++pl) {
+        const bool implicit = OPS != kOpsPlanes && op == TOP;
+        const char* s0 = src[op * C::NPL + pl] + thr_off + (size_t)kt * (C::BK * 2);
+        const int passes = op == 0 ? C::PA : C::PB;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (p < passes) {
+            char* dst = smem + buf * C::STAGE + tile_off(op, pl) + p * (THREADS * 16) + wave * 1024;
+            const char* g = implicit ? tab[pl] + (size_t)toep_index(p) * 16 : s0 + (size_t)p * (THREADS / 8) * ldk;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+          }
+        }
       }
-    }
     if constexpr (OPS != kOpsPlanes) toep_advance();
   };
+  (void)TP;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = ((EPI == kEpiRatio || EPI == kEpiLoss) && BETA != kEuc) ? kEps : 0.f;
 
-  const int a_rowoff = (wm * 64 + j) * 128;  // + mi * 4096
-  const int b_rowoff = (wn * 64 + j) * 128;
+  const int a_rowoff = (wm * MI * 32 + j) * 128;  // + mi * 4096
+  const int b_rowoff = (wn * NI * 32 + j) * 128;
   const int swz = ((j >> 1) & 7) << 4;
 
   stage_issue(0, 0);
@@ -175,20 +203,21 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
     const char* sb = smem + buf * C::STAGE;
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
-    u32x4 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+    u32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
     auto load_frags = [&](int ks, int fb) {
       const int so = ((2 * ks + hl) << 4) ^ swz;          // row-major tile: 128-byte rows, XOR-swizzled 16-byte slots
-      const int co = (2 * ks + hl) * 2048;                // chunk-major tile of the implicit operand
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ao = (OPS == kOpsAHu) ? co + (wm * 64 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
-        const int bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? co + (wn * 64 + i * 32 + j) * 16 : b_rowoff + i * 4096 + so;
+      for (int i = 0; i < MI; ++i) {
+        const int ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
         ah[fb][i] = ld16(sb + ao);
-        bh[fb][i] = ld16(sb + C::NPL * C::TILE + bo);
-        if constexpr (X3) {
-          al[fb][i] = ld16(sb + C::TILE + ao);
-          bl[fb][i] = ld16(sb + 3 * C::TILE + bo);
-        }
+        if constexpr (X3) al[fb][i] = ld16(sb + C::A_TILE + ao);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16
+                                                           : b_rowoff + i * 4096 + so;
+        bh[fb][i] = ld16(sb + C::NPL * C::A_TILE + bo);
+        if constexpr (X3) bl[fb][i] = ld16(sb + C::NPL * C::A_TILE + C::B_TILE + bo);
       }
     };
     load_frags(0, 0);
@@ -197,9 +226,9 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
       const int fb = ks & 1;
       if (ks + 1 < 4) load_frags(ks + 1, fb ^ 1);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           if constexpr (X3) {
             acc[mi][ni] = mfma_bf16(al[fb][mi], bh[fb][ni], acc[mi][ni]);
             acc[mi][ni] = mfma_bf16(ah[fb][mi], bl[fb][ni], acc[mi][ni]);
@@ -208,15 +237,18 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
         }
     }
     {
-      constexpr int RD = 4 * C::NPL, MF = X3 ? 3 : 1;
+      // pin the order: the first k-step's fragment reads, then per MFMA (group) its share of the next k-step's reads
+      constexpr int RD = (MI + NI) * C::NPL, NM = MI * NI, MF = X3 ? 3 : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      static_for<4>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<NM>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
           __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-          if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
-        }
+          constexpr int nrd = (RD * (q + 1)) / NM - (RD * q) / NM;
+          if constexpr (ks + 1 < 4 && nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+        });
+      });
     }
     __syncthreads();
   }
@@ -224,65 +256,82 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
   // ---------------- epilogue: accumulator e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column j
   if constexpr (EPI == kEpiFold) {
     // rows m = r T + t, columns n = b L + l; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)] runs along the diagonals
-    // n - m = j + (b L - r T).  With T, L >= 128 a tile holds at most two r and two b: four (r, b) segments, 255
-    // diagonals each.  The tile goes through LDS (the staging buffers, every wave is past the last barrier; rows padded
-    // to 129 floats: the lanes of a wave walk their diagonals from different rows, and with a 128-float pitch the short
-    // diagonals of one wave would all sit in one bank), thread dd sums diagonal dd = nl - ml + 127 top to bottom, split
-    // by segment.  Entries whose j falls outside
-    // [0, Lh) land on diagonals the gather never reads; padding rows / columns are exact zeros.
-    float* tl = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          tl[(wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl) * kFoldLd + wn * 64 + ni * 32 + j] = acc[mi][ni][e];
-    __syncthreads();
+    // n - m = j + (b L - r T).  With T, L >= 128 a 128 x 128 quadrant of the tile holds at most two r and two b: four
+    // (r, b) segments, 255 diagonals each.  A quadrant goes through LDS (the staging buffers, every wave is past the last
+    // barrier; rows padded to 129 floats: the lanes of a wave walk their diagonals from different rows, and with a
+    // 128-float pitch the short diagonals of one wave would all sit in one bank), thread dd sums diagonal
+    // dd = nl - ml + 127 top to bottom, split by segment.  THREADS / 256 quadrants are in flight at a time.  Entries whose
+    // j falls outside [0, Lh) land on diagonals the gather never reads; padding rows / columns are exact zeros.
+    constexpr int QM = C::BM / 128, QN = C::BN / 128, QP = THREADS / 256, QBUF = 128 * kFoldLd;
+    static_assert((QM * QN) % QP == 0, "whole quadrant groups");
+    float* tl_all = reinterpret_cast<float*>(smem);
     const int L = a.tLh + a.tT - 1;
-    const int rb = (bm * 128 / a.tT + 1) * a.tT - bm * 128;   // first tile row of the second r (>= 128: none)
-    const int nb = (bn * 128 / L + 1) * L - bn * 128;         // first tile column of the second b
-    const int dd = tid;
-    if (dd < 255) {
-      // every (second r?, second b?) segment of a diagonal is one contiguous run of rows: the r switch is at row rb,
-      // the b switch at row nb - (dd - 127); straight sums over up to four runs, four independent partial sums each
-      const int lo = max(0, 127 - dd), hi1 = min(127, 254 - dd) + 1;
-      const int rsw = min(max(rb, lo), hi1), bsw = min(max(nb - dd + 127, lo), hi1);
-      const float* pd = tl + dd - 127;
-      auto run = [&](int r0, int r1) {
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        int ml = r0;
-        for (; ml + 16 <= r1; ml += 16) {   // sixteen LDS reads in flight (the reads, not the adds, bound this loop)
-          float v[16];
+    const int tiles_n = a.n_pad / 128;
+    for (int g = 0; g < QM * QN; g += QP) {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = pd[(ml + u) * (kFoldLd + 1)];
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int u = 0; u < 16; u += 4) p0 += v[u], p1 += v[u + 1], p2 += v[u + 2], p3 += v[u + 3];
+        for (int ni = 0; ni < NI; ++ni) {
+          const int r0 = wm * MI * 32 + mi * 32, c0 = wn * NI * 32 + ni * 32;   // block origin inside the tile
+          const int q = (r0 >> 7) * QN + (c0 >> 7);
+          if (q >= g && q < g + QP) {
+            float* tl = tl_all + (q - g) * QBUF;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              tl[((r0 & 127) + (e & 3) + 8 * (e >> 2) + 4 * hl) * kFoldLd + (c0 & 127) + j] = acc[mi][ni][e];
+          }
         }
-        for (; ml + 4 <= r1; ml += 4) {
-          p0 += pd[ml * (kFoldLd + 1)], p1 += pd[(ml + 1) * (kFoldLd + 1)], p2 += pd[(ml + 2) * (kFoldLd + 1)], p3 += pd[(ml + 3) * (kFoldLd + 1)];
+      __syncthreads();
+      {
+        const int q = g + (tid >> 8), qm = q / QN, qn = q - qm * QN;
+        const int tm = bm * QM + qm, tn = bn * QN + qn;              // 128 x 128 tile coordinates in Y
+        const int rb = (tm * 128 / a.tT + 1) * a.tT - tm * 128;      // first quadrant row of the second r (>= 128: none)
+        const int nb = (tn * 128 / L + 1) * L - tn * 128;            // first quadrant column of the second b
+        const int dd = tid & 255;
+        if (dd < 255) {
+          // every (second r?, second b?) segment of a diagonal is one contiguous run of rows: the r switch is at row rb,
+          // the b switch at row nb - (dd - 127); straight sums over up to four runs, four independent partial sums each
+          const int lo = max(0, 127 - dd), hi1 = min(127, 254 - dd) + 1;
+          const int rsw = min(max(rb, lo), hi1), bsw = min(max(nb - dd + 127, lo), hi1);
+          const float* pd = tl_all + (tid >> 8) * QBUF + dd - 127;
+          auto run = [&](int r0, int r1) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            int ml = r0;
+            for (; ml + 16 <= r1; ml += 16) {   // sixteen LDS reads in flight
+              float v[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) v[u] = pd[(ml + u) * (kFoldLd + 1)];
+#pragma unroll
+              for (int u = 0; u < 16; u += 4) p0 += v[u], p1 += v[u + 1], p2 += v[u + 2], p3 += v[u + 3];
+            }
+            for (; ml + 4 <= r1; ml += 4) {
+              p0 += pd[ml * (kFoldLd + 1)], p1 += pd[(ml + 1) * (kFoldLd + 1)], p2 += pd[(ml + 2) * (kFoldLd + 1)],
+                  p3 += pd[(ml + 3) * (kFoldLd + 1)];
+            }
+            for (; ml < r1; ++ml) p0 += pd[ml * (kFoldLd + 1)];
+            return (p0 + p1) + (p2 + p3);
+          };
+          const float s0 = run(lo, min(rsw, bsw));        // first r, first b
+          const float s1 = run(max(lo, bsw), rsw);        // first r, second b
+          const float s2 = run(rsw, max(rsw, bsw));       // second r, first b   (rows [rsw, bsw))
+          const float s3 = run(max(rsw, bsw), hi1);       // second r, second b
+          float* po = a.out + ((size_t)(tm * tiles_n + tn) * 4) * 256 + dd;
+          po[0] = s0, po[256] = s1, po[512] = s2, po[768] = s3;
         }
-        for (; ml < r1; ++ml) p0 += pd[ml * (kFoldLd + 1)];
-        return (p0 + p1) + (p2 + p3);
-      };
-      const float s0 = run(lo, min(rsw, bsw));        // first r, first b
-      const float s1 = run(max(lo, bsw), rsw);        // first r, second b
-      const float s2 = run(rsw, max(rsw, bsw));       // second r, first b   (rows [rsw, bsw))
-      const float s3 = run(max(rsw, bsw), hi1);       // second r, second b
-      float* po = a.out + ((size_t)(bm * gridDim.x + bn) * 4) * 256 + dd;
-      po[0] = s0, po[256] = s1, po[512] = s2, po[768] = s3;
+      }
+      if (g + QP < QM * QN) __syncthreads();
     }
     return;
   }
   float lacc = 0.f;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = bn * 128 + wn * 64 + ni * 32 + j;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = bn * C::BN + wn * NI * 32 + ni * 32 + j;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = bm * 128 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const int m = bm * C::BM + wm * MI * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
         const size_t idx = (size_t)m * a.n_pad + n;
         const float s = acc[mi][ni][e];
         if constexpr (EPI == kEpiF32) {
@@ -311,15 +360,23 @@ __global__ void __launch_bounds__(256, (X3 ? 1 : 2)) nt_gemm_kernel(const GemmAr
     float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) red[wave] = lacc;
     __syncthreads();
-    if (tid == 0) a.out[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < THREADS / 64; ++w) tot += red[w];
+      a.out[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
   }
 }
 
-template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
-  using C = GemmCfg<X3>;
-  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < 128 * kFoldLd * 4) ? 128 * kFoldLd * 4 : C::LDS_BYTES;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS>;
+  using C = GemmCfg<X3, SH>;
+  constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
+  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES;
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -328,10 +385,11 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     *flag = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_pad / 128, a.m_pad / 128), dim3(256), kLds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, a.m_pad / C::BM), dim3(SH::THREADS), kLds, s, a);
   return (int)hipGetLastError();
 }
 
-int launch_gemm(int x3, int epi, int beta_kind, int ops, const GemmArgs& a, hipStream_t s);
+// big != 0: the 256 x 256 tile (bf16 single plane, beta == 1 ratio / loss, F32, FOLD); -2 when that variant is not built
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, const GemmArgs& a, hipStream_t s);
 
 }  // namespace nmfmu

@@ -16,7 +16,18 @@
 
 namespace nmfmu {
 
-int launch_gemm(int x3, int epi, int beta_kind, int ops, const GemmArgs& a, hipStream_t s) {
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, const GemmArgs& a, hipStream_t s) {
+  if (big) {
+    // 256 x 256 tiles: the combinations NMFD.fit uses at beta == 1 in the single-plane mode (nmfd_engine.py)
+    if (x3) return -2;
+#define GBIG(E, B, O) \
+  if (epi == E && (E == kEpiF32 || E == kEpiFold || beta_kind == B) && ops == O) return launch_gemm_one<false, E, B, O, GemmBig>(a, s);
+    GBIG(kEpiRatio, kKL, kOpsBHu) GBIG(kEpiRatio, kKL, kOpsAHu) GBIG(kEpiRatio, kKL, kOpsPlanes)
+    GBIG(kEpiLoss, kKL, kOpsBHu) GBIG(kEpiLoss, kKL, kOpsPlanes)
+    GBIG(kEpiF32, kEuc, kOpsPlanes) GBIG(kEpiF32, kEuc, kOpsBHuT) GBIG(kEpiFold, kEuc, kOpsPlanes)
+#undef GBIG
+    return -2;
+  }
   // operand combinations that occur (nmfd_engine.py): RATIO with planes | B = Hu | A = Hu; F32 with planes | B = HuT;
   // LOSS with planes | B = Hu
 #define G1(X, E, B, O) \
@@ -457,6 +468,18 @@ inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64
 
 extern "C" {
 
+int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops) {
+  if (precision != NMFMU_PREC_BF16) return 0;
+  const int kl = nmfmu_beta_kind(beta) == NMFMU_BETA_KL;
+  switch (epilogue) {
+    case NMFMU_EPI_RATIO: return kl && (ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HU || ops == NMFMU_OPS_A_HU);
+    case NMFMU_EPI_LOSS: return kl && (ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HU);
+    case NMFMU_EPI_F32: return ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HUT;
+    case NMFMU_EPI_FOLD: return ops == NMFMU_OPS_PLANES;
+    default: return 0;
+  }
+}
+
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
   if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % 128 || d->k_pad % 128)
@@ -497,7 +520,14 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else {
     return NMFMU_ERR_ARG;
   }
-  return launch_gemm(x3, epilogue, kind, d->ops, a, S(stream));
+  int big = 0;
+  if (d->tile_rows == 256) {
+    if (x3 || d->m_pad % 256 || d->n_pad % 256) return NMFMU_ERR_ARG;
+    big = 1;
+  } else if (d->tile_rows != 0 && d->tile_rows != 128) {
+    return NMFMU_ERR_ARG;
+  }
+  return launch_gemm(x3, epilogue, kind, d->ops, big, a, S(stream));
 }
 
 int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t row_outer_stride, int64_t row_inner_stride,

@@ -86,7 +86,17 @@ class ConvMU:
         self.W, self.H = W, H
         self.B, self.C, self.L, self.R, self.T, self.Lh = B, Cc, L, R, T, Lh
         dev = V.device
-        self.c_pad, self.bl_pad, self.rp_pad = _pad128(Cc), _pad128(B * L), _pad128(R * T)
+        # 256 x 256 GEMM tiles (nmfmu_gemm_desc.tile_rows; single bf16 plane, beta == 1) halve the operand traffic per MFMA:
+        # 52 % instead of 27 % MFMA-busy per CU.  Opt-in (TORCHNMF_AMD_NMFD_TILE=256), because no measured shape gains yet:
+        # at configs[3] the 256-row padding (1025 channels -> 1280) and the 160-workgroup grids eat it (2 210 vs 2 650
+        # it/s), the rank > 256 NMF path is bound by its ratio epilogues, not by the GEMM loop.  It is the building block
+        # for stream-K scheduling.
+        want = os.environ.get('TORCHNMF_AMD_NMFD_TILE', '128')
+        self.tile = 256 if (want == '256' and own_loop and nd == 1 and self.kl and
+                            self.precision == _capi.PREC_BF16) else 128
+        self._tile_forced = want == '256'
+        pad = (lambda n: (n + self.tile - 1) // self.tile * self.tile)
+        self.c_pad, self.bl_pad, self.rp_pad = pad(Cc), pad(B * L), pad(R * T)
         cp, blp, rpp = self.c_pad, self.bl_pad, self.rp_pad
 
         # targets: X_w[c][(b,l)] and X_h[(b,l)][c], fp32, zero padded; validation fused into the first gather
@@ -128,7 +138,7 @@ class ConvMU:
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
-        self.loss_part = torch.empty((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)
+        self.loss_part = torch.zeros((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)   # 256-tiles write fewer
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self.graphable = True   # fixed launches on fixed buffers: fit() replays an iteration as one hipGraph
         self.refresh_images()
@@ -145,10 +155,14 @@ class ConvMU:
         if self.implicit:
             ops = (_capi.OPS_A_HU if a is self.hu else _capi.OPS_B_HU if b is self.hu else
                    _capi.OPS_B_HUT if b is self.hut else _capi.OPS_PLANES)
+        tile = 128
+        if (self.tile == 256 and (self._tile_forced or (a.rows_pad // 256) * (b.rows_pad // 256) >= 128) and
+                self.lib.nmfmu_gemm_tile256_supported(self.precision, self.beta, epi, ops)):
+            tile = 256
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), a.rows_pad, b.rows_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
-                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh)
+                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
 
     def _rank_sums(self, src, outer, inner, out):
