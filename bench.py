@@ -137,7 +137,7 @@ def main_nmfd(a):
     """BASELINE configs[3]: NMFD spectrogram 1025 x 8192, rank 8, T = 400, beta = 1 (replicas only: 1 GPU)."""
     dev = torch.device('cuda', 0)
     from torchnmf_amd.nmfd_engine import ConvMU
-    Cc, L, R, T, beta = 1025, 8192, 8, a.taps, a.beta
+    Cc, L, R, T, beta = (a.rows or 1025), (a.cols or 8192), (a.rank or 8), a.taps, a.beta   # --rows = channels, --cols = frames
     g = torch.Generator(device=dev).manual_seed(1000)
     if a.workload == 'nmf2d':       # NMF2D, the next row after NMFD (same engine, two shift axes)
         Cc, R = 64, 8
@@ -151,7 +151,7 @@ def main_nmfd(a):
         V = torch.rand(1, Cc, L, device=dev, generator=g).bfloat16().float()
         W = torch.randn(Cc, R, T, device=dev, generator=g).abs_()
         H = torch.randn(1, R, L - T + 1, device=dev, generator=g).abs_()
-        title = f'NMFD 1x{Cc}x{L} rank={R} T={T}' + (' (BASELINE configs[3])' if T == 400 else '')
+        title = f'NMFD 1x{Cc}x{L} rank={R} T={T}' + (' (BASELINE configs[3])' if (Cc, L, R, T) == (1025, 8192, 8, 400) else '')
     Vc, Wc, Hc = V.cpu(), W.cpu(), H.cpu()
     eng = ConvMU(V, W, H, beta, precision=a.precision)
 
@@ -173,11 +173,13 @@ def main_nmfd(a):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
     flops = (4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T
-    # the dominant kernel (nt_gemm) timed live: 4 launches per iteration, each 2*C*L*R*T algorithmic flops
+    # the dominant kernel (nt_gemm) timed live: 4 launches per iteration, each 2*C*L*R*T algorithmic flops.  Timed as the
+    # iteration runs it: the reconstruction of the W half-step (GEMM over the channels that fill whole 128-row tiles +
+    # the ragged-channel kernel when C = 128 k + 1..8)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for _ in range(a.steps):
-        eng._gemm(eng.wm, eng.hu, 0, x=eng.x_w, gn=eng.gn, gp=eng.gp)
+        eng.recon_ratio_w()
     ev[1].record()
     torch.cuda.synchronize()
     gemm_ms = ev[0].elapsed_time(ev[1]) / a.steps
@@ -205,7 +207,8 @@ def main_nmfd(a):
                    'precision': a.precision, 'parallelism': 'single GPU (replicas only)',
                    'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': round(ach / peak, 4), 'traffic': None, 'kernel': 'nmfmu::nt_gemm_kernel (EPI_RATIO)',
+                     'frac': round(ach / peak, 4), 'traffic': None,
+                     'kernel': 'nmfmu::nt_gemm_kernel (EPI_RATIO)' + (' + conv_ragged_rows_kernel' if getattr(eng, 'ragged', False) else ''),
                      'avg_launch_ms': round(gemm_ms, 5),
                      'note': 'bf16x3 issues 3 MFMAs per algorithmic product: hardware MFMA rate is 3x achieved'
                      if a.precision == 'bf16x3' else ''},

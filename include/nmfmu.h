@@ -246,6 +246,13 @@ typedef struct nmfmu_gemm_desc {
    * (m_pad and n_pad multiples of 256; BF16 only; RATIO / LOSS at beta == 1, F32, FOLD -- nmfmu_gemm_tile256_supported,
    * else NMFMU_ERR_UNSUPPORTED). */
   int32_t tile_rows;
+  /* Leading dimension of x / gn / gp / out when the GEMM covers only the first n_pad columns of wider matrices
+   * (0 = n_pad).  Together with a reduced m_pad this lets a caller leave a few ragged rows / columns to
+   * nmfmu_conv_ragged_rows instead of paying a whole 128-wide tile row for them. */
+  int32_t n_ld;
+  /* Contraction length actually run (0 = k_pad; a multiple of 64 covering the logical extent): the zero tail of
+   * 128-padded planes need not be multiplied. */
+  int32_t k_len;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
@@ -264,6 +271,19 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
 int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops);
+
+/* Ragged channels of the NMFD reconstruction (RATIO / LOSS epilogues with A or B = Wm): channels c0 .. channels-1 by
+ * direct summation S[c][(b,l)] = sum_{r,t} w[c][r][t] h[b][r][l-t] from the fp32 masters, so that the GEMM only has to
+ * cover the first c0 = floor(channels / 128) * 128 of them (m_pad resp. n_pad = c0, n_ld = the planes' width): a
+ * spectrogram with 2^k + 1 bins otherwise pays a whole 128-row tile row for one channel.
+ *   mode 0: ratio planes gn (gp) [c][ld]   (W half-step)      mode 1: [(b,l)][ld]   (H half-step)
+ *   mode 2: beta_div partials, loss_part[nmfmu_conv_ragged_blocks() * (channels - c0)]
+ * x has the layout of the outputs.  BF16 / BF16X3. */
+int nmfmu_conv_ragged_supported(int rank, int taps);
+int nmfmu_conv_ragged_blocks(int batch, int lh, int taps);
+int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, const float* h, int batch, int lh, int c0,
+                           int precision, float beta, int mode, const float* x, int64_t ld, void* gn_hi, void* gn_lo,
+                           void* gp_hi, void* gp_lo, float* loss_part, void* stream);
 
 /* Strided 2-D gather of an fp32 tensor into a zero-padded row-major matrix (fp32 copy and/or bf16 hi[,lo] planes):
  *   dst[row][col] = src[(row / row_inner) * row_outer_stride + (row % row_inner) * row_inner_stride

@@ -34,6 +34,7 @@ struct GemmArgs {
   const uint16_t* b_hi;  // [n_pad][k_pad]
   const uint16_t* b_lo;
   int m_pad, n_pad, k_pad;
+  int k_len;             // contraction length actually run (multiple of 64, <= k_pad = the planes' row pitch)
   // epilogue operands
   const float* x;        // [m_pad][n_pad] fp32 (ratio / loss)
   uint16_t* gn_hi;       // ratio outputs, [m_pad][n_pad]
@@ -42,6 +43,7 @@ struct GemmArgs {
   uint16_t* gp_lo;
   float* out;            // EPI_F32: [m_pad][n_pad];  EPI_LOSS: [gridDim.x * gridDim.y] partials
   int m_valid, n_valid;  // loss masking
+  int ldn;               // leading dimension of x / gn / gp / out (>= n_pad; a GEMM over the first n_pad columns of wider planes)
   float beta;
   // implicit Toeplitz operand (OPS != kOpsPlanes): the operand's *_hi / *_lo point to a window table
   int tB, tR, tT, tLh;   // H is (B, R, Lh), T taps
@@ -62,6 +64,7 @@ struct GemmShape {
 };
 using GemmSmall = GemmShape<2, 2, 2, 2>;
 using GemmBig = GemmShape<4, 2, 2, 4>;
+// (256 x 128 and 128 x 256 with eight 64 x 64 waves were measured too: same time as two 128 x 128 workgroups per CU.)
 
 template <bool X3, class SH>
 struct GemmCfg {
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int j = lane & 31, hl = lane >> 5;
   const int wm = wave / SH::WN, wn = wave % SH::WN;
   const int bm = blockIdx.y, bn = blockIdx.x;
-  const int ktiles = a.k_pad / C::BK;
+  const int ktiles = a.k_len / C::BK;
   const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
 
   // DMA source pointers: thread handles chunk c = p*THREADS + tid of a tile: row = c >> 3, LDS slot = c & 7,
@@ -117,11 +120,12 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   constexpr int TOP = OPS == kOpsAHu ? 0 : 1;                 // which operand is implicit
   constexpr int TROWS = TOP == 0 ? C::BM : C::BN;             // rows of the implicit operand's tile
   constexpr int TP = TOP == 0 ? C::PA : C::PB;
-  static_assert(OPS == kOpsPlanes || THREADS == 2 * TROWS, "two k-chunks of the implicit operand per DMA pass");
+  constexpr int KPP = THREADS / TROWS;                        // k-chunks of the implicit operand per DMA pass
+  static_assert(OPS == kOpsPlanes || (KPP * TROWS == THREADS && KPP * TP == 8), "whole k-chunks per DMA pass");
   constexpr bool kHuRows = OPS == kOpsBHu || OPS == kOpsAHu;  // rows (b,l), k = (r,t); else rows (r,t), k = (b,l)
   int trow = -1;      // chunk-index contribution of this thread's row (the same in all passes), -1 = padding row
   int tL = 0, tJJ = 0, tT8 = 0;
-  // k position of the thread's chunk in pass p (k-chunk 2p + tid / TROWS of the k-tile), advanced by one k-tile per
+  // k position of the thread's chunk in pass p (k-chunk KPP p + tid / TROWS of the k-tile), advanced by one k-tile per
   // stage_issue call, which come strictly in k order (no integer division in the loop):
   //   rows-(b,l) operand: k = r T + 8 tc  -> (kq, kr) = (r, tc);   rows-(r,t) operand: k = b L + l0 -> (kq, kr) = (b, l0)
   int kq[4] = {0, 0, 0, 0}, kr[4] = {0, 0, 0, 0};
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kc = 2 * p + (tid / TROWS);
+      const int kc = KPP * p + (tid / TROWS);
       if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
@@ -182,7 +186,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       }
     if constexpr (OPS != kOpsPlanes) toep_advance();
   };
-  (void)TP;
+  (void)TP; (void)KPP;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = bm * C::BM + wm * MI * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        const size_t idx = (size_t)m * a.n_pad + n;
+        const size_t idx = (size_t)m * a.ldn + n;
         const float s = acc[mi][ni][e];
         if constexpr (EPI == kEpiF32) {
           a.out[idx] = s;

@@ -377,6 +377,123 @@ __global__ void __launch_bounds__(256) conv_fold_apply_h_kernel(float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Ragged channels of the NMFD reconstruction.  The GEMMs work on 128-row tiles; a spectrogram with 2^k + 1 bins (1025 at
+// BASELINE configs[3]) pays a whole tile row -- 64 of 576 workgroups, a second scheduling round on 512 slots, 30 us per
+// reconstruction -- for ONE channel.  The host instead runs the GEMM over the first floor(C/128)*128 channels and this
+// kernel over the rest: S[c][(b,l)] = sum_{r,t} W[c][r][t] H[b][r][l-t] (nmf.py:776-779) by direct summation from the
+// fp32 masters (rounded to bf16 first in the single-plane mode, like the GEMM's operands), then the same elementwise
+// epilogue.  mode 0: ratio planes [c][(b,l)] (W half-step), 1: [(b,l)][c] (H half-step), 2: loss partials.
+// Block = 64 frames x 8 rank groups (one wave each, private W row + H window in LDS), combined in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+struct RaggedArgs {
+  const float* w;   // (C, R, T)
+  const float* h;   // (B, R, Lh)
+  int C, R, T, B, Lh, c0, x3, mode;
+  float beta;
+  const float* x;   // mode 0 / 2: [c][ld], mode 1: [(b,l)][ld]
+  int64_t ld;
+  uint16_t *gn_hi, *gn_lo, *gp_hi, *gp_lo;
+  float* loss_part; // mode 2: gridDim.x * gridDim.y partials
+};
+
+template <int BETA>
+__global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  const int tid = threadIdx.x, ll = tid & 63, rg = tid >> 6;
+  const int L = a.Lh + a.T - 1, lblocks = (L + 63) / 64;
+  const int b = blockIdx.x / lblocks, l0 = (blockIdx.x - b * lblocks) * 64;
+  const int c = a.c0 + blockIdx.y;
+  const int HS = a.T + 63;                       // H window of a 64-frame block: j = l0 - (T-1) .. l0 + 63
+  float* wl = rsm + rg * (a.T + HS);             // this wave's W[c][r][:] ...
+  float* hs = wl + a.T;                          // ... and H[b][r][window]
+  auto rnd = [&](float v) { return a.x3 ? v : bf16_lo(pack_bf16(v, 0.f)); };
+  float s = 0.f;
+  for (int r0 = 0; r0 < a.R; r0 += 8) {
+    const int r = r0 + rg;
+    if (r < a.R) {
+      // eight loads in flight per lane, then the LDS writes (a load -> write loop serialises the miss latencies)
+      const float* wp = a.w + ((size_t)c * a.R + r) * a.T;
+      const float* hp = a.h + ((size_t)b * a.R + r) * a.Lh;
+      for (int t0 = 0; t0 < a.T; t0 += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (t0 + u * 64 + ll < a.T) ? wp[t0 + u * 64 + ll] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (t0 + u * 64 + ll < a.T) wl[t0 + u * 64 + ll] = rnd(v[u]);
+      }
+      for (int k0 = 0; k0 < HS; k0 += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int jx = l0 - (a.T - 1) + k0 + u * 64 + ll;
+          v[u] = (k0 + u * 64 + ll < HS && jx >= 0 && jx < a.Lh) ? hp[jx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u * 64 + ll < HS) hs[k0 + u * 64 + ll] = rnd(v[u]);
+      }
+    }
+    __syncthreads();
+    if (r < a.R) {
+      const float* hq = hs + ll + a.T - 1;       // H[b][r][l - t] = hq[-t]
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+      int t = 0;
+      for (; t + 16 <= a.T; t += 16) {           // LDS latency, not bandwidth, bounds this loop: 32 reads in flight
+        float wv[16], hv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = wl[t + u], hv[u] = hq[-t - u];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          p0 = fmaf(wv[u], hv[u], p0), p1 = fmaf(wv[u + 1], hv[u + 1], p1);
+          p2 = fmaf(wv[u + 2], hv[u + 2], p2), p3 = fmaf(wv[u + 3], hv[u + 3], p3);
+        }
+      }
+      for (; t < a.T; ++t) p0 = fmaf(wl[t], hq[-t], p0);
+      s += (p0 + p1) + (p2 + p3);
+    }
+    __syncthreads();
+  }
+  float* red = rsm;                              // [8][64]
+  red[rg * 64 + ll] = s;
+  __syncthreads();
+  float lv = 0.f;
+  if (rg == 0) {
+    float S = (BETA != kEuc) ? kEps : 0.f;       // the GEMM seeds its accumulators the same way
+#pragma unroll
+    for (int g = 0; g < 8; ++g) S += red[g * 64 + ll];
+    const int l = l0 + ll;
+    if (l < L) {
+      const int64_t n = (int64_t)b * L + l;
+      const size_t idx = a.mode == 1 ? (size_t)n * a.ld + c : (size_t)c * a.ld + n;
+      const float x = a.x[idx];
+      if (a.mode == 2) {
+        lv = loss_elem<BETA>(S, x, a.beta);
+      } else {
+        float gn, gp;
+        mu_elem<BETA>(S, x, a.beta, gn, gp);
+        const uint32_t nh = pack_bf16(gn, 0.f);
+        a.gn_hi[idx] = (uint16_t)nh;
+        if (a.x3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
+        if constexpr (BETA != kKL) {
+          const uint32_t ph = pack_bf16(gp, 0.f);
+          a.gp_hi[idx] = (uint16_t)ph;
+          if (a.x3) a.gp_lo[idx] = (uint16_t)pack_bf16(gp - bf16_lo(ph), 0.f);
+        }
+      }
+    }
+  }
+  if (a.mode == 2) {
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o, 64);
+      if (ll == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = lv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // NMF2D / NMF3D (nmf.py:782-942): the same unfold / fold with up to three shift axes.  Axes are stored outermost
 // first and missing leading axes have extent 1, so 1-D .. 3-D share this code.  Used by the explicit-operand path
 // only (these layers are small: the reference's own examples are (33,50) x 3x3 and (64,64,100) x 5x5x20).
@@ -491,6 +608,8 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   a.a_hi = (const uint16_t*)d->a_hi, a.a_lo = (const uint16_t*)d->a_lo;
   a.b_hi = (const uint16_t*)d->b_hi, a.b_lo = (const uint16_t*)d->b_lo;
   a.m_pad = d->m_pad, a.n_pad = d->n_pad, a.k_pad = d->k_pad;
+  a.k_len = d->k_len ? d->k_len : d->k_pad;
+  if (a.k_len <= 0 || a.k_len > d->k_pad || a.k_len % 64) return NMFMU_ERR_ARG;
   a.x = d->x;
   a.gn_hi = (uint16_t*)d->gn_hi, a.gn_lo = (uint16_t*)d->gn_lo, a.gp_hi = (uint16_t*)d->gp_hi, a.gp_lo = (uint16_t*)d->gp_lo;
   a.out = d->out;
@@ -527,6 +646,8 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else if (d->tile_rows != 0 && d->tile_rows != 128) {
     return NMFMU_ERR_ARG;
   }
+  a.ldn = d->n_ld ? d->n_ld : d->n_pad;
+  if (a.ldn < d->n_pad || (a.ldn != d->n_pad && epilogue == NMFMU_EPI_FOLD)) return NMFMU_ERR_ARG;
   return launch_gemm(x3, epilogue, kind, d->ops, big, a, S(stream));
 }
 
@@ -631,6 +752,40 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
   const int grid = batch * rank * ((lh + 63) / 64);
   hipLaunchKernelGGL(conv_fold_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
                      y_num, y_den, kl_den, bl_pad, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_ragged_supported(int rank, int taps) {
+  return rank > 0 && taps > 0 && (size_t)8 * (2 * (size_t)taps + 63) * sizeof(float) <= 64 * 1024;
+}
+
+int nmfmu_conv_ragged_blocks(int batch, int lh, int taps) { return batch * ((lh + taps - 1 + 63) / 64); }
+
+int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, const float* h, int batch, int lh, int c0,
+                           int precision, float beta, int mode, const float* x, int64_t ld, void* gn_hi, void* gn_lo,
+                           void* gp_hi, void* gp_lo, float* loss_part, void* stream) {
+  if (!w || !h || !x || channels <= 0 || batch <= 0 || lh <= 0 || c0 < 0 || c0 >= channels || mode < 0 || mode > 2)
+    return NMFMU_ERR_ARG;
+  if (!nmfmu_conv_ragged_supported(rank, taps)) return NMFMU_ERR_UNSUPPORTED;
+  const int x3 = precision == NMFMU_PREC_BF16X3;
+  if (precision != NMFMU_PREC_BF16 && !x3) return NMFMU_ERR_UNSUPPORTED;
+  const int kind = nmfmu_beta_kind(beta);
+  if (mode == 2) {
+    if (!loss_part) return NMFMU_ERR_ARG;
+  } else {
+    if (!gn_hi || (x3 && !gn_lo)) return NMFMU_ERR_ARG;
+    if (kind != NMFMU_BETA_KL && (!gp_hi || (x3 && !gp_lo))) return NMFMU_ERR_ARG;
+  }
+  RaggedArgs a{w, h, channels, rank, taps, batch, lh, c0, x3, mode, beta, x, ld, (uint16_t*)gn_hi, (uint16_t*)gn_lo,
+               (uint16_t*)gp_hi, (uint16_t*)gp_lo, loss_part};
+  const dim3 grid(nmfmu_conv_ragged_blocks(batch, lh, taps), channels - c0);
+  const size_t lds = std::max<size_t>((size_t)8 * (2 * (size_t)taps + 63), 512) * sizeof(float);
+  switch (kind) {
+    case kKL: hipLaunchKernelGGL(conv_ragged_rows_kernel<kKL>, grid, dim3(512), lds, S(stream), a); break;
+    case kEuc: hipLaunchKernelGGL(conv_ragged_rows_kernel<kEuc>, grid, dim3(512), lds, S(stream), a); break;
+    case kIS: hipLaunchKernelGGL(conv_ragged_rows_kernel<kIS>, grid, dim3(512), lds, S(stream), a); break;
+    default: hipLaunchKernelGGL(conv_ragged_rows_kernel<kGen>, grid, dim3(512), lds, S(stream), a); break;
+  }
   return (int)hipGetLastError();
 }
 

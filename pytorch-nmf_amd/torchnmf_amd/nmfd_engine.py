@@ -35,10 +35,11 @@ def _stream() -> int:
 class _Planes:
     """bf16 (hi[, lo]) planes of a zero-padded row-major matrix."""
 
-    def __init__(self, rows_pad, cols_pad, x3, dev):
+    def __init__(self, rows_pad, cols_pad, x3, dev, zero=False):
         self.rows_pad, self.cols_pad = rows_pad, cols_pad
-        self.hi = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev)
-        self.lo = torch.empty(rows_pad * cols_pad, dtype=torch.int16, device=dev) if x3 else None
+        alloc = torch.zeros if zero else torch.empty     # zero: a writer that does not cover the padding every time
+        self.hi = alloc(rows_pad * cols_pad, dtype=torch.int16, device=dev)
+        self.lo = alloc(rows_pad * cols_pad, dtype=torch.int16, device=dev) if x3 else None
 
 
 class _Table:
@@ -122,10 +123,18 @@ class ConvMU:
         else:
             self.hu = _Planes(blp, rpp, x3, dev)    # [(b,l)][(r,t)]
             self.hut = _Planes(rpp, blp, x3, dev)   # [(r,t)][(b,l)]
-        self.gn = _Planes(cp, blp, x3, dev)     # W half-step ratio, [c][(b,l)]
-        self.gnt = _Planes(blp, cp, x3, dev)    # H half-step ratio, [(b,l)][c]
-        self.gp = None if self.kl else _Planes(cp, blp, x3, dev)
-        self.gpt = None if self.kl else _Planes(blp, cp, x3, dev)
+        # Ragged channels: with C = 128 k + (1..8) channels (1025 bins at configs[3]) the reconstruction GEMMs run over the
+        # first 128 k only and nmfmu_conv_ragged_rows sums the rest directly -- a whole tile row (64 of 576 workgroups,
+        # i.e. a second scheduling round: 30 us per reconstruction) for one channel otherwise.
+        self.c_main = (Cc // 128) * 128
+        self.ragged = (own_loop and nd == 1 and self.tile == 128 and self.c_main >= 128 and 0 < Cc - self.c_main <= 8 and
+                       bool(self.lib.nmfmu_conv_ragged_supported(R, T)) and
+                       os.environ.get('TORCHNMF_AMD_NMFD_RAGGED', '1') != '0')
+        rz = self.ragged                        # the GEMM then leaves the padding rows / columns of the ratio planes alone
+        self.gn = _Planes(cp, blp, x3, dev, rz)     # W half-step ratio, [c][(b,l)]
+        self.gnt = _Planes(blp, cp, x3, dev, rz)    # H half-step ratio, [(b,l)][c]
+        self.gp = None if self.kl else _Planes(cp, blp, x3, dev, rz)
+        self.gpt = None if self.kl else _Planes(blp, cp, x3, dev, rz)
         self.num_w = torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         self.den_w = None if self.kl else torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         # H numerator Y[(r,t)][(b,l)] before the col2im sum: with >= 128 taps the GEMM hands over per-tile diagonal sums
@@ -138,7 +147,9 @@ class ConvMU:
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
-        self.loss_part = torch.zeros((cp // 128) * (blp // 128), dtype=torch.float32, device=dev)   # 256-tiles write fewer
+        self._loss_main = (self.c_main // 128) * (blp // 128)      # partials of the GEMM part when the channels are ragged
+        nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
+        self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self.graphable = True   # fixed launches on fixed buffers: fit() replays an iteration as one hipGraph
         self.refresh_images()
@@ -149,8 +160,13 @@ class ConvMU:
                                           _ptr(dst_f32), _ptr(planes.hi) if planes else None,
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
-    def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0):
+    def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
+              n_rows=None, k_len=0):
+        """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
+        output planes keep their leading dimension."""
         assert a.cols_pad == b.cols_pad
+        m_pad, n_pad = m_rows or a.rows_pad, n_rows or b.rows_pad
+        n_ld = b.rows_pad if n_rows else 0
         ops = _capi.OPS_PLANES
         if self.implicit:
             ops = (_capi.OPS_A_HU if a is self.hu else _capi.OPS_B_HU if b is self.hu else
@@ -159,11 +175,20 @@ class ConvMU:
         if (self.tile == 256 and (self._tile_forced or (a.rows_pad // 256) * (b.rows_pad // 256) >= 128) and
                 self.lib.nmfmu_gemm_tile256_supported(self.precision, self.beta, epi, ops)):
             tile = 256
-        d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), a.rows_pad, b.rows_pad, a.cols_pad,
+        d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), m_pad, n_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
-                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile)
+                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
+
+    def _ragged(self, mode, x, gn=None, gp=None):
+        """The channels the reconstruction GEMM left out (mode 0: W half-step planes, 1: H half-step planes, 2: loss)."""
+        ld = self.bl_pad if mode != 1 else self.c_pad
+        loss = self.loss_part.data_ptr() + 4 * self._loss_main if mode == 2 else None
+        _capi.check(self.lib.nmfmu_conv_ragged_rows(
+            self.W.data_ptr(), self.C, self.R, self.T, self.H.data_ptr(), self.B, self.Lh, self.c_main, self.precision,
+            self.beta, mode, x.data_ptr(), ld, _ptr(gn.hi) if gn else None, _ptr(gn.lo) if gn else None,
+            _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None, loss, _stream()), 'nmfmu_conv_ragged_rows')
 
     def _rank_sums(self, src, outer, inner, out):
         """beta == 1 denominators (nmf.py:122-131): sum over everything but the rank axis.  (Running these two small
@@ -211,9 +236,18 @@ class ConvMU:
         bad, mn = (int(x) for x in self.flags.tolist())
         return bool(bad), mn == 0
 
+    def recon_ratio_w(self):
+        """Reconstruction + ratio planes of the W half-step (nmf.py:61-74 on Wm Hu^T): the GEMM over the channels that
+        fill whole tiles, the ragged ones by direct summation."""
+        if self.ragged:
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_main)
+            self._ragged(0, self.x_w, self.gn, self.gp)
+        else:
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp)
+
     def w_step(self):
         """nmf.py:367-378 for the conv1d model."""
-        self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp)
+        self.recon_ratio_w()
         self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w)
         if not self.kl:
             self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
@@ -221,11 +255,16 @@ class ConvMU:
 
     def h_step(self):
         """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
-        self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt)
+        if self.ragged:
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_main)
+            self._ragged(1, self.x_h, self.gnt, self.gpt)
+        else:
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt)
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
-        self._gemm(self.wmt, self.gnt, epi, out=self.y)
+        kc = -(-self.C // 64) * 64             # the contraction runs over the channels: skip the zero tail of the padding
+        self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc)
         if not self.kl:
-            self._gemm(self.wmt, self.gpt, epi, out=self.y_den)
+            self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc)
         kl_den = self.sum_w.data_ptr() if self.kl else None
         if self.fold_parts:
             _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
@@ -247,7 +286,9 @@ class ConvMU:
     def divergence(self) -> float:
         """beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401).  One host sync."""
         self._gemm(self.wm, self.hu, _capi.EPI_LOSS, x=self.x_w, out=self.loss_part, m_valid=self.C,
-                   n_valid=self.B * self.L)
+                   n_valid=self.B * self.L, m_rows=self.c_main if self.ragged else None)
+        if self.ragged:
+            self._ragged(2, self.x_w)
         return float(self.loss_part.double().sum().item())
 
 

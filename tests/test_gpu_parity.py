@@ -636,6 +636,44 @@ def test_nmfd_256x256_gemm_tiles(dev, shape, monkeypatch):
     assert rel_err(res['256'][0], Wr) < 5e-3 and rel_err(res['256'][1], Hr) < 5e-3
 
 
+@pytest.mark.parametrize('shape', [(1, 129, 304, 4, 8), (2, 257, 200, 3, 24), (1, 136, 600, 2, 400), (1, 1025, 520, 3, 136),
+                                   (3, 130, 96, 9, 5)])
+@pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (1, 'bf16')])
+def test_nmfd_ragged_channels(dev, shape, beta, prec, monkeypatch):
+    """C = 128 k + (1..8) channels (the 1025 bins of configs[3]): the reconstruction GEMMs cover the first 128 k channels,
+    nmfmu_conv_ragged_rows the rest by direct summation, for both half-steps and the loss.  Must agree with the all-GEMM
+    path (same rounded operands, another summation order for the ragged rows) and with the oracle; ragged counts 1, 2
+    and 8, batches, implicit and explicit Toeplitz operands, more ranks than rank groups (R = 9)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_RAGGED', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, 0.01, 0.02, precision=prec)
+        assert eng.ragged == (mode == '1')
+        l0 = eng.divergence()
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), l0, eng.divergence())
+    tol = 2e-6 if prec == 'bf16x3' else 2e-5     # bf16: a ratio that rounds the other way moves an element by 2^-8
+    assert rel_err(res['0'][0], res['1'][0]) < tol and rel_err(res['0'][1], res['1'][1]) < tol
+    # the ragged rows themselves (not drowned in the norm of the other 128 k)
+    cm = (Cc // 128) * 128
+    assert rel_err(res['0'][0][cm:], res['1'][0][cm:]) < (1e-5 if prec == 'bf16x3' else 5e-3)
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5) and res['0'][3] == pytest.approx(res['1'][3], rel=1e-5)
+    if prec == 'bf16x3':
+        Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
+        assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
+        assert rel_err(res['1'][0][cm:], Wr[cm:]) < TOL
+
+
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
