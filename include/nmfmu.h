@@ -318,6 +318,21 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
                             const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream);
 /* The same update from the per-tile diagonal sums of NMFMU_EPI_FOLD GEMMs (p_num / p_den) instead of Y: saves writing
  * and re-reading 4 * R*T * B*L bytes per GEMM.  Deterministic (fixed gather order). */
+/* The same two kernels with the beta == 1 denominators (nmf.py:122-131) fused in instead of nmfmu_rank_sums launches:
+ *   nmfmu_conv_apply_pack_w_sums     takes sum_{b,j} H[b][r][j] as kl_den (finished) or as kl_hpart[rank][n_hparts]
+ *                                    partials, and leaves wcol[c_pad/64][rp_pad/64][2] = sums of W per 64 x 64 tile and
+ *                                    rank (taps >= 64: at most two ranks per tile);
+ *   nmfmu_conv_fold_parts_apply_h_sums takes sum_{c,t} W[c][r][t] as kl_den or as kl_wcol (c_tiles = c_pad / 64) and
+ *                                    leaves hsum_part[rank][nmfmu_fold_hsum_parts(batch, lh)] partial sums of the new H. */
+int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int c_pad,
+                                 int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi, void* wm_lo,
+                                 void* wmt_hi, void* wmt_lo, void* stream);
+int nmfmu_fold_hsum_parts(int batch, int lh);
+int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,
+                                       const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
+                                       int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma,
+                                       void* stream);
 size_t nmfmu_fold_part_bytes(int m_pad, int n_pad);
 int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps);
 int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,

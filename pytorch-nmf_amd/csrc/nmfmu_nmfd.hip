@@ -271,27 +271,68 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
                                                                 const float* __restrict__ kl_den, int c_pad, int rp_pad,
                                                                 float l1, float l2, float gamma, int update,
                                                                 uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
-                                                                uint16_t* wmt_lo, const float* __restrict__ scale) {
+                                                                uint16_t* wmt_lo, const float* __restrict__ scale,
+                                                                const float* __restrict__ kl_hpart, int n_hparts,
+                                                                float* __restrict__ wcol) {
   constexpr int LDT = 65;
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  for (int idx = tid; idx < 64 * 64; idx += 256) {     // consecutive threads along k: coalesced fp32 traffic
-    const int cl = idx >> 6, kl = idx & 63, c = c0 + cl, kk = k0 + kl;
-    float v = 0.f;
+  // the tile's own loads first (sixteen elements per thread, consecutive threads along k: coalesced fp32 traffic) ...
+  const bool klm = kl_den != nullptr || kl_hpart != nullptr;
+  float wv[16], nv[16], dv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = i * 256 + tid, c = c0 + (idx >> 6), kk = k0 + (idx & 63);
+    const bool in = c < C && kk < RT;
+    wv[i] = in ? W[(size_t)c * RT + kk] : 0.f;
+    nv[i] = (in && update) ? num[(size_t)c * rp_pad + kk] : 0.f;
+    dv[i] = (in && update && !klm) ? den[(size_t)c * rp_pad + kk] : 0.f;
+  }
+  // ... then the beta == 1 denominators sum_{b,j} H[b][r][j], handed over as per-block partials of the kernel that
+  // updated H (kl_hpart[r][n_hparts]).  With T >= 64 a 64-wide k range touches at most two ranks: every wave finishes
+  // both sums itself (butterfly: every lane ends up with the total, fixed order) -- no LDS, no barrier.
+  const int r_lo = k0 / T;
+  float den_lo = 0.f, den_hi = 0.f;
+  if (update && kl_hpart) {
+    const int lane = tid & 63, r_hi = min(r_lo + 1, (RT - 1) / T);
+    for (int pp = lane; pp < n_hparts; pp += 64) {
+      den_lo += kl_hpart[(size_t)r_lo * n_hparts + pp];
+      den_hi += kl_hpart[(size_t)r_hi * n_hparts + pp];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) den_lo += __shfl_xor(den_lo, o, 64), den_hi += __shfl_xor(den_hi, o, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = i * 256 + tid, cl = idx >> 6, kl = idx & 63, c = c0 + cl, kk = k0 + kl;
+    float v = wv[i];
     if (c < C && kk < RT) {
-      const size_t wi = (size_t)c * RT + kk;
-      v = W[wi];
       if (update) {
-        const size_t o = (size_t)c * rp_pad + kk;
-        v = mu_update(v, num[o], kl_den ? kl_den[kk / T] : den[o], kl_den != nullptr, l1, l2, gamma);
-        W[wi] = v;
+        const float pos = kl_hpart ? (kk < (r_lo + 1) * T ? den_lo : den_hi) : kl_den ? kl_den[kk / T] : dv[i];
+        v = mu_update(v, nv[i], pos, klm, l1, l2, gamma);
+        W[(size_t)c * RT + kk] = v;
       }
       if (scale) v *= scale[kk / T];   // planes of W * Z (shift-invariant PLCA); the master is not scaled
     }
     tile[cl * LDT + kl] = v;
   }
   __syncthreads();
+  if (wcol && tid < 64) {
+    // sum of this 64 x 64 tile per rank (at most two: T >= 64), [c tile][k tile][2]: the next H half-step finishes
+    // sum_{c,t} W[c][r][t] from these (nmf.py:122-131) instead of two reduction launches
+    float sacc = 0.f;
+#pragma unroll 8
+    for (int cl = 0; cl < 64; ++cl) sacc += tile[cl * LDT + tid];
+    const bool second = (k0 + tid) / T != r_lo;
+    float a0 = second ? 0.f : sacc, a1 = second ? sacc : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a0 += __shfl_xor(a0, o, 64), a1 += __shfl_xor(a1, o, 64);
+    if (tid == 0) {
+      float* po = wcol + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+      po[0] = a0, po[1] = a1;
+    }
+  }
   for (int idx = tid; idx < 2 * 64 * 8; idx += 256) {  // 16-byte chunks: 512 of Wm (8 consecutive k), 512 of WmT (8 c)
     const bool tr = idx >= 512;
     const int q = idx & 511, row = q >> 3, ch = (q & 7) * 8;
@@ -317,31 +358,70 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
 __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __restrict__ H, int B, int R, int Lh, int T,
                                                                       const float* __restrict__ pnum,
                                                                       const float* __restrict__ pden,
-                                                                      const float* __restrict__ kl_den, int tiles_n,
-                                                                      float l1, float l2, float gamma) {
+                                                                      const float* __restrict__ kl_den,
+                                                                      const float* __restrict__ kl_wcol, int c_tiles,
+                                                                      int rp_pad, float* __restrict__ hsum_part,
+                                                                      int tiles_n, float l1, float l2, float gamma) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
   const int L = Lh + T - 1;
   const int jblocks = (Lh + 255) / 256;
   const int jb = blockIdx.x % jblocks, r = (blockIdx.x / jblocks) % R, b = blockIdx.x / (jblocks * R);
-  const int jx = jb * 256 + threadIdx.x;
-  if (jx >= Lh) return;
+  const int jx = jb * 256 + tid;
+  const bool valid = jx < Lh;
+  auto block_sum = [&](float v) {   // fixed-order tree: identical bits in every block that sums the same values
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float tot = red[0];
+    __syncthreads();
+    return tot;
+  };
+  // beta == 1 denominator sum_{c,t} W[c][r][t] (nmf.py:122-131): either finished (kl_den) or as the per-tile sums
+  // conv_apply_pack_w left behind (kl_wcol: no separate reduction launches)
+  const bool kl = kl_den != nullptr || kl_wcol != nullptr;
+  float den = 0.f;
+  if (kl_wcol) {
+    // [c tile][k tile][2] tile sums of W (conv_apply_pack_w): the k tiles that hold taps of rank r, slot = second rank
+    const int kt_lo = (r * T) / 64, kt_n = (r * T + T - 1) / 64 - kt_lo + 1, k_tiles = rp_pad / 64;
+    float sacc = 0.f;
+    for (int i = tid; i < c_tiles * kt_n; i += 256) {
+      const int ct = i / kt_n, kt = kt_lo + (i - ct * kt_n);
+      sacc += kl_wcol[((size_t)ct * k_tiles + kt) * 2 + (r > (kt * 64) / T ? 1 : 0)];
+    }
+    den = block_sum(sacc);
+  } else if (kl_den) {
+    den = kl_den[r];
+  }
   const int m_lo = r * T, m_hi = m_lo + T;
   const int diag = jx + b * L - m_lo;        // n - m of every element of this sum
-  float neg = 0.f, pos = 0.f;
-  for (int tm = m_lo / 128; tm <= (m_hi - 1) / 128; ++tm) {
-    const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
-    const int rbit = r > (tm * 128) / T ? 2 : 0;
-    const int na = b * L + jx + ta, nz = b * L + jx + tb - 1;
-    for (int tn = na / 128; tn <= nz / 128; ++tn) {
-      const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
-      const int dd = diag - 128 * (tn - tm) + 127;
-      const size_t i = ((size_t)(tm * tiles_n + tn) * 4 + seg) * 256 + dd;
-      neg += pnum[i];
-      if (!kl_den) pos += pden[i];
+  float neg = 0.f, pos = 0.f, hv = 0.f;
+  if (valid) {
+    for (int tm = m_lo / 128; tm <= (m_hi - 1) / 128; ++tm) {
+      const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
+      const int rbit = r > (tm * 128) / T ? 2 : 0;
+      const int na = b * L + jx + ta, nz = b * L + jx + tb - 1;
+      for (int tn = na / 128; tn <= nz / 128; ++tn) {
+        const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
+        const int dd = diag - 128 * (tn - tm) + 127;
+        const size_t i = ((size_t)(tm * tiles_n + tn) * 4 + seg) * 256 + dd;
+        neg += pnum[i];
+        if (!kl) pos += pden[i];
+      }
     }
+    if (kl) pos = den;
+    const size_t i = ((size_t)b * R + r) * Lh + jx;
+    hv = mu_update(H[i], neg, pos, kl, l1, l2, gamma);
+    H[i] = hv;
   }
-  if (kl_den) pos = kl_den[r];
-  const size_t i = ((size_t)b * R + r) * Lh + jx;
-  H[i] = mu_update(H[i], neg, pos, kl_den != nullptr, l1, l2, gamma);
+  if (hsum_part) {   // partial sum_{b,j} H[b][r][j] of the NEW H for the next W half-step: [r][b * jblocks + jb]
+    const float tot = block_sum(hv);
+    if (tid == 0) hsum_part[(size_t)r * (B * jblocks) + b * jblocks + jb] = tot;
+  }
 }
 
 // H (B, R, Lh) in place; neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)], Y fp32 [rp_pad][bl_pad].
@@ -715,20 +795,22 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
 
 static int conv_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                        const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
-                       void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream) {
+                       void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream,
+                       const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr) {
   if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
-  if (update && (!num || (!den && !kl_den))) return NMFMU_ERR_ARG;
+  if (update && (!num || (!den && !kl_den && !kl_hpart))) return NMFMU_ERR_ARG;
+  if ((kl_hpart && n_hparts <= 0) || (wcol && scale) || ((kl_hpart || wcol) && taps < 64)) return NMFMU_ERR_ARG;
   if (c_pad < channels || rp_pad < (int64_t)rank * taps || c_pad % 64 || rp_pad % 64 || (wm_lo == nullptr) != (wmt_lo == nullptr))
     return NMFMU_ERR_ARG;
   const dim3 grid(rp_pad / 64, c_pad / 64);
   if (wm_lo)
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
-                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale);
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol);
   else
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
-                       nullptr, scale);
+                       nullptr, scale, kl_hpart, n_hparts, wcol);
   return (int)hipGetLastError();
 }
 
@@ -737,6 +819,14 @@ int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const fl
                             void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
   return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
                      wmt_lo, nullptr, stream);
+}
+
+int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int c_pad,
+                                 int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi, void* wm_lo,
+                                 void* wmt_hi, void* wmt_lo, void* stream) {
+  return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
+                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol);
 }
 
 int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,
@@ -795,14 +885,31 @@ int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps) {
   return batch > 0 && rank > 0 && lh > 0 && taps >= 128 && lh + taps - 1 >= 128;
 }
 
-int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
-                                  const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream) {
-  if (!h || !p_num || (!p_den && !kl_den) || bl_pad % 128 || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
+static int fold_parts_apply(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
+                            const float* kl_den, const float* kl_wcol, int c_tiles, int rp_pad, float* hsum_part, int bl_pad,
+                            float l1, float l2, float gamma, void* stream) {
+  if (!h || !p_num || (!p_den && !kl_den && !kl_wcol) || bl_pad % 128 || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
+  if (kl_wcol && (c_tiles <= 0 || rp_pad < rank * taps)) return NMFMU_ERR_ARG;
   if (!nmfmu_fold_parts_supported(batch, rank, lh, taps)) return NMFMU_ERR_UNSUPPORTED;
   const int grid = batch * rank * ((lh + 255) / 256);
   hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps, p_num,
-                     p_den, kl_den, bl_pad / 128, l1, l2, gamma);
+                     p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma);
   return (int)hipGetLastError();
+}
+
+int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
+                                  const float* kl_den, int bl_pad, float l1, float l2, float gamma, void* stream) {
+  return fold_parts_apply(h, batch, rank, lh, taps, p_num, p_den, kl_den, nullptr, 0, 0, nullptr, bl_pad, l1, l2, gamma, stream);
+}
+
+int nmfmu_fold_hsum_parts(int batch, int lh) { return batch * ((lh + 255) / 256); }
+
+int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,
+                                       const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
+                                       int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma,
+                                       void* stream) {
+  return fold_parts_apply(h, batch, rank, lh, taps, p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad, l1, l2,
+                          gamma, stream);
 }
 
 static int make_geom(int nd, const int32_t* lh, const int32_t* taps, ConvGeom* g) {

@@ -147,6 +147,13 @@ class ConvMU:
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
+        # beta == 1 on the fold-parts path: the rank sums ride in the kernels that produce / consume them
+        self.fused_sums = (self.kl and self.fold_parts and os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
+        if self.fused_sums:
+            self.n_hparts = self.lib.nmfmu_fold_hsum_parts(B, Lh)
+            self.hpart = torch.zeros(R * self.n_hparts, dtype=torch.float32, device=dev)
+            self.wcol = torch.zeros((cp // 64) * (rpp // 64) * 2, dtype=torch.float32, device=dev)
+        self._h_parts_valid = False
         self._loss_main = (self.c_main // 128) * (blp // 128)      # partials of the GEMM part when the channels are ragged
         nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
         self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
@@ -200,6 +207,17 @@ class ConvMU:
 
     def _pack_w(self, update: bool = False):
         """W -> Wm / WmT planes (one kernel); with ``update`` the MU apply of nmf.py:78-92 runs in the same pass."""
+        if self.fused_sums:
+            # beta == 1 denominators ride along: sum_h arrives finished or as the partials of the kernel that updated H,
+            # the column sums of the new W leave as per-64-channel-tile partials for the H half-step (no rank_sums launches)
+            kl = update and self.kl
+            _capi.check(self.lib.nmfmu_conv_apply_pack_w_sums(
+                self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None, None,
+                self.sum_h.data_ptr() if (kl and not self._h_parts_valid) else None,
+                self.hpart.data_ptr() if (kl and self._h_parts_valid) else None, self.n_hparts, self.wcol.data_ptr(),
+                self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
+                _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w_sums')
+            return
         _capi.check(self.lib.nmfmu_conv_apply_pack_w(
             self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None,
             _ptr(self.den_w) if update else None, self.sum_h.data_ptr() if (update and self.kl) else None, self.c_pad,
@@ -207,14 +225,16 @@ class ConvMU:
             _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w')
         self._rank_sums(self.W, self.C, self.T, self.sum_w)
 
-    def _pack_h(self):
+    def _pack_h(self, sums: bool = True):
         if self.implicit:
             _capi.check(self.lib.nmfmu_conv_tables(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
                                                    _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), _stream()),
                         'nmfmu_conv_tables')
         else:
             self._unfold()
-        self._rank_sums(self.H, self.B, self.Lh, self.sum_h)
+        if sums:
+            self._rank_sums(self.H, self.B, self.Lh, self.sum_h)
+            self._h_parts_valid = False
 
     def _unfold(self):
         if self.nd == 1:
@@ -266,6 +286,14 @@ class ConvMU:
         if not self.kl:
             self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc)
         kl_den = self.sum_w.data_ptr() if self.kl else None
+        if self.fused_sums:
+            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_sums(
+                self.H.data_ptr(), self.B, self.R, self.Lh, self.T, self.y.data_ptr(), None, None, self.wcol.data_ptr(),
+                self.c_pad // 64, self.rp_pad, self.hpart.data_ptr(), self.bl_pad, self.l1, self.l2, self.gamma, _stream()),
+                'nmfmu_conv_fold_parts_apply_h_sums')
+            self._h_parts_valid = True
+            self._pack_h(sums=False)
+            return
         if self.fold_parts:
             _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
                                                                self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,

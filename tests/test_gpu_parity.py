@@ -674,6 +674,38 @@ def test_nmfd_ragged_channels(dev, shape, beta, prec, monkeypatch):
         assert rel_err(res['1'][0][cm:], Wr[cm:]) < TOL
 
 
+@pytest.mark.parametrize('shape', [(1, 40, 520, 3, 136), (2, 33, 335, 2, 130), (1, 129, 600, 2, 400), (3, 70, 300, 5, 128)])
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+def test_nmfd_rank_sums_ride_in_their_producers(dev, shape, prec, monkeypatch):
+    """beta == 1 with >= 128 taps: the denominators sum_{c,t} W and sum_{b,j} H (nmf.py:122-131) are not separate
+    reduction launches -- conv_apply_pack_w leaves per-channel-tile column sums of W that the H update finishes, the H
+    update leaves per-block sums that the next W update finishes.  Same values, another summation order: must agree with
+    the nmfmu_rank_sums path to fp32 rounding over three iterations (the hand-over crosses iteration boundaries)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_FUSED_SUMS', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, 1, 0.01, 0.02, precision=prec)
+        assert eng.fused_sums == (mode == '1')
+        for _ in range(3):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), eng.divergence())
+    tol = 3e-6 if prec == 'bf16x3' else 3e-5
+    assert rel_err(res['0'][0], res['1'][0]) < tol and rel_err(res['0'][1], res['1'][1]) < tol
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5)
+    if prec == 'bf16x3':
+        Wr, Hr, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 3, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
+        assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
+
+
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
