@@ -253,6 +253,9 @@ typedef struct nmfmu_gemm_desc {
   /* Contraction length actually run (0 = k_pad; a multiple of 64 covering the logical extent): the zero tail of
    * 128-padded planes need not be multiplied. */
   int32_t k_len;
+  /* NMFMU_EPI_F32 only: k_split (> 1) workgroups share the contraction of every tile; partial z goes to
+   * out + z * m_pad * n_ld (the consumer adds them).  For long-k GEMMs with too few tiles to fill the chip. */
+  int32_t k_split;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
@@ -319,15 +322,16 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
 /* The same update from the per-tile diagonal sums of NMFMU_EPI_FOLD GEMMs (p_num / p_den) instead of Y: saves writing
  * and re-reading 4 * R*T * B*L bytes per GEMM.  Deterministic (fixed gather order). */
 /* The same two kernels with the beta == 1 denominators (nmf.py:122-131) fused in instead of nmfmu_rank_sums launches:
- *   nmfmu_conv_apply_pack_w_sums     takes sum_{b,j} H[b][r][j] as kl_den (finished) or as kl_hpart[rank][n_hparts]
+ *   nmfmu_conv_apply_pack_w_sums     takes num as num_slabs split-K partials [slab][c_pad][rp_pad] (nmfmu_gemm_desc.k_split),
+ *                                    sum_{b,j} H[b][r][j] as kl_den (finished) or as kl_hpart[rank][n_hparts]
  *                                    partials, and leaves wcol[c_pad/64][rp_pad/64][2] = sums of W per 64 x 64 tile and
  *                                    rank (taps >= 64: at most two ranks per tile);
  *   nmfmu_conv_fold_parts_apply_h_sums takes sum_{c,t} W[c][r][t] as kl_den or as kl_wcol (c_tiles = c_pad / 64) and
  *                                    leaves hsum_part[rank][nmfmu_fold_hsum_parts(batch, lh)] partial sums of the new H. */
 int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
-                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int c_pad,
-                                 int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi, void* wm_lo,
-                                 void* wmt_hi, void* wmt_lo, void* stream);
+                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
+                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi,
+                                 void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
 int nmfmu_fold_hsum_parts(int batch, int lh);
 int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,
                                        const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,

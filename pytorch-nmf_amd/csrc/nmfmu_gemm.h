@@ -35,6 +35,7 @@ struct GemmArgs {
   const uint16_t* b_lo;
   int m_pad, n_pad, k_pad;
   int k_len;             // contraction length actually run (multiple of 64, <= k_pad = the planes' row pitch)
+  int k_split;           // EPI_F32 only: gridDim.z workgroups share the contraction; slab z of out = its partial sum
   // epilogue operands
   const float* x;        // [m_pad][n_pad] fp32 (ratio / loss)
   uint16_t* gn_hi;       // ratio outputs, [m_pad][n_pad]
@@ -88,7 +89,11 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int j = lane & 31, hl = lane >> 5;
   const int wm = wave / SH::WN, wn = wave % SH::WN;
   const int bm = blockIdx.y, bn = blockIdx.x;
-  const int ktiles = a.k_len / C::BK;
+  const int ktiles_all = a.k_len / C::BK;
+  // split-K (EPI_F32): workgroup z runs k-tiles [kt0, kt0 + ktiles) and stores its partial into slab z
+  const int kt_per = (ktiles_all + a.k_split - 1) / a.k_split;
+  const int kt0 = blockIdx.z * kt_per;
+  const int ktiles = max(0, min(kt_per, ktiles_all - kt0));
   const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
 
   // DMA source pointers: thread handles chunk c = p*THREADS + tid of a tile: row = c >> 3, LDS slot = c & 7,
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kc = KPP * p + (tid / TROWS);
+      const int kc = kt0 * 8 + KPP * p + (tid / TROWS);     // 8 chunks per k-tile
       if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl) {
         const bool implicit = OPS != kOpsPlanes && op == TOP;
-        const char* s0 = src[op * C::NPL + pl] + thr_off + (size_t)kt * (C::BK * 2);
+        const char* s0 = src[op * C::NPL + pl] + thr_off + (size_t)(kt0 + kt) * (C::BK * 2);
         const int passes = op == 0 ? C::PA : C::PB;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -339,7 +344,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         const size_t idx = (size_t)m * a.ldn + n;
         const float s = acc[mi][ni][e];
         if constexpr (EPI == kEpiF32) {
-          a.out[idx] = s;
+          a.out[(size_t)blockIdx.z * a.m_pad * a.ldn + idx] = s;
         } else if constexpr (EPI == kEpiLoss) {
           const float x = a.x[idx];
           lacc += (m < a.m_valid && n < a.n_valid) ? loss_elem<BETA>(s, x, a.beta) : 0.f;
@@ -389,7 +394,8 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     *flag = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, a.m_pad / C::BM), dim3(SH::THREADS), kLds, s, a);
+  if (a.k_split > 1 && EPI != kEpiF32) return -3;
+  hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, a.m_pad / C::BM, a.k_split), dim3(SH::THREADS), kLds, s, a);
   return (int)hipGetLastError();
 }
 

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
                                                                 uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
                                                                 uint16_t* wmt_lo, const float* __restrict__ scale,
                                                                 const float* __restrict__ kl_hpart, int n_hparts,
-                                                                float* __restrict__ wcol) {
+                                                                float* __restrict__ wcol, int num_slabs) {
   constexpr int LDT = 65;
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
@@ -287,6 +287,8 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
     const bool in = c < C && kk < RT;
     wv[i] = in ? W[(size_t)c * RT + kk] : 0.f;
     nv[i] = (in && update) ? num[(size_t)c * rp_pad + kk] : 0.f;
+    for (int sl = 1; sl < num_slabs; ++sl)     // split-K partials of the numerator GEMM ([slab][c_pad][rp_pad])
+      nv[i] += (in && update) ? num[(size_t)sl * c_pad * rp_pad + (size_t)c * rp_pad + kk] : 0.f;
     dv[i] = (in && update && !klm) ? den[(size_t)c * rp_pad + kk] : 0.f;
   }
   // ... then the beta == 1 denominators sum_{b,j} H[b][r][j], handed over as per-block partials of the kernel that
@@ -690,6 +692,8 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   a.m_pad = d->m_pad, a.n_pad = d->n_pad, a.k_pad = d->k_pad;
   a.k_len = d->k_len ? d->k_len : d->k_pad;
   if (a.k_len <= 0 || a.k_len > d->k_pad || a.k_len % 64) return NMFMU_ERR_ARG;
+  a.k_split = d->k_split > 1 ? d->k_split : 1;
+  if (a.k_split > 1 && (epilogue != NMFMU_EPI_F32 || (a.k_len / 64) % a.k_split)) return NMFMU_ERR_ARG;
   a.x = d->x;
   a.gn_hi = (uint16_t*)d->gn_hi, a.gn_lo = (uint16_t*)d->gn_lo, a.gp_hi = (uint16_t*)d->gp_hi, a.gp_lo = (uint16_t*)d->gp_lo;
   a.out = d->out;
@@ -796,7 +800,7 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
 static int conv_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                        const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
                        void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream,
-                       const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr) {
+                       const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr, int num_slabs = 1) {
   if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
   if (update && (!num || (!den && !kl_den && !kl_hpart))) return NMFMU_ERR_ARG;
   if ((kl_hpart && n_hparts <= 0) || (wcol && scale) || ((kl_hpart || wcol) && taps < 64)) return NMFMU_ERR_ARG;
@@ -806,11 +810,11 @@ static int conv_pack_w(float* w, int channels, int rank, int taps, const float* 
   if (wm_lo)
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
-                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol);
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol, num_slabs);
   else
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
-                       nullptr, scale, kl_hpart, n_hparts, wcol);
+                       nullptr, scale, kl_hpart, n_hparts, wcol, num_slabs);
   return (int)hipGetLastError();
 }
 
@@ -822,11 +826,12 @@ int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const fl
 }
 
 int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
-                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int c_pad,
-                                 int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi, void* wm_lo,
-                                 void* wmt_hi, void* wmt_lo, void* stream) {
+                                 const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
+                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi,
+                                 void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+  if (num_slabs < 1 || num_slabs > 8) return NMFMU_ERR_ARG;
   return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
-                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol);
+                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol, num_slabs);
 }
 
 int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,

@@ -50,7 +50,7 @@ class GemmDesc(C.Structure):
                 ('beta', C.c_float), ('x', C.c_void_p), ('gn_hi', C.c_void_p), ('gn_lo', C.c_void_p),
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
-                ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32)]
+                ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32)]
 
 
 ABI_VERSION = 3   # include/nmfmu.h: NMFMU_ABI_VERSION
@@ -144,9 +144,9 @@ SIGNATURES = {
                                          C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_apply_pack_w_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
-                                               C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p]),
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                               C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
     'nmfmu_fold_hsum_parts': (C.c_int, [C.c_int, C.c_int]),
     'nmfmu_conv_fold_parts_apply_h_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -135,7 +135,6 @@ class ConvMU:
         self.gnt = _Planes(blp, cp, x3, dev, rz)    # H half-step ratio, [(b,l)][c]
         self.gp = None if self.kl else _Planes(cp, blp, x3, dev, rz)
         self.gpt = None if self.kl else _Planes(blp, cp, x3, dev, rz)
-        self.num_w = torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         self.den_w = None if self.kl else torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         # H numerator Y[(r,t)][(b,l)] before the col2im sum: with >= 128 taps the GEMM hands over per-tile diagonal sums
         # (NMFMU_EPI_FOLD, 4 KiB per tile) instead of storing Y (4 R T B L bytes, 105 MB at configs[3])
@@ -154,6 +153,13 @@ class ConvMU:
             self.hpart = torch.zeros(R * self.n_hparts, dtype=torch.float32, device=dev)
             self.wcol = torch.zeros((cp // 64) * (rpp // 64) * 2, dtype=torch.float32, device=dev)
         self._h_parts_valid = False
+        # W numerator GEMM: [C x B L] . [B L x R T] has few tiles and a long contraction (225 tiles x 128 k-steps at
+        # configs[3]: one workgroup per CU, the second slot idle): split the contraction in two when that fills the chip
+        # better; the apply kernel adds the partials (beta == 1 fused-sums path only)
+        tiles = (cp // 128) * (rpp // 128)
+        self.w_ksplit = 2 if (os.environ.get('TORCHNMF_AMD_NMFD_KSPLIT', '1') != '0' and self.fused_sums and
+                              tiles <= 256 and (blp // 64) % 2 == 0 and blp >= 2048) else 1
+        self.num_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
         self._loss_main = (self.c_main // 128) * (blp // 128)      # partials of the GEMM part when the channels are ragged
         nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
         self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
@@ -168,7 +174,7 @@ class ConvMU:
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
-              n_rows=None, k_len=0):
+              n_rows=None, k_len=0, k_split=0):
         """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
         output planes keep their leading dimension."""
         assert a.cols_pad == b.cols_pad
@@ -185,7 +191,7 @@ class ConvMU:
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), m_pad, n_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
-                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len)
+                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split)
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
 
     def _ragged(self, mode, x, gn=None, gp=None):
@@ -215,7 +221,7 @@ class ConvMU:
                 self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None, None,
                 self.sum_h.data_ptr() if (kl and not self._h_parts_valid) else None,
                 self.hpart.data_ptr() if (kl and self._h_parts_valid) else None, self.n_hparts, self.wcol.data_ptr(),
-                self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
+                self.w_ksplit, self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
                 _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w_sums')
             return
         _capi.check(self.lib.nmfmu_conv_apply_pack_w(
@@ -268,7 +274,7 @@ class ConvMU:
     def w_step(self):
         """nmf.py:367-378 for the conv1d model."""
         self.recon_ratio_w()
-        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w)
+        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit)
         if not self.kl:
             self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
         self._pack_w(update=True)

@@ -706,6 +706,37 @@ def test_nmfd_rank_sums_ride_in_their_producers(dev, shape, prec, monkeypatch):
         assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
 
 
+@pytest.mark.parametrize('shape', [(1, 130, 2100, 2, 136), (2, 40, 1100, 3, 128)])
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+def test_nmfd_w_numerator_split_k(dev, shape, prec, monkeypatch):
+    """The W numerator GEMM (few tiles, contraction over all frames) runs as two half-contractions whose partials the
+    apply kernel adds (nmfmu_gemm_desc.k_split, implicit HuT operand starting mid-way): same products, one more rounding
+    per element."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_KSPLIT', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, 1, precision=prec)
+        assert eng.w_ksplit == (2 if mode == '1' else 1)
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), eng.divergence())
+    tol = 2e-6 if prec == 'bf16x3' else 2e-5
+    assert rel_err(res['0'][0], res['1'][0]) < tol and rel_err(res['0'][1], res['1'][1]) < tol
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5)
+    if prec == 'bf16x3':
+        Wr, Hr, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 2, kind='nmfd')
+        assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
+
+
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
