@@ -486,8 +486,13 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
   const int b = blockIdx.x / lblocks, l0 = (blockIdx.x - b * lblocks) * 64;
   const int c = a.c0 + blockIdx.y;
   const int HS = a.T + 63;                       // H window of a 64-frame block: j = l0 - (T-1) .. l0 + 63
-  float* wl = rsm + rg * (a.T + HS);             // this wave's W[c][r][:] ...
-  float* hs = wl + a.T;                          // ... and H[b][r][window]
+  const int TP = (a.T + 3) & ~3, WS = (TP + HS + 3) & ~3;   // 16-byte aligned pieces: W is read four taps at a time
+  float* wl = rsm + rg * WS;                     // this wave's W[c][r][:] ...
+  float* hs = wl + TP;                           // ... and H[b][r][window]
+  // the target element of this lane's frame, fetched now so that its latency hides behind the summation
+  const int lx = l0 + ll;
+  const size_t xidx = a.mode == 1 ? ((size_t)b * L + lx) * a.ld + c : (size_t)c * a.ld + (size_t)b * L + lx;
+  const float xval = (rg == 0 && lx < L) ? a.x[xidx] : 0.f;
   auto rnd = [&](float v) { return a.x3 ? v : bf16_lo(pack_bf16(v, 0.f)); };
   float s = 0.f;
   for (int r0 = 0; r0 < a.R; r0 += 8) {
@@ -524,7 +529,9 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
       for (; t + 16 <= a.T; t += 16) {           // LDS latency, not bandwidth, bounds this loop: 32 reads in flight
         float wv[16], hv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) wv[u] = wl[t + u], hv[u] = hq[-t - u];
+        for (int u = 0; u < 16; u += 4) *reinterpret_cast<float4*>(wv + u) = *reinterpret_cast<const float4*>(wl + t + u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) hv[u] = hq[-t - u];
 #pragma unroll
         for (int u = 0; u < 16; u += 4) {
           p0 = fmaf(wv[u], hv[u], p0), p1 = fmaf(wv[u + 1], hv[u + 1], p1);
@@ -546,9 +553,8 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
     for (int g = 0; g < 8; ++g) S += red[g * 64 + ll];
     const int l = l0 + ll;
     if (l < L) {
-      const int64_t n = (int64_t)b * L + l;
-      const size_t idx = a.mode == 1 ? (size_t)n * a.ld + c : (size_t)c * a.ld + n;
-      const float x = a.x[idx];
+      const size_t idx = xidx;
+      const float x = xval;
       if (a.mode == 2) {
         lv = loss_elem<BETA>(S, x, a.beta);
       } else {
@@ -851,7 +857,7 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
 }
 
 int nmfmu_conv_ragged_supported(int rank, int taps) {
-  return rank > 0 && taps > 0 && (size_t)8 * (2 * (size_t)taps + 63) * sizeof(float) <= 64 * 1024;
+  return rank > 0 && taps > 0 && (size_t)8 * (2 * (size_t)taps + 63 + 8) * sizeof(float) <= 64 * 1024;
 }
 
 int nmfmu_conv_ragged_blocks(int batch, int lh, int taps) { return batch * ((lh + taps - 1 + 63) / 64); }
@@ -874,7 +880,7 @@ int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, con
   RaggedArgs a{w, h, channels, rank, taps, batch, lh, c0, x3, mode, beta, x, ld, (uint16_t*)gn_hi, (uint16_t*)gn_lo,
                (uint16_t*)gp_hi, (uint16_t*)gp_lo, loss_part};
   const dim3 grid(nmfmu_conv_ragged_blocks(batch, lh, taps), channels - c0);
-  const size_t lds = std::max<size_t>((size_t)8 * (2 * (size_t)taps + 63), 512) * sizeof(float);
+  const size_t lds = std::max<size_t>((size_t)8 * (2 * (size_t)taps + 63 + 8), 512) * sizeof(float);
   switch (kind) {
     case kKL: hipLaunchKernelGGL(conv_ragged_rows_kernel<kKL>, grid, dim3(512), lds, S(stream), a); break;
     case kEuc: hipLaunchKernelGGL(conv_ragged_rows_kernel<kEuc>, grid, dim3(512), lds, S(stream), a); break;
