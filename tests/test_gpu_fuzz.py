@@ -73,3 +73,38 @@ def test_random_nmfd_fit_matches_oracle(i, B, C, L, R, T, beta):
     Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, -1e9, 3, kind='nmfd')
     ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
     assert n == nr == 3 and ew < 1e-4 and eh < 1e-4, (B, C, L, R, T, beta, ew, eh)
+
+
+def _conv_cases_long_taps():
+    rng = random.Random(11)
+    out = []
+    for i in range(7):     # (the CPU oracle dominates the run time of these)
+        B = rng.choice([1, 1, 2])
+        C = rng.choice([40, 128, 129, 130, 136, 200, 257, 385])      # 128 k + 1..8 take the ragged-channel path
+        T = rng.choice([128, 130, 136, 200, 400])                    # >= 128 taps: fold from tile diagonal sums, fused sums
+        L = T + rng.choice([40, 200, 333, 600, 2100])               # B L >= 2048 (and even in 64s): split-K numerator
+        R = rng.choice([1, 2, 3, 9])
+        out.append((i, B, C, L, R, T, rng.choice([1, 1, 1, 2, 0.5]), rng.choice(['bf16x3', 'bf16x3', 'bf16'])))
+    return out
+
+
+@pytest.mark.parametrize('i,B,C,L,R,T,beta,prec', _conv_cases_long_taps())
+def test_random_nmfd_long_taps_matches_oracle(i, B, C, L, R, T, beta, prec):
+    """The round-2 NMFD paths through the public ``NMFD.fit``: per-tile diagonal sums instead of the Y matrix, ragged
+    channels off the GEMM tile grid, rank sums fused into their producers, split-K W numerator -- whichever combination
+    the shape selects -- over 12 iterations (one loss evaluation, same stopping decision as the oracle)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMFD
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(900 + i)
+    V = torch.rand(B, C, L, generator=g) + 1e-3
+    W0 = torch.randn(C, R, T, generator=g).abs() + 1e-3
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs() + 1e-3
+    Vp = V.bfloat16().float() if prec == 'bf16' else V
+    m = NMFD(W=W0, H=H0).to(dev)
+    n = m.fit(Vp.to(dev), beta, -1e9, 12, precision=prec)
+    Wr, Hr, nr, losses, _ = O.fit(Vp, W0, H0, beta, -1e9, 12, kind='nmfd')
+    tol = 1e-4 if prec == 'bf16x3' else 3e-2
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    assert n == nr == 12 and ew < tol and eh < tol, (B, C, L, R, T, beta, prec, ew, eh)
+    assert bool(torch.isfinite(m.W.data).all()) and bool(torch.isfinite(m.H.data).all())
