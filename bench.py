@@ -476,7 +476,7 @@ def main():
         # (recording inside the timed region costs ~2 % and folds the dispatch gap in front of each kernel into its
         # span; these spans agree with the rocprofv3 kernel-trace durations)
         if want_roofline:
-            eng.timer = KernelTimer(6 * a.steps + 8)
+            eng.timer = KernelTimer(8 * a.steps + 8)
             ar_ms = []
             for _ in range(a.steps):
                 step()
@@ -484,6 +484,8 @@ def main():
             spans = eng.timer.spans()
             eng.timer.close()
             eng.timer = None
+            if 'h' not in spans and 'h0' in spans:      # sharded path: the H half-step runs as two row halves
+                spans['h'] = [x + y for x, y in zip(spans['h0'], spans['h1'])]
             all_ms = spans.get('w', []) + spans.get('h', [])
             avg_ms = sum(all_ms) / len(all_ms)
             flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
@@ -508,6 +510,8 @@ def main():
                             'algorithmic_bytes_per_launch': int(bytes_per_launch)}}
             if 'ar' in spans:
                 roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
+                roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
+                                          'second half\'s kernel' if 'h0' in spans else 'blocking, after the H half-step kernel')
             out['roofline'] = roof
         return out
 

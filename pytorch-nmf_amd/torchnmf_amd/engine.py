@@ -77,6 +77,11 @@ class HipBackend:
                     'nmfmu_pack_x')
         return xp
 
+    def xp_rows(self, xp, r0, n, k_pad, precision):
+        """Fragment-order X of owner rows [r0, r0 + n) (r0, n multiples of the tile height): row blocks are outermost."""
+        lo = self.lib.nmfmu_xp_bytes(r0, k_pad, precision)
+        return xp[lo:lo + self.lib.nmfmu_xp_bytes(n, k_pad, precision)]
+
     def pack_factor(self, fac: 'FactorBuf', rank, r_pad, precision):
         _capi.check(self.lib.nmfmu_pack_factor(C.byref(fac.struct), rank, r_pad, precision, self.stream()),
                     'nmfmu_pack_factor')
@@ -224,6 +229,41 @@ class StepBuf:
                                  r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2)
 
 
+class _FactorRows:
+    """Rows [r0, r0 + n) of a FactorBuf (n, r0 multiples of 256): same storage, offset pointers."""
+
+    def __init__(self, fac: FactorBuf, r0: int, n: int, r_pad: int):
+        self.f = fac.f[r0:r0 + n]
+        self.rows, self.rank, self.rows_pad = self.f.shape[0], fac.rank, n
+        img = lambda t, per_row: None if t is None else t[r0 * per_row:(r0 + n) * per_row]
+        self.p1_hi, self.p1_lo = img(fac.p1_hi, r_pad * 2), img(fac.p1_lo, r_pad * 2)     # row-major image
+        self.p2_hi, self.p2_lo = img(fac.p2_hi, r_pad * 2), img(fac.p2_lo, r_pad * 2)     # 64-row tiles: 64 | r0
+        self.colsum, self.colsum_part = fac.colsum, fac.colsum_part
+        self.struct = _capi.Factor(_ptr(self.f), _ptr(self.p1_hi), _ptr(self.p1_lo), _ptr(self.p2_hi), _ptr(self.p2_lo),
+                                   _ptr(self.colsum), _ptr(self.colsum_part), self.rows, n)
+
+
+class StepRows:
+    """The partial-sum part of a half-step restricted to owner rows [r0, r0 + n): X, owner images and slabs of that row
+    range, the whole panel.  Lets the sharded H half-step run as two launches so that the first half's all-reduce
+    travels while the second half computes.  (The apply stays whole: it owns the column-sum finalize.)"""
+
+    def __init__(self, st: StepBuf, r0: int, n: int, backend, k_pad: int):
+        s0 = st.struct
+        self.owner, self.panel = _FactorRows(st.owner, r0, n, st.r_pad), st.panel
+        self.xp = backend.xp_rows(st.xp, r0, n, k_pad, s0.precision)
+        dev = st.owner.f.device
+        # its own contraction split: half the row blocks want twice the workgroups per block to fill the chip
+        self.nsplit = max(st.nsplit, backend.choose_nsplit(n, k_pad, st.block_rows, dev))
+        self.r_pad, self.block_rows = st.r_pad, st.block_rows
+        self.r0, self.plane = r0, n * st.r_pad
+        self.slab_num = torch.empty(self.nsplit * self.plane, dtype=torch.float32, device=dev)
+        self.slab_den = None if st.slab_den is None else torch.empty(self.nsplit * self.plane, dtype=torch.float32, device=dev)
+        self.struct = _capi.Step(_ptr(self.xp), self.owner.struct, st.panel.struct, _ptr(self.slab_num), _ptr(self.slab_den),
+                                 s0.rank, s0.r_pad, self.nsplit, s0.precision, s0.stage, s0.block_rows, s0.beta, s0.gamma,
+                                 s0.l1, s0.l2)
+
+
 # Factory of the compute backend.  It is HipBackend in the product; the CPU test-suite swaps in an oracle-backed
 # stand-in (tests/cpu_backend.py) to exercise the host logic (sharding, all-reduce packing, fit loop) without a GPU.
 DEFAULT_BACKEND_FACTORY = HipBackend
@@ -323,6 +363,16 @@ class DenseMU:
             # [numerator | denominator (N x R for beta != 1, else R column sums)] -> ONE all-reduce per iteration
             tail = self.r_pad if self.kl else self.step_h.plane
             self.xbuf = torch.empty(self.step_h.plane + tail, dtype=torch.float32, device=dev)
+            # overlap: the H half-step as two row halves -- the first half's numerators are on the wire while the second
+            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0: one launch, one blocking all-reduce)
+            st = self.step_h
+            r0 = (st.owner.rows_pad // 512) * 256
+            self._h_rows = None
+            if (os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0' and r0 >= 256 and st.owner.rows > r0
+                    and hasattr(self.be, 'xp_rows')):
+                k_pad = st.panel.rows_pad
+                self._h_rows = [StepRows(st, 0, r0, self.be, k_pad),
+                                StepRows(st, r0, st.owner.rows_pad - r0, self.be, k_pad)]
 
     # ------------------------------------------------------------------
     def refresh_images(self):
@@ -403,10 +453,33 @@ class DenseMU:
             self._local_step(st, self.fW.colsum if self.kl else None, 'h')
             return
         self.ensure_colsums()
-        self._partial(st, 'h')
         import torch.distributed as dist
         num = self.xbuf[:st.plane]
         tail = self.xbuf[st.plane:]
+        if self._h_rows is not None:
+            # rows [0, r0): partial sums -> reduced slab -> all-reduce in flight; rows [r0, N): the same, its all-reduce
+            # (with the denominators) is the exposed one
+            v0, v1 = self._h_rows
+            self._partial(v0, 'h0')
+            self.be.slab_reduce(v0, num[:v0.plane], None if self.kl else tail[:v0.plane])
+            w0 = dist.all_reduce(self.xbuf[:v0.plane], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._partial(v1, 'h1')
+            self.be.slab_reduce(v1, num[v0.plane:], None if self.kl else tail[v0.plane:])
+            if self.kl:
+                tail.copy_(self.fW.colsum)
+            if self.timer is not None:
+                self.timer.mark('ar<')
+            w1 = dist.all_reduce(self.xbuf[v0.plane:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w0.wait()
+            w1.wait()
+            if self.timer is not None:
+                self.timer.mark('ar>')
+            if self.kl:
+                self.be.mu_apply(st, num, None, 1, tail)
+            else:
+                self.be.mu_apply(st, num, tail, 1, None)
+            return
+        self._partial(st, 'h')
         if self.kl:
             self.be.slab_reduce(st, num, None)
             tail.copy_(self.fW.colsum)

@@ -43,6 +43,9 @@ class OracleBackend:
             flags[1] = min(int(flags[1]), mn)
         return (V.t() if transpose else V).contiguous().clone()
 
+    def xp_rows(self, xp, r0, n, k_pad, precision):
+        return xp[r0:r0 + n]
+
     def pack_factor(self, fac, rank, r_pad, precision):
         fac.colsum.zero_()
         fac.colsum[:rank] = fac.f.sum(0)

@@ -78,3 +78,62 @@ def test_column_sharded_fit_world2(tmp_path, beta, alpha):
         assert rel_err(p['H'], Hr) < 1e-5
     assert torch.equal(parts[0]['H'], parts[1]['H'])
     assert all(torch.load(tmp_path / f'bad{r}.pt') for r in range(world))
+
+
+def _worker_rows(rank, world, port, beta, overlap, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cpu_backend import OracleBackend
+        from oracle import mu_oracle as O
+        from torchnmf_amd import engine
+        from torchnmf_amd import nmf as anmf
+        from torchnmf_amd.nmf import NMF
+        engine.DEFAULT_BACKEND_FACTORY = OracleBackend
+        anmf._require_device = lambda t_, what: None
+        torch.set_num_threads(1)
+        V, W0, H0 = _tall_problem(beta)
+        s, e = O.shard_bounds(V.shape[1], world)[rank]
+        m = NMF(W=W0[s:e].clone(), H=H0.clone())
+        seen = {}
+        orig = engine.DenseMU.h_step
+
+        def spy(self):
+            seen['rows'] = None if self._h_rows is None else [(v.r0, v.owner.rows, v.owner.rows_pad) for v in self._h_rows]
+            return orig(self)
+        engine.DenseMU.h_step = spy
+        n = m.fit(V[:, s:e].contiguous(), beta, 1e-4, 25, alpha=0.05, l1_ratio=0.5, process_group=dist.group.WORLD)
+        torch.save({'W': m.W.data, 'H': m.H.data, 'n': n, 'rows': seen.get('rows')}, os.path.join(out_dir, f'r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def _tall_problem(beta):
+    g = torch.Generator().manual_seed(77)
+    N, Cc, R = 700, 90, 5          # 700 rows pad to 768: row halves [0, 256) and [256, 768) with 444 valid rows
+    V = torch.rand(N, Cc, generator=g) + (1e-3 if beta <= 0 else 0.0)
+    return V, torch.randn(Cc, R, generator=g).abs() + 1e-3, torch.randn(N, R, generator=g).abs() + 1e-3
+
+
+@pytest.mark.parametrize('beta', [1, 2])
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_sharded_h_step_in_row_halves_world2(tmp_path, beta, overlap):
+    """The overlapped form of the sharded H half-step: two row halves, the first half's numerators all-reduced
+    (async) while the second half is computed, the denominators with the second; one apply.  Must give what the
+    single-launch form gives and what the unsharded oracle gives."""
+    from oracle import mu_oracle as O
+    world = 2
+    mp.spawn(_worker_rows, args=(world, _free_port(), beta, overlap, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    V, W0, H0 = _tall_problem(beta)
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 25, 0.05, 0.5)
+    for p in parts:
+        assert p['rows'] == ([(0, 256, 256), (256, 444, 512)] if overlap == '1' else None)
+        assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
+    assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5
+    assert torch.equal(parts[0]['H'], parts[1]['H'])

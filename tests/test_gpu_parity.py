@@ -805,16 +805,36 @@ def test_sharded_path_world1_rccl(dev):
         Vb = torch.rand(700, 2100, generator=gg).bfloat16().float().to(dev)
         Wb, Hb = torch.randn(2100, 100, generator=gg).abs(), torch.randn(700, 100, generator=gg).abs()
         res = []
-        for grp in (None, dist.group.WORLD):
+        for grp, overlap in ((None, '1'), (dist.group.WORLD, '1'), (dist.group.WORLD, '0')):
+            os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
             W, H = Wb.clone().to(dev), Hb.clone().to(dev)
             eng = DenseMU(Vb, W, H, 1.0, precision='bf16', group=grp)
+            if grp is not None:     # 700 rows pad to 768: the overlapped form runs rows [0, 256) and [256, 768) separately
+                assert (eng._h_rows is not None) == (overlap == '1')
+                if overlap == '1':
+                    assert [(v.r0, v.owner.rows, v.owner.rows_pad) for v in eng._h_rows] == [(0, 256, 256), (256, 444, 512)]
             for _ in range(3):
                 eng.w_step()
                 eng.h_step()
             res.append((W.cpu(), H.cpu(), eng.divergence()))
-        # (the two paths sum the column sums in different orders; a 1e-7 difference flips a few bf16 roundings)
-        assert rel_err(res[1][0], res[0][0]) < 1e-4 and rel_err(res[1][1], res[0][1]) < 1e-4
-        assert res[1][2] == pytest.approx(res[0][2], rel=1e-5)
+        # (the paths sum the column sums in different orders; a 1e-7 difference flips a few bf16 roundings)
+        for r in res[1:]:
+            assert rel_err(r[0], res[0][0]) < 1e-4 and rel_err(r[1], res[0][1]) < 1e-4
+            assert r[2] == pytest.approx(res[0][2], rel=1e-5)
+        # the same row halves with numerator AND denominator slabs (beta = 2), fp32-grade mode, against the oracle
+        os.environ['TORCHNMF_AMD_AR_OVERLAP'] = '1'
+        Vc, Wc, Hc = Vb.cpu()[:, :500], Wb[:500, :24], Hb[:, :24]
+        W, H = Wc.clone().to(dev), Hc.clone().to(dev)
+        eng = DenseMU(Vc.to(dev).contiguous(), W, H, 2.0, 0.05, 0.05, precision='bf16x3', group=dist.group.WORLD)
+        assert eng._h_rows is not None
+        for _ in range(3):
+            eng.w_step()
+            eng.h_step()
+        Wr, Hr = Wc, Hc
+        for _ in range(3):
+            Wr = O.nmf_w_step(Vc, Wr, Hr, 2, 1.0, 0.05, 0.05)
+            Hr = O.nmf_h_step(Vc, Wr, Hr, 2, 1.0, 0.05, 0.05)
+        assert rel_err(W.cpu(), Wr) < TOL and rel_err(H.cpu(), Hr) < TOL
     finally:
         dist.destroy_process_group()
 
