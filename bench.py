@@ -173,6 +173,26 @@ def main_nmfd(a):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
     flops = (4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T
+    # second timed leg in the parity-grade mode (split bf16, 3 MFMAs per product) so that the line carries both
+    pm = None
+    if a.precision not in ('bf16x3', 'f16') and not a.no_parity_mode and a.workload == 'nmfd':
+        # the parity-grade mode fit() picks by itself: fp16 operands where built (beta == 1, >= 128 taps), else split bf16
+        pprec = 'f16' if (beta == 1 and T >= 128 and T % 8 == 0 and L % 8 == 0) else 'bf16x3'
+        Wp, Hp = W.clone(), H.clone()
+        e3 = ConvMU(V, Wp, Hp, beta, precision=pprec)
+        for _ in range(max(3, a.warmup // 2)):
+            e3.w_step(); e3.h_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            e3.w_step(); e3.h_step()
+        torch.cuda.synchronize()
+        ms3 = 1e3 * (time.perf_counter() - t0) / a.steps
+        pm = {'precision': pprec, 'dtype': 'f16 operands / fp32 accumulate (same MFMA rate as bf16)' if pprec == 'f16'
+              else 'bf16x3 (split bf16, fp32-grade: 3 MFMAs per product)',
+              'iters_per_s': round(1e3 / ms3, 2), 'ms_per_step': round(ms3, 4),
+              'value': round((4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T / (ms3 * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s'}
+        del e3
     # the dominant kernel (nt_gemm) timed live: 4 launches per iteration, each 2*C*L*R*T algorithmic flops.  Timed as the
     # iteration runs it: the reconstruction of the W half-step (GEMM over the channels that fill whole 128-row tiles +
     # the ragged-channel kernel when C = 128 k + 1..8)
@@ -186,14 +206,31 @@ def main_nmfd(a):
     ach = 2.0 * Cc * L * R * T / (gemm_ms * 1e-3) / 1e12
     peak = MFMA_BF16_PEAK_TFLOPS
     cpu = None
+    parity = None
     if a.cpu_iters > 0:
         from oracle import aten_port
         torch.set_flush_denormal(True)
         cores, tried = pick_threads(lambda: aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1))
         aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1)
         t0 = time.perf_counter()
-        aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, a.cpu_iters)
+        Wr, Hr = aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, a.cpu_iters)
         dt = (time.perf_counter() - t0) / a.cpu_iters
+        # in-run parity: the same k iterations on the GPU from the same V, W0, H0, per precision mode
+        def rel(x, y):
+            return float((x.double() - y.double()).norm() / y.double().norm())
+        modes = {}
+        for prec in dict.fromkeys([a.precision] + (['f16'] if a.workload == 'nmfd' and beta == 1 and T >= 128 else []) + ['bf16x3']):
+            Wg, Hg = Wc.clone().to(dev), Hc.clone().to(dev)
+            e2 = ConvMU(V, Wg, Hg, beta, precision=prec)
+            for _ in range(a.cpu_iters):
+                e2.w_step()
+                e2.h_step()
+            torch.cuda.synchronize()
+            rw, rh = rel(Wg.cpu(), Wr), rel(Hg.cpu(), Hr)
+            modes[prec] = {'rel_W': float(f'{rw:.4g}'), 'rel_H': float(f'{rh:.4g}'), 'meets_1e-4': bool(max(rw, rh) < 1e-4)}
+            del e2
+        parity = {'k': a.cpu_iters, 'reference': 'oracle/aten_port.py (fp32, same V, W0, H0), the timed CPU iterations',
+                  'bar': 1e-4, 'modes': modes}
         cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
                f'workload, fp32, F.conv{2 if a.workload == "nmf2d" else 1}d + two backward passes (oracle/aten_port.py)'}
@@ -212,7 +249,7 @@ def main_nmfd(a):
                      'avg_launch_ms': round(gemm_ms, 5),
                      'note': 'bf16x3 issues 3 MFMAs per algorithmic product: hardware MFMA rate is 3x achieved'
                      if a.precision == 'bf16x3' else ''},
-        'cpu_baseline': cpu}))
+        'cpu_baseline': cpu, 'parity': parity, 'parity_mode': pm}))
 
 
 def main_sparse(a):

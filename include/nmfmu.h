@@ -274,6 +274,12 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
 int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops);
+/* NMFMU_PREC_F16 in the GEMM engine: fp16 operand planes / window tables (nmfmu_conv_tables_f16,
+ * nmfmu_conv_apply_pack_w_sums with precision F16) and fp16 ratio planes, one plane each, same MFMA rate as bf16 with
+ * 11 significant bits; ratios saturate at 65504.  Built for the combinations of the beta == 1 NMFD iteration on implicit
+ * operands: RATIO with B or A = Hu, LOSS with B = Hu, F32 with B = HuT, FOLD (else NMFMU_ERR_UNSUPPORTED). */
+int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops);
+int nmfmu_conv_tables_f16(const float* h, int batch, int rank, int lh, int taps, void* rev, void* fwd, void* stream);
 
 /* Ragged channels of the NMFD reconstruction (RATIO / LOSS epilogues with A or B = Wm): channels c0 .. channels-1 by
  * direct summation S[c][(b,l)] = sum_{r,t} w[c][r][t] h[b][r][l-t] from the fp32 masters, so that the GEMM only has to
@@ -281,7 +287,7 @@ int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int op
  * spectrogram with 2^k + 1 bins otherwise pays a whole 128-row tile row for one channel.
  *   mode 0: ratio planes gn (gp) [c][ld]   (W half-step)      mode 1: [(b,l)][ld]   (H half-step)
  *   mode 2: beta_div partials, loss_part[nmfmu_conv_ragged_blocks() * (channels - c0)]
- * x has the layout of the outputs.  BF16 / BF16X3. */
+ * x has the layout of the outputs.  BF16 / BF16X3 / F16. */
 int nmfmu_conv_ragged_supported(int rank, int taps);
 int nmfmu_conv_ragged_blocks(int batch, int lh, int taps);
 int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, const float* h, int batch, int lh, int c0,
@@ -330,8 +336,8 @@ int nmfmu_conv_fold_apply_h(float* h, int batch, int rank, int lh, int taps, con
  *                                    leaves hsum_part[rank][nmfmu_fold_hsum_parts(batch, lh)] partial sums of the new H. */
 int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
                                  const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
-                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi,
-                                 void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
+                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, int precision,
+                                 void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
 int nmfmu_fold_hsum_parts(int batch, int lh);
 int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,
                                        const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,

@@ -10,10 +10,6 @@
 
 namespace nmfmu {
 
-__device__ __forceinline__ uint32_t pack_img(float a, float b, int f16) {
-  return f16 ? pack_f16(fminf(a, 65504.f), fminf(b, 65504.f)) : pack_bf16(a, b);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // pack_x: V fp32 (row-major, ld) -> fragment-order X (bf16 or fp32), zero padded.  One thread = one 16-byte chunk.
 // Fused with the validation passes of nmf.py:329-336 (any(v < 0 or NaN), min(v)).

@@ -161,6 +161,46 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 
+// ---- operand element type of the single-plane kernels (nmfmu_pp.h, nmfmu_gemm.h): bf16, or fp16 (11 significant bits
+// at the same MFMA rate; values clamped to 65504 when packed, conversions saturate under MODE.FP16_OVFL)
+enum OperandType : int { kOpBf16 = 0, kOpF16 = 1 };
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+template <int OPT>
+__device__ __forceinline__ f32x16 mfma_op(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (OPT == kOpF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return mfma_bf16(a, b, c);
+}
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 r = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE; saturates under MODE.FP16_OVFL)
+  return __builtin_bit_cast(uint32_t, r);
+}
+template <int OPT>
+__device__ __forceinline__ uint32_t pack_op(float a, float b) {
+  if constexpr (OPT == kOpF16) return pack_f16(a, b);
+  else return pack_bf16(a, b);
+}
+template <int OPT>
+__device__ __forceinline__ float unpack_lo(uint32_t w) {
+  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[0];
+  else return bf16_lo(w);
+}
+template <int OPT>
+__device__ __forceinline__ float unpack_hi(uint32_t w) {
+  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[1];
+  else return bf16_hi(w);
+}
+
+__device__ __forceinline__ uint32_t pack_img(float a, float b, int f16) {
+  return f16 ? pack_f16(fminf(a, 65504.f), fminf(b, 65504.f)) : pack_bf16(a, b);
+}
+
 // nmf.py:61-74: the two "grad_output" tensors, per element.  `s` already
 // contains +eps (the S accumulator is initialised with eps) except for
 // beta == 2, where the reference adds none.

@@ -79,9 +79,12 @@ struct GemmCfg {
   static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
 };
 
-template <bool X3, int EPI, int BETA, int OPS, class SH>
+template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT>
 __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
   using C = GemmCfg<X3, SH>;
+  static_assert(!(X3 && OPT == kOpF16), "fp16 operands are single-plane");
+  // fp16: the ratio planes are converted with saturation (a ratio above 65504 becomes 65504, not inf)
+  if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
   constexpr int MI = SH::MI, NI = SH::NI, THREADS = SH::THREADS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
             acc[mi][ni] = mfma_bf16(al[fb][mi], bh[fb][ni], acc[mi][ni]);
             acc[mi][ni] = mfma_bf16(ah[fb][mi], bl[fb][ni], acc[mi][ni]);
           }
-          acc[mi][ni] = mfma_bf16(ah[fb][mi], bh[fb][ni], acc[mi][ni]);
+          acc[mi][ni] = mfma_op<OPT>(ah[fb][mi], bh[fb][ni], acc[mi][ni]);
         }
     }
     {
@@ -352,11 +355,11 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
           const float x = a.x[idx];
           float gn, gp;
           mu_elem<BETA>(s, x, a.beta, gn, gp);
-          const uint32_t nh = pack_bf16(gn, 0.f);
+          const uint32_t nh = pack_op<OPT>(gn, 0.f);
           a.gn_hi[idx] = (uint16_t)nh;
           if constexpr (X3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
           if constexpr (BETA != kKL) {
-            const uint32_t ph = pack_bf16(gp, 0.f);
+            const uint32_t ph = pack_op<OPT>(gp, 0.f);
             a.gp_hi[idx] = (uint16_t)ph;
             if constexpr (X3) a.gp_lo[idx] = (uint16_t)pack_bf16(gp - bf16_lo(ph), 0.f);
           }
@@ -378,14 +381,14 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   }
 }
 
-template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3, SH>;
   constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
   constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES;
   static_assert(kLds <= 160 * 1024, "LDS budget");
   if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -400,6 +403,7 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
 }
 
 // big != 0: the 256 x 256 tile (bf16 single plane, beta == 1 ratio / loss, F32, FOLD); -2 when that variant is not built
-int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, const GemmArgs& a, hipStream_t s);
+// f16 != 0: fp16 operand planes / window tables and fp16 ratio planes (single plane; the beta == 1 NMFD path)
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, int f16, const GemmArgs& a, hipStream_t s);
 
 }  // namespace nmfmu

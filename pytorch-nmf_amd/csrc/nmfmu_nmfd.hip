@@ -16,7 +16,18 @@
 
 namespace nmfmu {
 
-int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, const GemmArgs& a, hipStream_t s) {
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, int f16, const GemmArgs& a, hipStream_t s) {
+  if (f16) {
+    // fp16 operands: the combinations of the beta == 1 NMFD iteration on implicit operands (nmfd_engine.py, precision 'f16')
+    if (x3 || big) return -2;
+#define GF16(E, B, O) \
+  if (epi == E && (E == kEpiF32 || E == kEpiFold || beta_kind == B) && ops == O) \
+    return launch_gemm_one<false, E, B, O, GemmSmall, kOpF16>(a, s);
+    GF16(kEpiRatio, kKL, kOpsBHu) GF16(kEpiRatio, kKL, kOpsAHu) GF16(kEpiLoss, kKL, kOpsBHu)
+    GF16(kEpiF32, kEuc, kOpsBHuT) GF16(kEpiFold, kEuc, kOpsPlanes)
+#undef GF16
+    return -2;
+  }
   if (big) {
     // 256 x 256 tiles: the combinations NMFD.fit uses at beta == 1 in the single-plane mode (nmfd_engine.py)
     if (x3) return -2;
@@ -112,7 +123,8 @@ __global__ void __launch_bounds__(256) pack2d_kernel(Pack2D p, float* dst_f32, u
 // (nmfmu_conv_tables).  One thread per chunk; the tables are ~8x H (2 MB at BASELINE configs[3]) where the explicit
 // Hu / HuT matrices are T x H each (2 x 52 MB written and 3 x 52 MB read per iteration).
 __global__ void __launch_bounds__(256) conv_tables_kernel(const float* __restrict__ H, int B, int R, int Lh, int T,
-                                                          u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo) {
+                                                          u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo,
+                                                          int f16) {
   const int JJ = Lh + 2 * T - 2;
   const int64_t n = 1 + (int64_t)B * R * JJ;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -133,9 +145,9 @@ __global__ void __launch_bounds__(256) conv_tables_kernel(const float* __restric
     u32x4 rh, rl, fh, fl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      uint32_t h = pack_bf16(vr[2 * e], vr[2 * e + 1]);
+      uint32_t h = pack_img(vr[2 * e], vr[2 * e + 1], f16);
       rh[e] = h, rl[e] = pack_bf16(vr[2 * e] - bf16_lo(h), vr[2 * e + 1] - bf16_hi(h));
-      h = pack_bf16(vf[2 * e], vf[2 * e + 1]);
+      h = pack_img(vf[2 * e], vf[2 * e + 1], f16);
       fh[e] = h, fl[e] = pack_bf16(vf[2 * e] - bf16_lo(h), vf[2 * e + 1] - bf16_hi(h));
     }
     rev_hi[i] = rh, fwd_hi[i] = fh;
@@ -273,7 +285,7 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
                                                                 uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
                                                                 uint16_t* wmt_lo, const float* __restrict__ scale,
                                                                 const float* __restrict__ kl_hpart, int n_hparts,
-                                                                float* __restrict__ wcol, int num_slabs) {
+                                                                float* __restrict__ wcol, int num_slabs, int f16) {
   constexpr int LDT = 65;
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
@@ -343,7 +355,7 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
     for (int e = 0; e < 4; ++e) {
       const float x0 = tr ? tile[(ch + 2 * e) * LDT + row] : tile[row * LDT + ch + 2 * e];
       const float x1 = tr ? tile[(ch + 2 * e + 1) * LDT + row] : tile[row * LDT + ch + 2 * e + 1];
-      const uint32_t h = pack_bf16(x0, x1);
+      const uint32_t h = pack_img(x0, x1, f16);
       hi[e] = h;
       lo[e] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
     }
@@ -470,7 +482,7 @@ __global__ void __launch_bounds__(256) conv_fold_apply_h_kernel(float* __restric
 struct RaggedArgs {
   const float* w;   // (C, R, T)
   const float* h;   // (B, R, Lh)
-  int C, R, T, B, Lh, c0, x3, mode;
+  int C, R, T, B, Lh, c0, x3, mode, f16;
   float beta;
   const float* x;   // mode 0 / 2: [c][ld], mode 1: [(b,l)][ld]
   int64_t ld;
@@ -493,7 +505,9 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
   const int lx = l0 + ll;
   const size_t xidx = a.mode == 1 ? ((size_t)b * L + lx) * a.ld + c : (size_t)c * a.ld + (size_t)b * L + lx;
   const float xval = (rg == 0 && lx < L) ? a.x[xidx] : 0.f;
-  auto rnd = [&](float v) { return a.x3 ? v : bf16_lo(pack_bf16(v, 0.f)); };
+  auto rnd = [&](float v) {     // what the GEMM's operand planes hold
+    return a.x3 ? v : a.f16 ? unpack_lo<kOpF16>(pack_img(v, 0.f, 1)) : bf16_lo(pack_bf16(v, 0.f));
+  };
   float s = 0.f;
   for (int r0 = 0; r0 < a.R; r0 += 8) {
     const int r = r0 + rg;
@@ -560,7 +574,7 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
       } else {
         float gn, gp;
         mu_elem<BETA>(S, x, a.beta, gn, gp);
-        const uint32_t nh = pack_bf16(gn, 0.f);
+        const uint32_t nh = pack_img(gn, 0.f, a.f16);
         a.gn_hi[idx] = (uint16_t)nh;
         if (a.x3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
         if constexpr (BETA != kKL) {
@@ -673,6 +687,17 @@ inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64
 
 extern "C" {
 
+int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops) {
+  const int kl = nmfmu_beta_kind(beta) == NMFMU_BETA_KL;
+  switch (epilogue) {
+    case NMFMU_EPI_RATIO: return kl && (ops == NMFMU_OPS_B_HU || ops == NMFMU_OPS_A_HU);
+    case NMFMU_EPI_LOSS: return kl && ops == NMFMU_OPS_B_HU;
+    case NMFMU_EPI_F32: return ops == NMFMU_OPS_B_HUT;
+    case NMFMU_EPI_FOLD: return ops == NMFMU_OPS_PLANES;
+    default: return 0;
+  }
+}
+
 int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops) {
   if (precision != NMFMU_PREC_BF16) return 0;
   const int kl = nmfmu_beta_kind(beta) == NMFMU_BETA_KL;
@@ -689,7 +714,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
   if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % 128 || d->k_pad % 128)
     return NMFMU_ERR_ARG;
-  const int x3 = d->precision == NMFMU_PREC_BF16X3;
+  const int x3 = d->precision == NMFMU_PREC_BF16X3, f16 = d->precision == NMFMU_PREC_F16;
   if (x3 && (!d->a_lo || !d->b_lo)) return NMFMU_ERR_ARG;
   const int kind = nmfmu_beta_kind(d->beta);
   GemmArgs a{};
@@ -738,7 +763,8 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   }
   a.ldn = d->n_ld ? d->n_ld : d->n_pad;
   if (a.ldn < d->n_pad || (a.ldn != d->n_pad && epilogue == NMFMU_EPI_FOLD)) return NMFMU_ERR_ARG;
-  return launch_gemm(x3, epilogue, kind, d->ops, big, a, S(stream));
+  const int rc = launch_gemm(x3, epilogue, kind, d->ops, big, f16, a, S(stream));
+  return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 
 int nmfmu_pack2d(const float* src, int rows, int cols, int row_inner, int64_t row_outer_stride, int64_t row_inner_stride,
@@ -782,7 +808,15 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
   if (taps % 8 || (lh + taps - 1) % 8 || (rev_lo == nullptr) != (fwd_lo == nullptr)) return NMFMU_ERR_ARG;
   const int64_t n = 1 + (int64_t)batch * rank * (lh + 2 * taps - 2);
   hipLaunchKernelGGL(conv_tables_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
-                     (u32x4*)rev_hi, (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo);
+                     (u32x4*)rev_hi, (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo, 0);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_tables_f16(const float* h, int batch, int rank, int lh, int taps, void* rev, void* fwd, void* stream) {
+  if (!h || !rev || !fwd || batch <= 0 || rank <= 0 || lh <= 0 || taps <= 0 || taps % 8 || (lh + taps - 1) % 8) return NMFMU_ERR_ARG;
+  const int64_t n = 1 + (int64_t)batch * rank * (lh + 2 * taps - 2);
+  hipLaunchKernelGGL(conv_tables_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                     (u32x4*)rev, nullptr, (u32x4*)fwd, nullptr, 1);
   return (int)hipGetLastError();
 }
 
@@ -806,21 +840,23 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
 static int conv_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                        const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
                        void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream,
-                       const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr, int num_slabs = 1) {
+                       const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr, int num_slabs = 1,
+                       int f16 = 0) {
   if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
   if (update && (!num || (!den && !kl_den && !kl_hpart))) return NMFMU_ERR_ARG;
   if ((kl_hpart && n_hparts <= 0) || (wcol && scale) || ((kl_hpart || wcol) && taps < 64)) return NMFMU_ERR_ARG;
   if (c_pad < channels || rp_pad < (int64_t)rank * taps || c_pad % 64 || rp_pad % 64 || (wm_lo == nullptr) != (wmt_lo == nullptr))
     return NMFMU_ERR_ARG;
+  if (f16 && wm_lo) return NMFMU_ERR_ARG;
   const dim3 grid(rp_pad / 64, c_pad / 64);
   if (wm_lo)
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
-                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol, num_slabs);
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol, num_slabs, 0);
   else
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
-                       nullptr, scale, kl_hpart, n_hparts, wcol, num_slabs);
+                       nullptr, scale, kl_hpart, n_hparts, wcol, num_slabs, f16);
   return (int)hipGetLastError();
 }
 
@@ -833,11 +869,13 @@ int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const fl
 
 int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, const float* num, const float* den,
                                  const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
-                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, void* wm_hi,
-                                 void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
+                                 int c_pad, int rp_pad, float l1, float l2, float gamma, int update, int precision,
+                                 void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
   if (num_slabs < 1 || num_slabs > 8) return NMFMU_ERR_ARG;
+  if (precision != NMFMU_PREC_BF16 && precision != NMFMU_PREC_BF16X3 && precision != NMFMU_PREC_F16) return NMFMU_ERR_ARG;
+  if ((precision == NMFMU_PREC_BF16X3) != (wm_lo != nullptr)) return NMFMU_ERR_ARG;
   return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
-                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol, num_slabs);
+                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol, num_slabs, precision == NMFMU_PREC_F16);
 }
 
 int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,
@@ -868,8 +906,8 @@ int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, con
   if (!w || !h || !x || channels <= 0 || batch <= 0 || lh <= 0 || c0 < 0 || c0 >= channels || mode < 0 || mode > 2)
     return NMFMU_ERR_ARG;
   if (!nmfmu_conv_ragged_supported(rank, taps)) return NMFMU_ERR_UNSUPPORTED;
-  const int x3 = precision == NMFMU_PREC_BF16X3;
-  if (precision != NMFMU_PREC_BF16 && !x3) return NMFMU_ERR_UNSUPPORTED;
+  const int x3 = precision == NMFMU_PREC_BF16X3, f16 = precision == NMFMU_PREC_F16;
+  if (precision != NMFMU_PREC_BF16 && !x3 && !f16) return NMFMU_ERR_UNSUPPORTED;
   const int kind = nmfmu_beta_kind(beta);
   if (mode == 2) {
     if (!loss_part) return NMFMU_ERR_ARG;
@@ -877,7 +915,7 @@ int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, con
     if (!gn_hi || (x3 && !gn_lo)) return NMFMU_ERR_ARG;
     if (kind != NMFMU_BETA_KL && (!gp_hi || (x3 && !gp_lo))) return NMFMU_ERR_ARG;
   }
-  RaggedArgs a{w, h, channels, rank, taps, batch, lh, c0, x3, mode, beta, x, ld, (uint16_t*)gn_hi, (uint16_t*)gn_lo,
+  RaggedArgs a{w, h, channels, rank, taps, batch, lh, c0, x3, mode, f16, beta, x, ld, (uint16_t*)gn_hi, (uint16_t*)gn_lo,
                (uint16_t*)gp_hi, (uint16_t*)gp_lo, loss_part};
   const dim3 grid(nmfmu_conv_ragged_blocks(batch, lh, taps), channels - c0);
   const size_t lds = std::max<size_t>((size_t)8 * (2 * (size_t)taps + 63 + 8), 512) * sizeof(float);

@@ -41,40 +41,6 @@
 
 namespace nmfmu {
 
-enum OperandType : int { kOpBf16 = 0, kOpF16 = 1 };
-
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-
-template <int OPT>
-__device__ __forceinline__ f32x16 mfma_op(u32x4 a, u32x4 b, f32x16 c) {
-  if constexpr (OPT == kOpF16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return mfma_bf16(a, b, c);
-}
-
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  f32x2 v = {a, b};
-  f16x2 r = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE; saturates under MODE.FP16_OVFL)
-  return __builtin_bit_cast(uint32_t, r);
-}
-template <int OPT>
-__device__ __forceinline__ uint32_t pack_op(float a, float b) {
-  if constexpr (OPT == kOpF16) return pack_f16(a, b);
-  else return pack_bf16(a, b);
-}
-template <int OPT>
-__device__ __forceinline__ float unpack_lo(uint32_t w) {
-  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[0];
-  else return bf16_lo(w);
-}
-template <int OPT>
-__device__ __forceinline__ float unpack_hi(uint32_t w) {
-  if constexpr (OPT == kOpF16) return (float)__builtin_bit_cast(f16x2, w)[1];
-  else return bf16_hi(w);
-}
-
 // VAR bits (build-time experiment switches, selected per launch through FusedArgs-independent dispatch):
 //   1: s_setprio 1 for the matrix segments      2: static s_setprio 1 for the younger half (waves 4-7)
 //   4: LDS-DMA issued after the elementwise work instead of before it

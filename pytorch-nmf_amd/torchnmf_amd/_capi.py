@@ -138,6 +138,8 @@ SIGNATURES = {
     'nmfmu_conv_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_gemm_tile256_supported': (C.c_int, [C.c_int, C.c_float, C.c_int, C.c_int]),
+    'nmfmu_gemm_f16_supported': (C.c_int, [C.c_float, C.c_int, C.c_int]),
+    'nmfmu_conv_tables_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_ragged_supported': (C.c_int, [C.c_int, C.c_int]),
     'nmfmu_conv_ragged_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_ragged_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -145,7 +147,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_apply_pack_w_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
-                                               C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
     'nmfmu_fold_hsum_parts': (C.c_int, [C.c_int, C.c_int]),
     'nmfmu_conv_fold_parts_apply_h_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

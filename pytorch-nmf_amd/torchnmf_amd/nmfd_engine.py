@@ -54,6 +54,10 @@ class _Table:
 class ConvMU:
     """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
 
+    F16_MIN_DIM = 1024       # 'auto' -> 'f16' from this size on (every contraction at least this long)
+    F16_MAX_ABS = 3.0e4      # ... and only when V, W, H fit fp16's range with headroom
+    F16_MIN_MEAN = 2.0 ** -10
+
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True, own_loop=True):
         # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM) needs the plain Y buffer
         self.lib = _capi.load()
@@ -74,10 +78,28 @@ class ConvMU:
         self._t_arr = (C.c_int32 * nd)(*self.ts)
         for t_ in (W, H):
             assert t_.dtype == torch.float32 and t_.is_contiguous()
+        # 'f16' (fp16 operand planes, window tables and ratio planes: 11 significant bits at the bf16 MFMA rate) exists
+        # for the beta == 1 iteration on implicit operands with >= 128 taps (the fold-parts / fused-sums path): that is
+        # where NMFD is large enough for throughput to matter and for the rounding errors to average down (DESIGN.md
+        # section 4).  'auto' takes it there when the data fit fp16's range, the fp32-grade split mode otherwise.
+        f16_ok = (own_loop and nd == 1 and float(beta) == 1.0 and T % 8 == 0 and L % 8 == 0 and T >= 128 and
+                  os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1' and
+                  os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0' and
+                  os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0' and
+                  os.environ.get('TORCHNMF_AMD_NMFD_TILE', '128') == '128')
         if precision in (None, 'auto'):
             precision = 'bf16x3'
+            if (f16_ok and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0' and min(Cc, B * L) >= self.F16_MIN_DIM
+                    and R * T >= self.F16_MIN_DIM):
+                stats = torch.stack([V.abs().max(), W.abs().max(), H.abs().max(), V.abs().mean(), W.abs().mean(),
+                                     H.abs().mean()]).tolist()          # one host sync at engine set-up
+                if max(stats[:3]) <= self.F16_MAX_ABS and min(stats[3:]) >= self.F16_MIN_MEAN:
+                    precision = 'f16'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
+        if precision == 'f16' and not f16_ok:
+            raise ValueError("precision 'f16' is built for NMFD with beta == 1, taps >= 128 and taps / frames that are "
+                             "multiples of 8 (implicit Toeplitz operands); use 'bf16x3' or 'bf16'")
         self.precision_name = precision
         self.precision = _capi.PRECISIONS[precision]
         x3 = self.precision == _capi.PREC_BF16X3
@@ -221,7 +243,8 @@ class ConvMU:
                 self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None, None,
                 self.sum_h.data_ptr() if (kl and not self._h_parts_valid) else None,
                 self.hpart.data_ptr() if (kl and self._h_parts_valid) else None, self.n_hparts, self.wcol.data_ptr(),
-                self.w_ksplit, self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
+                self.w_ksplit, self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), self.precision, _ptr(self.wm.hi),
+                _ptr(self.wm.lo),
                 _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w_sums')
             return
         _capi.check(self.lib.nmfmu_conv_apply_pack_w(
@@ -233,9 +256,14 @@ class ConvMU:
 
     def _pack_h(self, sums: bool = True):
         if self.implicit:
-            _capi.check(self.lib.nmfmu_conv_tables(self.H.data_ptr(), self.B, self.R, self.Lh, self.T, _ptr(self.hu.hi),
-                                                   _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), _stream()),
-                        'nmfmu_conv_tables')
+            if self.precision == _capi.PREC_F16:
+                _capi.check(self.lib.nmfmu_conv_tables_f16(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
+                                                           _ptr(self.hu.hi), _ptr(self.hut.hi), _stream()),
+                            'nmfmu_conv_tables_f16')
+            else:
+                _capi.check(self.lib.nmfmu_conv_tables(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
+                                                       _ptr(self.hu.hi), _ptr(self.hu.lo), _ptr(self.hut.hi),
+                                                       _ptr(self.hut.lo), _stream()), 'nmfmu_conv_tables')
         else:
             self._unfold()
         if sums:

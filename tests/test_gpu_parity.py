@@ -737,6 +737,46 @@ def test_nmfd_w_numerator_split_k(dev, shape, prec, monkeypatch):
         assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
 
 
+@pytest.mark.parametrize('shape', [(1, 257, 1096, 4, 136), (2, 130, 640, 3, 128), (1, 64, 2200, 2, 400)])
+def test_nmfd_f16_mode(dev, shape):
+    """precision='f16' of the NMFD engine (fp16 operand planes, window tables and ratio planes; beta == 1, >= 128 taps,
+    implicit operands): three iterations against the fp32 oracle -- one rounding to 11 significant bits per operand, so
+    an order of magnitude closer than the bf16 single-plane mode -- through the ragged-channel, fold-parts, fused-sums and
+    split-K paths; exact zeros stay exact; unsupported configurations refuse loudly; 'auto' only picks it when the
+    problem is large."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    W0[3] = 0.0                                   # a silent channel template stays exactly zero
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 3, kind='nmfd')
+    err = {}
+    for prec in ('f16', 'bf16'):
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, 1, precision=prec)
+        assert eng.precision_name == prec and eng.fused_sums
+        l0 = eng.divergence()
+        for _ in range(3):
+            eng.w_step()
+            eng.h_step()
+        err[prec] = (rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr))
+        assert bool(torch.isfinite(W).all()) and bool(torch.isfinite(H).all())
+        assert float(W[3].abs().max()) == 0.0
+        assert l0 == pytest.approx(float(O.beta_div(O.nmfd_reconstruct(H0, W0), V, 1)), rel=2e-3 if prec == 'bf16' else 3e-4)
+    print(f'nmfd f16 {shape}: f16 relW={err["f16"][0]:.2e} relH={err["f16"][1]:.2e}; bf16 relW={err["bf16"][0]:.2e}')
+    assert max(err['f16']) < 6e-4 and max(err['f16']) < 0.4 * max(err['bf16'])
+    with pytest.raises(ValueError):               # fewer than 128 taps / beta != 1: not built
+        ConvMU(V[:, :, :256].to(dev).contiguous(), W0[:, :, :16].clone().to(dev).contiguous(),
+               torch.rand(B, R, 241).to(dev), 1, precision='f16')
+    with pytest.raises(ValueError):
+        ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 2, precision='f16')
+    small = ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 1, precision='auto')
+    assert small.precision_name == ('f16' if min(Cc, B * L, R * T) >= 1024 else 'bf16x3')
+
+
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_nmf2d_nmf3d_fit_g8_golden(dev, name, cls, beta):
@@ -1353,7 +1393,7 @@ def test_nmfd_cfg4_full_size(dev):
     H0 = torch.randn(1, R, L - T + 1, generator=g).abs()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     Wr, Hr = aten_port.mu_iterations_nmfd(V, W0, H0, 1, 2)
-    for prec, tol in (('bf16x3', 1e-4), ('bf16', 2e-2)):
+    for prec, tol in (('bf16x3', 1e-4), ('bf16', 2e-2), ('f16', 1e-4), ('auto', 1e-4)):
         m = NMFD(W=W0, H=H0).to(dev)
         n = m.fit(V.to(dev), 1, NO_STOP, 2, precision=prec)
         assert n == 2
