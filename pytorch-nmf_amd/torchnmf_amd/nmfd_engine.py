@@ -228,7 +228,7 @@ class ConvMU:
     def _rank_sums(self, src, outer, inner, out):
         """beta == 1 denominators (nmf.py:122-131): sum over everything but the rank axis.  (Running these two small
         kernels on a side stream beside the next GEMM was measured: no gain -- the event fork / join costs what the
-        overlap saves.)"""
+        overlap saves; the same holds for the ragged-channel kernel beside its reconstruction GEMM.)"""
         if self.kl:
             _capi.check(self.lib.nmfmu_rank_sums(src.data_ptr(), outer, self.R, inner, self.sum_part.data_ptr(),
                                                  out.data_ptr(), _stream()), 'nmfmu_rank_sums')
