@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "nmfmu_fused.h"
 
@@ -149,15 +150,20 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kc = kt0 * 8 + KPP * p + (tid / TROWS);     // 8 chunks per k-tile
+      // (wave-uniform: a wave's 64 lanes are 64 consecutive rows of ONE k-chunk -- kept in scalar registers, so the
+      // per-k-tile position arithmetic below costs no vector instructions)
+      const int kc = kt0 * 8 + KPP * p + __builtin_amdgcn_readfirstlane(tid / TROWS);     // 8 chunks per k-tile
       if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
   }
   auto toep_index = [&](int p) -> int {   // table chunk of (row, k-chunk p); 0 = the all-zero chunk
-    if (trow < 0) return 0;
-    if constexpr (kHuRows) return kq[p] < a.tR ? 1 + trow + kq[p] * tJJ - 8 * kr[p] : 0;
-    else return kq[p] < a.tB ? 1 + trow + kq[p] * a.tR * tJJ + kr[p] : 0;
+    // scalar part first (k position), then one vector add / select for the lane's row
+    int soff;
+    bool live;
+    if constexpr (kHuRows) soff = 1 + kq[p] * tJJ - 8 * kr[p], live = kq[p] < a.tR;
+    else soff = 1 + kq[p] * a.tR * tJJ + kr[p], live = kq[p] < a.tB;
+    return (live && trow >= 0) ? trow + soff : 0;
   };
   auto toep_advance = [&]() {
 #pragma unroll
@@ -210,8 +216,10 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
 
   stage_issue(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int buf = kt & 1;
+  // one k-tile; the staging buffer index is a compile-time constant (the loop below is unrolled by two), so every LDS
+  // address of the fragment reads and of the DMA destinations is a register base plus an immediate
+  auto k_tile = [&](int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
     if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
     const char* sb = smem + buf * C::STAGE;
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
@@ -263,6 +271,14 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       });
     }
     __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 2 <= ktiles; kt += 2) {
+      k_tile(kt, std::integral_constant<int, 0>{});
+      k_tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < ktiles) k_tile(kt, std::integral_constant<int, 0>{});
   }
 
   // ---------------- epilogue: accumulator e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column j
