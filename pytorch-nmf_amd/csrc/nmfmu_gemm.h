@@ -180,21 +180,34 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   // LDS offset of plane pl of operand op inside a stage
   auto tile_off = [](int op, int pl) { return op == 0 ? pl * C::A_TILE : C::NPL * C::A_TILE + pl * C::B_TILE; };
 
+  // LDS-DMA by inline asm in the scalar-base form (global_load_lds_dwordx4 v_off, s[base:base+1]): the k-tile advance of
+  // an explicit operand is a scalar add on its base, the pass offsets are four precomputed registers, the implicit
+  // operand's offset is (row + scalar k position) * 16 -- a handful of vector instructions per k-tile instead of a
+  // 64-bit address per pass.  hipcc does not count these loads: the waits before the barriers are explicit.
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned voff_exp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) voff_exp[p] = (unsigned)(thr_off + (size_t)p * (THREADS / 8) * ldk);
+  auto dma1k = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
+  };
   auto stage_issue = [&](int kt, int buf) {
 #pragma unroll
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl) {
         const bool implicit = OPS != kOpsPlanes && op == TOP;
-        const char* s0 = src[op * C::NPL + pl] + thr_off + (size_t)(kt0 + kt) * (C::BK * 2);
+        const char* s0 = src[op * C::NPL + pl] + (size_t)(kt0 + kt) * (C::BK * 2);     // scalar
         const int passes = op == 0 ? C::PA : C::PB;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           if (p < passes) {
-            char* dst = smem + buf * C::STAGE + tile_off(op, pl) + p * (THREADS * 16) + wave * 1024;
-            const char* g = implicit ? tab[pl] + (size_t)toep_index(p) * 16 : s0 + (size_t)p * (THREADS / 8) * ldk;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+            const unsigned dst = lds_base + buf * C::STAGE + tile_off(op, pl) + p * (THREADS * 16) + wave * 1024;
+            if (implicit) dma1k(tab[pl], (unsigned)toep_index(p) * 16u, dst);
+            else dma1k(s0, voff_exp[p], dst);
           }
         }
       }
@@ -215,6 +228,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int swz = ((j >> 1) & 7) << 4;
 
   stage_issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // one k-tile; the staging buffer index is a compile-time constant (the loop below is unrolled by two), so every LDS
   // address of the fragment reads and of the DMA destinations is a register base plus an immediate
@@ -270,6 +284,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         });
       });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed (this wave's share of it)
     __syncthreads();
   };
   {
