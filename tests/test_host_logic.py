@@ -141,6 +141,34 @@ def cpu_engine(monkeypatch):
     monkeypatch.setattr(anmf, '_require_device', lambda t_, what: None)
 
 
+def test_static_queries_of_the_gemm_engine():
+    """Round-2 host-side queries of the NMFD path (no device work): which shapes take which kernel, buffer sizes."""
+    lib = _capi.load()
+    # per-tile diagonal sums instead of the Y matrix: >= 128 taps (a 128 x 128 tile then holds at most two ranks / batches)
+    assert lib.nmfmu_fold_parts_supported(1, 8, 7793, 400) == 1 and lib.nmfmu_fold_parts_supported(1, 8, 7793, 127) == 0
+    assert lib.nmfmu_fold_parts_supported(0, 8, 100, 400) == 0
+    assert lib.nmfmu_fold_part_bytes(3200, 8192) == 25 * 64 * 4 * 256 * 4          # 4 segments x 256 diagonals per tile
+    assert lib.nmfmu_fold_hsum_parts(2, 7793) == 2 * 31
+    # ragged channels: LDS for eight (W row + H window) pairs must fit 64 KiB
+    assert lib.nmfmu_conv_ragged_supported(8, 400) == 1 and lib.nmfmu_conv_ragged_supported(8, 1100) == 0
+    assert lib.nmfmu_conv_ragged_blocks(1, 7793, 400) == 128 and lib.nmfmu_conv_ragged_blocks(3, 201, 400) == 3 * 10
+    # fp16 operands: the beta == 1 iteration on implicit operands
+    E, O = _capi, _capi
+    assert lib.nmfmu_gemm_f16_supported(1.0, E.EPI_RATIO, O.OPS_B_HU) == 1
+    assert lib.nmfmu_gemm_f16_supported(1.0, E.EPI_RATIO, O.OPS_PLANES) == 0
+    assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_RATIO, O.OPS_B_HU) == 0
+    assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
+    assert lib.nmfmu_gemm_tile256_supported(_capi.PREC_BF16, 1.0, E.EPI_LOSS, O.OPS_B_HU) == 1
+    assert lib.nmfmu_gemm_tile256_supported(_capi.PREC_BF16X3, 1.0, E.EPI_LOSS, O.OPS_B_HU) == 0
+    # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
+    d = _capi.GemmDesc()
+    assert [f[0] for f in d._fields_][-4:] == ['tile_rows', 'n_ld', 'k_len', 'k_split']
+    # argument checking happens before any device work
+    assert lib.nmfmu_gemm(None, 0, None) == _capi.ERR_ARG
+    assert lib.nmfmu_conv_ragged_rows(None, 1, 1, 1, None, 1, 1, 0, 0, 1.0, 0, None, 0, None, None, None, None, None,
+                                      None) == _capi.ERR_ARG
+
+
 @pytest.mark.parametrize('beta', [0.5, 1, 2])
 def test_fit_loop_early_stop_matches_reference(cpu_engine, beta):
     g = load_golden('g3_early_stop')
