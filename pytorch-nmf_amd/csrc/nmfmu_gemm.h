@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
 #pragma unroll
   for (int p = 0; p < 4; ++p) voff_exp[p] = (unsigned)(thr_off + (size_t)p * (THREADS / 8) * ldk);
   auto dma1k = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory", "m0");
