@@ -568,7 +568,13 @@ def main():
         rows = slice(0, min(N, 512))
         rec, rec_r = Hc[rows] @ Wc.t(), Hr[rows] @ Wr.t()
         from oracle import mu_oracle as O
-        loss_r = float(O.beta_div(Hr @ Wr.t(), Vc, beta)) if N * C <= 4096 * 65536 else None
+        # reference loss accumulated in float64 over 512-row blocks: an fp32 sum over 2.7e8 terms wanders by ~1e-4..1e-3
+        # with the host's thread count (seen: the same GPU value 8e-6 off on one box, 5e-4 on another)
+        loss_r = None
+        if N * C <= 4096 * 65536:
+            loss_r = 0.0
+            for r0 in range(0, N, 512):
+                loss_r += float(O.beta_div((Hr[r0:r0 + 512] @ Wr.t()).double(), Vc[r0:r0 + 512].double(), beta))
         d = {'rel_W': rel(Wc, Wr), 'rel_H': rel(Hc, Hr), 'rel_recon': rel(rec, rec_r),
              'rel_loss': (abs(loss - loss_r) / abs(loss_r)) if loss_r else None}
         d = {kk: (None if v is None else float(f'{v:.3e}')) for kk, v in d.items()}
