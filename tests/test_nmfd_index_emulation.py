@@ -1,0 +1,151 @@
+"""CPU restatements (numpy) of the index algebra of the round-2 NMFD kernels, checked against direct formulas.
+
+* EPI_FOLD epilogue of nt_gemm_kernel + conv_fold_parts_apply_h_kernel (csrc/nmfmu_gemm.h, csrc/nmfmu_nmfd.hip): the H
+  numerator neg[b][r][j] = sum_t Y[(r,t)][(b, j+t)] (col2im of conv1d's backward pass, nmf.py:77/82 of the reference)
+  from per-tile diagonal sums part[(tm, tn)][seg][dd] -- never from Y itself.
+* the beta == 1 denominators handed from kernel to kernel as partial sums: per 64 x 64 tile and rank for W
+  (conv_apply_pack_w_kernel -> the H update), per block for H (the H update -> conv_apply_pack_w_kernel).
+* the implicit Toeplitz operand's chunk index (row + scalar k position) against Hu[(b,l)][(r,t)] = H[b][r][l-t].
+
+If one of these mirrors and the device code drift apart the GPU parity tests fail; if the algebra itself is wrong, these
+fail without a GPU.
+"""
+import numpy as np
+import pytest
+
+
+def fold_parts_of_tile(Y, tm, tn, T, L):
+    """What the EPI_FOLD epilogue emits for the 128 x 128 tile (tm, tn) of Y [m_pad][n_pad]: [4][256]."""
+    out = np.zeros((4, 256))
+    rb = (tm * 128 // T + 1) * T - tm * 128          # first tile row of the second r (>= 128: none)
+    nb = (tn * 128 // L + 1) * L - tn * 128          # first tile column of the second b
+    tile = Y[tm * 128:(tm + 1) * 128, tn * 128:(tn + 1) * 128]
+    for dd in range(255):
+        lo, hi1 = max(0, 127 - dd), min(127, 254 - dd) + 1
+        rsw = min(max(rb, lo), hi1)
+        bsw = min(max(nb - dd + 127, lo), hi1)
+        run = lambda r0, r1: sum(tile[ml, ml + dd - 127] for ml in range(r0, r1))
+        out[0, dd] = run(lo, min(rsw, bsw))
+        out[1, dd] = run(max(lo, bsw), rsw)
+        out[2, dd] = run(rsw, max(rsw, bsw))
+        out[3, dd] = run(max(rsw, bsw), hi1)
+    return out
+
+
+def gather(parts, tiles_n, b, r, jx, T, L):
+    """conv_fold_parts_apply_h_kernel's sum for one (b, r, j)."""
+    m_lo, m_hi = r * T, r * T + T
+    diag = jx + b * L - m_lo
+    neg = 0.0
+    for tm in range(m_lo // 128, (m_hi - 1) // 128 + 1):
+        ta, tb = max(m_lo, tm * 128) - m_lo, min(m_hi, tm * 128 + 128) - m_lo
+        rbit = 2 if r > (tm * 128) // T else 0
+        na, nz = b * L + jx + ta, b * L + jx + tb - 1
+        for tn in range(na // 128, nz // 128 + 1):
+            seg = rbit + (1 if b > (tn * 128) // L else 0)
+            dd = diag - 128 * (tn - tm) + 127
+            assert 0 <= dd <= 254
+            neg += parts[tm * tiles_n + tn][seg, dd]
+    return neg
+
+
+@pytest.mark.parametrize('B,R,T,Lh', [(1, 2, 128, 130), (2, 3, 130, 77), (1, 1, 400, 201), (3, 2, 136, 200), (2, 2, 257, 1)])
+def test_fold_from_tile_diagonal_sums(B, R, T, Lh):
+    L = Lh + T - 1
+    rng = np.random.default_rng(B * 1000 + T)
+    m_pad, n_pad = -(-R * T // 128) * 128, -(-B * L // 128) * 128
+    Y = np.zeros((m_pad, n_pad))
+    Y[:R * T, :B * L] = rng.random((R * T, B * L))     # padding rows / columns are exact zeros on the device too
+    tiles_m, tiles_n = m_pad // 128, n_pad // 128
+    parts = [fold_parts_of_tile(Y, tm, tn, T, L) for tm in range(tiles_m) for tn in range(tiles_n)]
+    for b in range(B):
+        for r in range(R):
+            for jx in sorted({0, min(1, Lh - 1), Lh // 2, Lh - 1}):
+                want = sum(Y[r * T + t, b * L + jx + t] for t in range(T))
+                assert gather(parts, tiles_n, b, r, jx, T, L) == pytest.approx(want, rel=1e-12)
+    # every element of Y that belongs to some (b, r, j) is counted exactly once: sum over all j of the gathers
+    total = sum(gather(parts, tiles_n, b, r, jx, T, L) for b in range(B) for r in range(R) for jx in range(Lh))
+    want = sum(Y[r * T + t, b * L + jx + t] for b in range(B) for r in range(R) for jx in range(Lh) for t in range(T))
+    assert total == pytest.approx(want, rel=1e-10)
+
+
+@pytest.mark.parametrize('C,R,T', [(70, 3, 64), (130, 2, 136), (257, 8, 400), (64, 5, 100)])
+def test_w_rank_sums_from_tile_sums(C, R, T):
+    """conv_apply_pack_w_kernel leaves, per 64 x 64 tile (channel tile ct, k tile kt) of Wm [C][R T], the sums of the first
+    and of the second rank in the tile; the H update finishes sum_{c,t} W[c][r][t] from the tiles that hold taps of r."""
+    rng = np.random.default_rng(C + T)
+    W = rng.random((C, R, T))
+    RT = R * T
+    c_pad, rp_pad = -(-C // 64) * 64, -(-RT // 64) * 64
+    Wm = np.zeros((c_pad, rp_pad))
+    Wm[:C, :RT] = W.reshape(C, RT)
+    c_tiles, k_tiles = c_pad // 64, rp_pad // 64
+    wcol = np.zeros((c_tiles, k_tiles, 2))
+    for ct in range(c_tiles):
+        for kt in range(k_tiles):
+            r_lo = kt * 64 // T
+            for kl in range(64):
+                second = (kt * 64 + kl) // T != r_lo
+                wcol[ct, kt, int(second)] += Wm[ct * 64:(ct + 1) * 64, kt * 64 + kl].sum()
+    for r in range(R):
+        kt_lo = r * T // 64
+        kt_n = (r * T + T - 1) // 64 - kt_lo + 1
+        got = sum(wcol[ct, kt, 1 if r > (kt * 64) // T else 0] for ct in range(c_tiles) for kt in range(kt_lo, kt_lo + kt_n))
+        assert got == pytest.approx(W[:, r, :].sum(), rel=1e-12)
+
+
+@pytest.mark.parametrize('B,R,Lh', [(1, 8, 7793), (3, 2, 300), (2, 5, 256)])
+def test_h_rank_sums_from_block_sums(B, R, Lh):
+    """The H update leaves one partial per (r, b, 256-frame block); conv_apply_pack_w sums hsum_part[r][:] (any order of
+    blocks, fixed on the device)."""
+    rng = np.random.default_rng(Lh)
+    H = rng.random((B, R, Lh))
+    jblocks = -(-Lh // 256)
+    part = np.zeros((R, B * jblocks))
+    for b in range(B):
+        for r in range(R):
+            for jb in range(jblocks):
+                part[r, b * jblocks + jb] = H[b, r, jb * 256:(jb + 1) * 256].sum()
+    assert np.allclose(part.sum(1), H.sum((0, 2)), rtol=1e-12)
+
+
+@pytest.mark.parametrize('B,R,T,Lh', [(1, 2, 8, 25), (2, 3, 16, 41), (1, 1, 24, 9)])
+def test_implicit_toeplitz_chunk_index(B, R, T, Lh):
+    """Window tables (nmfmu_conv_tables) and the GEMM's chunk index: rows-(b,l) operand, k = (r, 8 tc .. 8 tc + 7) is the
+    reversed window at j = l - 8 tc of (b, r): index 1 + (b R + r) JJ + (l - 8 tc) + (T - 1), i.e. the kernel's
+    (b R JJ + l + T - 1) + (1 + r JJ - 8 tc) = per-lane row part + wave-uniform k part."""
+    L, JJ = Lh + T - 1, Lh + 2 * T - 2
+    rng = np.random.default_rng(T)
+    H = rng.random((B, R, Lh))
+    rev = np.zeros((1 + B * R * JJ, 8))
+    fwd = np.zeros((1 + B * R * JJ, 8))
+    for br in range(B * R):
+        for jj in range(JJ):
+            j = jj - (T - 1)
+            for e in range(8):
+                if 0 <= j - e < Lh:
+                    rev[1 + br * JJ + jj, e] = H[br // R, br % R, j - e]
+                if 0 <= j + e < Lh:
+                    fwd[1 + br * JJ + jj, e] = H[br // R, br % R, j + e]
+    Hu = np.zeros((B * L, R * T))
+    for b in range(B):
+        for l in range(L):
+            for r in range(R):
+                for t in range(T):
+                    if 0 <= l - t < Lh:
+                        Hu[b * L + l, r * T + t] = H[b, r, l - t]
+    for row in range(B * L):
+        b, l = divmod(row, L)
+        trow = b * R * JJ + l + T - 1                       # per-lane part
+        for r in range(R):
+            for tc in range(T // 8):
+                soff = 1 + r * JJ - 8 * tc                   # wave-uniform part (kq = r, kr = tc)
+                assert np.array_equal(rev[trow + soff], Hu[row, r * T + 8 * tc:r * T + 8 * tc + 8])
+    # rows-(r,t) operand (HuT), k = (b, l0 .. l0 + 7): forward window at j = l0 - t
+    for r in range(R):
+        for t in range(T):
+            trow = r * JJ - t + T - 1
+            for b in range(B):
+                for l0 in range(0, L - 7, 8):
+                    soff = 1 + b * R * JJ + l0
+                    assert np.array_equal(fwd[trow + soff], Hu[b * L + l0:b * L + l0 + 8, r * T + t])
