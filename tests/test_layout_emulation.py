@@ -256,3 +256,36 @@ def test_transposing_reads_gather_the_g2_operand_conflict_free(r_pad):
                         for lane in range(32 * half, 32 * half + 32):
                             banks += [(addr[lane] // 4) % 64, (addr[lane] // 4 + 1) % 64]
                         assert len(set(banks)) == 64, ('bank conflict', r_pad, tt, m2, h, rt, half)
+
+
+@pytest.mark.parametrize('r_pad', [32, 64, 128])
+def test_fused_apply_epilogue_slot_map(r_pad):
+    """Round-2 fused-apply epilogue of the ping-pong kernel (nmfmu_pp.h): a wave's 32 x r_pad tile is handed out as
+    (row, 8-rank slot) chunks, lane -> slot lane % SP for the whole pass (denominators / column sums of those 8 ranks stay
+    in registers), rows i * (64 / SP) + lane / SP.  Every chunk exactly once; the row-major image slot and the
+    transposed image slot (8 consecutive rows of one rank) are 16 contiguous, aligned bytes; the column-sum butterfly
+    (xor 32, 16, ... down to SP) combines exactly the lanes that share a slot."""
+    SP = r_pad // 8
+    nch = 32 * SP // 64
+    seen = set()
+    for i in range(nch):
+        for lane in range(64):
+            rl, slot = i * (64 // SP) + lane // SP, lane % SP
+            assert 0 <= rl < 32 and (rl, slot) not in seen
+            seen.add((rl, slot))
+    assert len(seen) == 32 * SP
+    for row in (0, 5, 37, 63, 64 + 19):
+        for slot in range(SP):
+            offs = [p1_offset(row, slot * 8 + k, r_pad) for k in range(8)]
+            assert offs == list(range(offs[0], offs[0] + 8)) and offs[0] % 8 == 0
+    for row0 in (0, 8, 56, 64 + 24):
+        for r in (0, 1, 7, r_pad - 1):
+            offs = [p2_offset(row0 + k, r, r_pad) for k in range(8)]
+            assert offs == list(range(offs[0], offs[0] + 8)) and offs[0] % 8 == 0
+    # butterfly: lanes reachable from `lane` by xor with the masks >= SP are exactly those with the same lane % SP
+    masks = [m for m in (32, 16, 8, 4) if m >= SP]
+    for lane in range(64):
+        group = {lane}
+        for m in masks:
+            group |= {x ^ m for x in group}
+        assert group == {x for x in range(64) if x % SP == lane % SP}
