@@ -31,8 +31,10 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 3 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
-                               3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, nmfmu_mu_step_parts, NMFMU_PREC_F16 */
+#define NMFMU_ABI_VERSION 4 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+                               3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
+                               4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
+                                  nmfmu_parts_supported removed (measured neutral); NMFMU_STAGE_REG no longer built */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -42,7 +44,9 @@ extern "C" {
 #define NMFMU_PREC_BF16 0   /* X stored bf16; operands bf16                                   */
 #define NMFMU_PREC_BF16X3 1 /* X stored fp32; operands split hi+lo, 3 MFMAs per product        */
 #define NMFMU_PREC_F16 2    /* X stored fp16; operands fp16 (11 significant bits, same MFMA rate as bf16); values are
-                               clamped to +-65504.  beta == 1, padded rank <= 128 (ping-pong kernel, nmfmu_pp.h) */
+                               clamped to 65504 when packed, conversions saturate.  The single-plane mode that meets the
+                               reference within 1e-4 at the BASELINE shapes.  beta == 1 at padded rank <= 128 runs on the
+                               ping-pong kernel (nmfmu_pp.h), everything else on the four-wave kernel (nmfmu_fused.h) */
 
 /* beta branches of nmf.py:61-74 / metrics.py:78-96 */
 #define NMFMU_BETA_KL 0  /* beta == 1 */
@@ -51,7 +55,7 @@ extern "C" {
 #define NMFMU_BETA_GEN 3 /* anything else */
 
 /* how the panel tile reaches LDS */
-#define NMFMU_STAGE_REG 0 /* global -> VGPR -> ds_write */
+#define NMFMU_STAGE_REG 0 /* global -> VGPR -> ds_write: no longer built, NMFMU_ERR_UNSUPPORTED */
 #define NMFMU_STAGE_DMA 1 /* global_load_lds (LDS-DMA)  */
 
 /* One factor (W or H) as the engine sees it. */
@@ -139,18 +143,12 @@ int nmfmu_den_partial(const nmfmu_step* st, void* stream);
  * 2 = only what follows it (lets a caller bracket the dominant kernel with events). */
 int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream);
 
-/* The same half-step for beta == 1 WITHOUT the column-sum finalize launches between half-steps (nmf.py:122-131's
- * H.sum / W.sum): the denominators arrive as `kl_nparts` partial column sums [kl_nparts][r_pad] of the panel -- the
- * colsum_part buffer the panel's own last update (or nmfmu_pack_factor) left behind -- and every consuming workgroup
- * reduces them itself in a fixed order; the owner's new partials are left in st->owner.colsum_part
- * (nmfmu_colsum_nparts(st) of them; st->owner.colsum is NOT refreshed -- nmfmu_colsum_finalize does that on demand).
- * nmfmu_parts_supported(st): 1 when the step runs on the ping-pong kernel (beta == 1, bf16 / fp16, padded rank <= 128,
- * 256-row tiles).  nmfmu_pack_nparts(rows_pad): partial count nmfmu_pack_factor leaves. */
-int nmfmu_parts_supported(const nmfmu_step* st);
+/* Column-sum bookkeeping (nmf.py:122-131's H.sum / W.sum, deterministic two-stage sums): the number of partial sums
+ * [nparts][r_pad] a half-step (nmfmu_colsum_nparts) or nmfmu_pack_factor (nmfmu_pack_nparts) leaves in colsum_part, and
+ * the second stage on its own. */
 int nmfmu_colsum_nparts(const nmfmu_step* st);
 int nmfmu_pack_nparts(int rows_pad);
 int nmfmu_colsum_finalize(const nmfmu_factor* fac, int nparts, int r_pad, void* stream);
-int nmfmu_mu_step_parts(const nmfmu_step* st, const float* kl_part, int kl_nparts, int phase, void* stream);
 
 /* nmfmu_slab_reduce: num_out = sum_s slab_num[s] (and den_out likewise unless NULL).  Used by the column-sharded
  * multi-GPU path so that one all-reduce carries [owner.rows_pad x r_pad] floats. */
@@ -416,10 +414,10 @@ int nmfmu_timer_destroy(void* timer);
 int nmfmu_probe_mfma(const uint16_t* a /*32x16 bf16 row-major*/, const uint16_t* b /*16x32*/, float* d /*32x32*/,
                      void* stream);
 int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords /* multiple of 1024 */, void* stream);
-/* Diagnostic hook of the ping-pong kernel (nmfmu_pp.h): with a device buffer of >= 2 * 256 * 6 uint64 registered and
- * NMFMU_PP_VAR bit 128 set, workgroup 0 records s_memtime stamps of every segment of waves 0 and 4
- * ([half][tile][M start, M end, after barrier, E end, after barrier, spare]).  buf = NULL unregisters.  Not used by
- * the product path (tools/pp_timeline.py). */
+/* Diagnostic hook of the ping-pong kernel (nmfmu_pp.h), live only in libraries built with -DNMFMU_DEBUG_HOOKS
+ * (NMFMU_ERR_UNSUPPORTED otherwise): with a device buffer of >= (64 + 5 * workgroups) uint64 registered, every
+ * workgroup records clock stamps at kernel entry, loop start, loop end and exit (tools/pp_timeline.py).  buf = NULL
+ * unregisters.  Not used by the product path. */
 int nmfmu_debug_set_buffer(void* buf);
 
 #ifdef __cplusplus

@@ -26,9 +26,6 @@ struct ApplyArgs {
   float ortho;
   float* grad;          // [rows][rank] or nullptr
   int f16;              // images in fp16 (clamped to 65504) instead of bf16; no lo planes
-  const float* kl_part; // beta == 1 denominators as [kl_nparts][R_PAD] partial column sums (instead of kl_den)
-  int kl_nparts;
-  int skip_finalize;    // leave the owner's column sums as partials in colsum_part (the consumer reduces them)
 };
 
 int apply_stripe_rows(int rows_pad);   // rows per apply workgroup (= rows per column-sum partial): 16 or 64

@@ -107,33 +107,6 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   // trainer mode with an orthogonality penalty needs p.sum(1) of the OLD factor (trainer.py:105-106): stage the old
   // rows in the tile first, reduce each row in a fixed order
   float* rowsum = tile + ROWS * LDT;  // [ROWS]
-  float* klsum = rowsum + ROWS;       // [R_PAD]  (kl_part mode)
-  if constexpr (!PACK_ONLY) {
-    if (a.kl_part) {
-      // column sums of the panel from per-stripe partials: 256 / (R_PAD/4) interleaved float4 streams per column
-      // group, combined in a fixed order (every workgroup gets the same bits)
-      constexpr int R4c = R_PAD / 4, NG = 256 / R4c;
-      float4* part4 = reinterpret_cast<float4*>(klsum + R_PAD);   // [NG][R4c]
-      const int c4 = tid % R4c, gq = tid / R4c;
-      float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int pp = gq; pp < a.kl_nparts; pp += NG) {
-        const float4 v = *reinterpret_cast<const float4*>(a.kl_part + (size_t)pp * R_PAD + 4 * c4);
-        sacc.x += v.x, sacc.y += v.y, sacc.z += v.z, sacc.w += v.w;
-      }
-      part4[gq * R4c + c4] = sacc;
-      __syncthreads();
-      if (tid < R4c) {
-        float4 t = part4[tid];
-#pragma unroll
-        for (int g2 = 1; g2 < NG; ++g2) {
-          const float4 v = part4[g2 * R4c + tid];
-          t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
-        }
-        reinterpret_cast<float4*>(klsum)[tid] = t;
-      }
-      __syncthreads();
-    }
-  }
   if constexpr (!PACK_ONLY) {
     if (a.trainer && a.ortho > 0.f) {
       for (int idx = tid; idx < ROWS * R_PAD; idx += 256) {
@@ -184,9 +157,8 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
         float neg[4] = {n4.x, n4.y, n4.z, n4.w};
         float pos[4];
         const float den_eps = a.trainer ? 0.f : kEps;  // the trainer adds eps after the penalties (trainer.py:108)
-        if (a.kl_den || a.kl_part) {  // closed form, no relu / eps (nmf.py:80 branch skipped; trainer.py:84 ones-backward)
-          const float4 d4 = a.kl_part ? *reinterpret_cast<const float4*>(klsum + r)
-                                      : *reinterpret_cast<const float4*>(a.kl_den + r);
+        if (a.kl_den) {  // closed form, no relu / eps (nmf.py:80 branch skipped; trainer.py:84 ones-backward)
+          const float4 d4 = *reinterpret_cast<const float4*>(a.kl_den + r);
           pos[0] = d4.x, pos[1] = d4.y, pos[2] = d4.z, pos[3] = d4.w;
         } else {
           float4 d4 = *reinterpret_cast<const float4*>(a.den + e);
@@ -293,9 +265,7 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
 template <int R_PAD, int ROWS>
 int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   const int grid = a.rows_pad / ROWS;
-  // tile + row sums + kl_part scratch ([R_PAD] sums + [256 / (R_PAD/4)][R_PAD] partial streams)
-  const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float) + ROWS * sizeof(float) +
-                     (size_t)R_PAD * sizeof(float) * (1 + 256 / (R_PAD / 4));
+  const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float) + ROWS * sizeof(float);   // tile + row sums
 #define L(X, P)                                                                                                      \
   {                                                                                                                  \
     auto k = apply_kernel<R_PAD, X, P, ROWS>;                                                                        \
@@ -312,7 +282,7 @@ int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) 
   else L(false, false)
 #undef L
   int e = (int)hipGetLastError();
-  if (e || a.skip_finalize) return e;
+  if (e) return e;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(R_PAD / 32), dim3(256), 0, s, a.colsum_part, grid, R_PAD, a.colsum);
   return (int)hipGetLastError();
 }

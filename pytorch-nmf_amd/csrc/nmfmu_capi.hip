@@ -18,42 +18,40 @@ namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-static bool stage_is_reg(const nmfmu_step* st) { return st->stage == NMFMU_STAGE_REG; }
-
-// Experiment hooks (read once): NMFMU_PP=0 routes beta = 1 / bf16 half-steps back to the four-wave kernels of
-// nmfmu_fused.h; NMFMU_PP_VAR selects a build-time variant of the ping-pong kernel (nmfmu_pp.h, VAR bits).
+// Diagnostic builds only (make EXTRA=-DNMFMU_DEBUG_HOOKS): NMFMU_FORCE_NSPLIT overrides the contraction split and
+// nmfmu_debug_set_buffer registers the clock-stamp buffer of the ping-pong kernel (tools/pp_timeline.py).  The product
+// library reads no environment variable and keeps no global state.
+#ifdef NMFMU_DEBUG_HOOKS
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v && *v ? std::atoi(v) : dflt;
 }
-static int pp_enabled() {
-  static const int v = env_int("NMFMU_PP", 1);
-  return v;
-}
-static void* g_pp_debug = nullptr;   // nmfmu_debug_set_buffer
-static int pp_var() {
-  static const int v = env_int("NMFMU_PP_VAR", 0);
-  return v;
-}
+static void* g_pp_debug = nullptr;
+#endif
 // which half-steps the ping-pong kernel serves: beta == 1, one operand plane (bf16 or fp16), padded rank <= 128
 static bool pp_eligible(int r_pad, int precision, float beta) {
-  if (nmfmu_beta_kind(beta) != NMFMU_BETA_KL || r_pad > 128) return false;
-  if (precision == NMFMU_PREC_F16) return true;
-  return precision == NMFMU_PREC_BF16 && pp_enabled();
+  return nmfmu_beta_kind(beta) == NMFMU_BETA_KL && r_pad <= 128 &&
+         (precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_BF16);
+}
+// beta -> kernel branch (nmfmu_fused.h: BetaKind): the public kinds plus the two rsqrt special cases of the generic one
+static int kernel_beta_kind(float beta) {
+  if (beta == 0.5f) return kSqrt;
+  if (beta == 1.5f) return kSqrt3;
+  return nmfmu_beta_kind(beta);
 }
 
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
-                   const float* fuse_kl_den = nullptr, const float* fuse_kl_part = nullptr, int fuse_kl_nparts = 0) {
+                   const float* fuse_kl_den = nullptr) {
   if (!st || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
   if (!st->xp && mode == kModeMU) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
-  const int G = st->block_rows / 128;
+  if (st->stage != NMFMU_STAGE_DMA) return NMFMU_ERR_UNSUPPORTED;   // the register-staged variant is no longer built
   if (st->r_pad != pad_rank(st->rank) || st->nsplit < 1) return NMFMU_ERR_ARG;
-  const int x3 = st->precision == NMFMU_PREC_BF16X3 ? 1 : 0;
+  const bool x3 = st->precision == NMFMU_PREC_BF16X3;
   if (x3 && (!st->owner.p1_lo || !st->panel.p1_lo)) return NMFMU_ERR_ARG;
   const int kind = nmfmu_beta_kind(st->beta);
-  FusedArgs a;
+  FusedArgs a{};
   a.xp = st->xp;
   a.p1_hi = static_cast<const uint16_t*>(st->panel.p1_hi);
   a.p1_lo = static_cast<const uint16_t*>(st->panel.p1_lo);
@@ -71,14 +69,13 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   a.nsplit = st->nsplit;
   a.tiles_per_split = (a.ktiles + st->nsplit - 1) / st->nsplit;
   a.beta = st->beta;
-  a.fuse_apply = 0;
-  a.kl_part = nullptr, a.kl_nparts = 0;
-  if (fuse_kl_den || fuse_kl_part) {  // beta == 1, nsplit == 1: apply in the epilogue
+  a.cs_owner = st->owner.colsum;   // fp16 operands, beta < 1: typical S -> scale of Gn / Gp (nmfmu_fused.h)
+  a.cs_panel = st->panel.colsum;
+  if (fuse_kl_den) {  // beta == 1, nsplit == 1: apply in the epilogue
     a.fuse_apply = 1;
     a.rank = st->rank;
     a.f = st->owner.f;
     a.kl_den = fuse_kl_den;
-    a.kl_part = fuse_kl_part, a.kl_nparts = fuse_kl_nparts;
     a.o1_hi = static_cast<uint16_t*>(st->owner.p1_hi), a.o1_lo = static_cast<uint16_t*>(st->owner.p1_lo);
     a.o2_hi = static_cast<uint16_t*>(st->owner.p2_hi), a.o2_lo = static_cast<uint16_t*>(st->owner.p2_lo);
     a.colsum_part = st->owner.colsum_part;
@@ -87,30 +84,25 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   if (mode == kModeMU || mode == kModeDen) {
     if (!a.slab_num || !a.p2_hi || (x3 && !a.p2_lo)) return NMFMU_ERR_ARG;
     if (mode == kModeMU && kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
-    if (mode == kModeDen && (kind != kGen || G != 1 || stage_is_reg(st))) return NMFMU_ERR_UNSUPPORTED;
+    if (mode == kModeDen && (kind != kGen || st->block_rows != 128)) return NMFMU_ERR_UNSUPPORTED;
   } else if (!loss_part) {
     return NMFMU_ERR_ARG;
   }
   const int grid = (st->owner.rows_pad / st->block_rows) * st->nsplit;
-  const int stage = st->stage == NMFMU_STAGE_REG ? 0 : 1;
-  if (G == 2 && stage == 1 && st->xp && (mode == kModeMU || mode == kModeLoss) &&
-      pp_eligible(st->r_pad, st->precision, st->beta)) {
-    const int opt = st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16;
-    const int var = mode == kModeMU ? pp_var() : 0;
-    if (!(var & 256)) a.tiles_per_split = (a.tiles_per_split + 1) & ~1;   // register-X tile loop is unrolled by two
-    if (var & 128) {
-      if (!g_pp_debug) return NMFMU_ERR_ARG;
-      a.loss_part = static_cast<float*>(g_pp_debug);   // (unused by the MU mode otherwise)
-    }
-    return launch_pp(st->r_pad, opt, mode, var, a, grid, s);
+  if (st->block_rows == 256) {   // the eight-wave ping-pong kernel (beta == 1, one operand plane, padded rank <= 128)
+    if (!st->xp || mode == kModeDen || !pp_eligible(st->r_pad, st->precision, st->beta)) return NMFMU_ERR_UNSUPPORTED;
+    a.tiles_per_split = (a.tiles_per_split + 1) & ~1;   // its tile loop is unrolled by two
+#ifdef NMFMU_DEBUG_HOOKS
+    a.debug = mode == kModeMU ? g_pp_debug : nullptr;
+#endif
+    return launch_pp(st->r_pad, st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16, mode, a, grid, s);
   }
-  if (st->precision == NMFMU_PREC_F16) return NMFMU_ERR_UNSUPPORTED;   // fp16 operands exist in the ping-pong kernel only
-  if (a.kl_part) return NMFMU_ERR_UNSUPPORTED;                          // so do partial-sum denominators
+  const int kk = kernel_beta_kind(st->beta);
   switch (st->r_pad) {
-    case 32: return launch_fused_r32(kind, x3, mode, stage, G, a, grid, s);
-    case 64: return launch_fused_r64(kind, x3, mode, stage, G, a, grid, s);
-    case 128: return launch_fused_r128(kind, x3, mode, stage, G, a, grid, s);
-    case 256: return launch_fused_r256(kind, x3, mode, stage, G, a, grid, s);
+    case 32: return launch_fused_r32(kk, st->precision, mode, a, grid, s);
+    case 64: return launch_fused_r64(kk, st->precision, mode, a, grid, s);
+    case 128: return launch_fused_r128(kk, st->precision, mode, a, grid, s);
+    case 256: return launch_fused_r256(kk, st->precision, mode, a, grid, s);
   }
   return NMFMU_ERR_UNSUPPORTED;
 }
@@ -139,27 +131,24 @@ int nmfmu_supported(int r_pad, int precision) {
   if (r_pad != 32 && r_pad != 64 && r_pad != 128 && r_pad != 256) return 0;
   if (precision == NMFMU_PREC_BF16) return 1;
   if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
-  if (precision == NMFMU_PREC_F16) return r_pad <= 128;     // ping-pong kernel only (beta == 1)
+  if (precision == NMFMU_PREC_F16) return 1;                // ping-pong kernel (beta == 1, r_pad <= 128), else four-wave
   return 0;
 }
 
 int nmfmu_block_rows(int r_pad, int precision, float beta) {
   // beta == 1 with one operand plane and padded rank <= 128: the eight-wave ping-pong kernel on 256-row tiles.
-  // Everything else: 128-row tiles (two workgroups per CU) measure faster than the four-wave 256-row variant
-  // (0.154 vs 0.179 ms per half-step at 4096x65536 r128); those stay built and selectable where has_g2() holds.
-  if (pp_eligible(r_pad, precision, beta)) return 256;
-#if NMFMU_SP
-  if (r_pad == 128 && precision == NMFMU_PREC_BF16 && nmfmu_beta_kind(beta) == NMFMU_BETA_KL) return 256;
-#endif
-  return 128;
+  // Everything else: the four-wave kernel on 128-row tiles (two workgroups per CU where the registers allow).
+  return pp_eligible(r_pad, precision, beta) ? 256 : 128;
 }
 
 int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu) {
   if (owner_rows_pad <= 0 || panel_rows_pad <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int mblocks = owner_rows_pad / block_rows;
   const int ktiles = panel_rows_pad / kBK;
-  static const int forced = env_int("NMFMU_FORCE_NSPLIT", 0);   // experiment hook
+#ifdef NMFMU_DEBUG_HOOKS
+  static const int forced = env_int("NMFMU_FORCE_NSPLIT", 0);
   if (forced > 0) return std::min(forced, std::max(1, ktiles));
+#endif
   // 128-row tiles run two workgroups per CU (both wave slots of every SIMD); 256-row tiles run one.
   const int target = (block_rows == 128 ? 2 : 1) * std::max(num_cu, 1);
   int ns = (target + mblocks - 1) / mblocks;
@@ -170,12 +159,9 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
 
 int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu) {
   if (pp_eligible(r_pad, precision, beta)) return 256;   // both half-steps (the apply is fused there as well)
-  // Four-wave kernels: a half-step whose owner axis alone fills the chip with 128-row workgroups (no contraction
-  // split) keeps the 128-row tile: the MU apply then runs in the epilogue, which measures faster at two workgroups
-  // per CU (0.172 vs 0.178 ms at configs[1]'s W half-step).  Split half-steps take nmfmu_block_rows()'s tile.
-  const int ns128 = nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, 128, num_cu);
-  if (ns128 < 0) return ns128;
-  return ns128 == 1 ? 128 : nmfmu_block_rows(r_pad, precision, beta);
+  if (owner_rows_pad <= 0 || panel_rows_pad <= 0) return NMFMU_ERR_ARG;
+  (void)num_cu;
+  return 128;                                              // four-wave kernel
 }
 
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision) {
@@ -256,15 +242,6 @@ int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* st
   return e;
 }
 
-static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
-                        int trainer, float ortho, float* grad, void* stream, const float* kl_part, int kl_nparts,
-                        int skip_finalize);
-
-int nmfmu_parts_supported(const nmfmu_step* st) {
-  if (!st) return 0;
-  return st->block_rows == 256 && st->stage == NMFMU_STAGE_DMA && pp_eligible(st->r_pad, st->precision, st->beta) ? 1 : 0;
-}
-
 int nmfmu_colsum_nparts(const nmfmu_step* st) {
   if (!st || (st->block_rows != 128 && st->block_rows != 256)) return NMFMU_ERR_ARG;
   // fused apply (nsplit == 1): one partial per workgroup tile; otherwise one per apply-kernel stripe
@@ -276,21 +253,6 @@ int nmfmu_pack_nparts(int rows_pad) { return rows_pad <= 0 ? NMFMU_ERR_ARG : row
 int nmfmu_colsum_finalize(const nmfmu_factor* fac, int nparts, int r_pad, void* stream) {
   if (!fac || !fac->colsum || !fac->colsum_part || nparts <= 0) return NMFMU_ERR_ARG;
   return launch_colsum_finalize(fac->colsum_part, nparts, r_pad, fac->colsum, S(stream));
-}
-
-int nmfmu_mu_step_parts(const nmfmu_step* st, const float* kl_part, int kl_nparts, int phase, void* stream) {
-  if (!st || phase < 0 || phase > 2 || !kl_part || kl_nparts <= 0) return NMFMU_ERR_ARG;
-  if (!nmfmu_parts_supported(st)) return NMFMU_ERR_UNSUPPORTED;
-  const bool fuse = st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum_part;
-  int e = 0;
-  if (phase != 2) {
-    e = fuse ? fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream), nullptr, kl_part, kl_nparts)
-             : nmfmu_mu_partial(st, stream);
-    if (e) return e;
-  }
-  if (phase != 1 && !fuse)
-    e = apply_common(st, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, stream, kl_part, kl_nparts, /*skip_finalize=*/1);
-  return e;
 }
 
 int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void* stream) {
@@ -306,8 +268,7 @@ int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void
 }
 
 static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
-                        int trainer, float ortho, float* grad, void* stream, const float* kl_part,
-                        int kl_nparts, int skip_finalize) {
+                        int trainer, float ortho, float* grad, void* stream) {
   if (!st || !st->owner.f) return NMFMU_ERR_ARG;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   ApplyArgs a{};
@@ -316,9 +277,8 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.den = num ? den : st->slab_den;
   a.nslab = num ? nslab : st->nsplit;
   a.kl_den = kl ? kl_den : nullptr;
-  a.kl_part = kl ? kl_part : nullptr, a.kl_nparts = kl_nparts, a.skip_finalize = skip_finalize;
   if (!a.num || a.nslab < 1) return NMFMU_ERR_ARG;
-  if (kl ? (!a.kl_den && !a.kl_part) : !a.den) return NMFMU_ERR_ARG;
+  if (kl ? !a.kl_den : !a.den) return NMFMU_ERR_ARG;
   a.p1_hi = st->owner.p1_hi, a.p1_lo = st->owner.p1_lo, a.p2_hi = st->owner.p2_hi, a.p2_lo = st->owner.p2_lo;
   a.colsum_part = st->owner.colsum_part, a.colsum = st->owner.colsum;
   a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
@@ -331,13 +291,13 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
 
 int nmfmu_mu_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                    void* stream) {
-  return apply_common(st, num, den, nslab, kl_den, 0, 0.f, nullptr, stream, nullptr, 0, 0);
+  return apply_common(st, num, den, nslab, kl_den, 0, 0.f, nullptr, stream);
 }
 
 int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
                         float ortho, float* grad, void* stream) {
   if (!(ortho >= 0.f)) return NMFMU_ERR_ARG;
-  return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream, nullptr, 0, 0);
+  return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream);
 }
 
 int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit) {
@@ -414,8 +374,13 @@ int nmfmu_timer_destroy(void* timer) {
 }
 
 int nmfmu_debug_set_buffer(void* buf) {
+#ifdef NMFMU_DEBUG_HOOKS
   g_pp_debug = buf;
   return NMFMU_OK;
+#else
+  (void)buf;
+  return NMFMU_ERR_UNSUPPORTED;   // diagnostic builds only
+#endif
 }
 
 int nmfmu_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, void* stream) {

@@ -1,8 +1,8 @@
-// Instantiations of the fused MU kernel for padded rank 32 (one translation unit per rank so they build in parallel).
+// Instantiations of the four-wave fused MU kernel for padded rank 32 (one translation unit per rank so they build in parallel).
 #include "nmfmu_fused.h"
 
 namespace nmfmu {
-int launch_fused_r32(int beta_kind, int x3, int mode, int stage, int g, const FusedArgs& a, int grid, hipStream_t s) {
-  return launch_fused_dispatch<32, true>(beta_kind, x3, mode, stage, g, a, grid, s);
+int launch_fused_r32(int beta_kind, int prec, int mode, const FusedArgs& a, int grid, hipStream_t s) {
+  return launch_fused_dispatch<32, true>(beta_kind, prec, mode, a, grid, s);
 }
 }  // namespace nmfmu

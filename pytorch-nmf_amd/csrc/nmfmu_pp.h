@@ -13,7 +13,7 @@
 //   M(t) "matrix segment": G1(t) = S^T tiles of k-tile t (16 MFMA at rank pad 128), then G2(t-1) = numerator update
 //        with the ratios of the previous tile (16 MFMA); fillers are only the LDS operand reads (1 per MFMA).
 //   E(t) "elementwise segment": ratios Gn = X / (S + eps) -> packed 16-bit operands (VALU), the LDS-DMA of the panel
-//        tiles three k-tiles ahead and the X loads two k-tiles ahead (VMEM issue), the first operand reads of the
+//        tiles two k-tiles ahead and the X loads two k-tiles ahead (VMEM issue), the first operand reads of the
 //        next M segment.
 //
 // One raw s_barrier separates the segments, so a SIMD's matrix pipe always has exactly one wave feeding it while the
@@ -21,40 +21,32 @@
 // exchanged between the waves: each wave owns 32 owner rows, its S tile, ratios and numerator accumulators stay in
 // its registers exactly as in the four-wave kernel.
 //
-// Memory pipeline (everything arrives by LDS-DMA issued from inline asm, so hipcc neither counts nor drains it):
-//   panel images P1 / P2 : three-slot rings; waves 0-3 issue P1(t+2) and P2(t+1) in their E(t) and wait for them with
-//                          a COUNTED vmcnt at the end of their next M segment -- one barrier before anybody (the
-//                          operand prefetch of E(t+1)) reads them.  Waves 4-7 issue no panel traffic: their segments
-//                          are one barrier later, which would be one barrier too late for waves 0-3.
-//   X                    : two-slot ring of 256 x 64 tiles (fragment order of nmfmu_layout.h, so a wave's share is one
-//                          contiguous 4 KiB piece that only this wave ever reads: no cross-wave hazard, no barrier);
-//                          X(t+2) issued at the end of E(t) once the wave has read X(t).
+// Memory pipeline (everything is issued from inline asm, so hipcc neither counts nor drains it):
+//   panel images P1 / P2 : three-slot LDS rings filled by LDS-DMA; waves 0-3 issue P1(t+2) and P2(t+1) in their E(t)
+//                          and wait for them with a COUNTED vmcnt at the end of their next M segment -- one barrier
+//                          before anybody (the operand prefetch of E(t+1)) reads them.  Waves 4-7 issue no panel
+//                          traffic: their segments are one barrier later, which would be one barrier too late.
+//   X                    : global_load_dwordx4 ... nt straight into the lane that needs it (fragment order of
+//                          nmfmu_layout.h: a wave's share of a tile is one contiguous 4 KiB piece), two register
+//                          buffers, X(t+2) issued at the end of E(t) once the wave has consumed X(t).
 //   the only vmcnt in the loop is `vmcnt(4)` at the end of every M segment: it leaves exactly the wave's four youngest
-//   DMAs (its X piece two tiles ahead) in flight.
+//   loads (its X piece two tiles ahead) in flight.
 //
 // Operand types: bf16 (as nmfmu_fused.h) or fp16 -- same MFMA rate, 11 instead of 8 significant bits, which is what
 // brings the factors within 1e-4 of the fp32 reference at the BASELINE shapes.  In fp16 mode X
 // is stored fp16 and the ratio is ONE v_fma_mix_f32 per element (fp16 source half selected by op_sel); MODE.FP16_OVFL
 // is set so that an overflowing ratio saturates at 65504 instead of becoming inf.
+//
+// What was tried on this loop and measured not faster (profiles/r02_clock.md; the code is in the git history of
+// round 2): X through an LDS ring, an 8-deep operand ring, s_setprio for the matrix segments or for the younger
+// half, accumulators in AGPRs, ONE panel image with ds_read_b64_tr_b16 gathers for G2 (half the panel stream, +7 %
+// clock, +15 % cycles), column sums handed over as partials instead of finalize launches.
 #pragma once
 #include "nmfmu_fused.h"
 
 namespace nmfmu {
 
-// VAR bits (build-time experiment switches, selected per launch through FusedArgs-independent dispatch):
-//   1: s_setprio 1 for the matrix segments      2: static s_setprio 1 for the younger half (waves 4-7)
-//   4: LDS-DMA issued after the elementwise work instead of before it
-// ablations (wrong results, timing only):  8: no X DMA in the loop   16: no panel DMA in the loop
-//   32: no elementwise arithmetic (the ratio words are the raw X words)   64: no MFMAs
-// 128: s_memtime stamps of every segment of waves 0 and 4 of workgroup 0 into FusedArgs::loss_part
-// 256: X tiles go through a two-slot LDS ring (LDS-DMA) instead of straight into registers (global_load_dwordx4, two
-//      buffers, two tiles ahead): 32 KiB more LDS-DMA writes and LDS reads per tile, measured 5 % slower (no longer
-//      instantiated: its 160 KiB of LDS leave no room for the column-sum scratch)
-// 512: operand prefetch ring 8 deep instead of 4
-// 16384: single panel image -- G2's operands by ds_read_b64_tr_b16 from the row-major tile (see PPCfg::TR)
-// 8192: numerator accumulators in AGPRs ("a" operands of the MFMAs) -- measured 1-2 % slower, not instantiated
-// 1024 / 2048 (timing only): the panel DMA / the X loads are issued twice -- marginal cost of one VMEM instruction
-template <int R_PAD, int OPT, int MODE, int VAR>
+template <int R_PAD, int OPT, int MODE>
 struct PPCfg {
   static constexpr int BM = 256, WAVES = 8, THREADS = 512;
   static constexpr int KS = R_PAD / 16;      // k-steps of G1 (contraction over rank)
@@ -62,36 +54,24 @@ struct PPCfg {
   static constexpr int ROWB = 2 * R_PAD;     // bytes per P1 row
   static constexpr int IMG = kBK * ROWB;     // bytes of one image tile
   static constexpr bool LOSS = MODE == kModeLoss;
-  // TR (experimental, VAR bit 16384, padded rank 128 only): ONE panel image.  G2's k-contiguous operands are gathered
-  // from the row-major P1 tile with the transposing read ds_read_b64_tr_b16 (two per MFMA) instead of coming from a
-  // second, transposed image: half the panel LDS-DMA per tile and 64 KiB of LDS instead of 96.  Parity-green and
-  // bank-conflict free, but NOT faster on MI355X (profiles/r02_clock.md: 3 073 instead of 2 680 cycles per tile at a
-  // 7 % higher clock; W half-step 0.164 vs 0.155 ms): the extra 16 LDS reads and 32 address XORs per tile cost what
-  // the halved panel stream saves.  The two-image path stays the default.
-  static constexpr bool TR = (VAR & 16384) != 0 && !LOSS;
   static constexpr int LEAD = 2;             // P1 runs LEAD tiles ahead, P2 LEAD - 1
-  static constexpr int NSLOT = TR ? 4 : 3;   // P1 ring depth (TR: tile t-1 is still read by G2 while t+2 arrives)
-  static constexpr int NSLOT2 = TR ? 0 : 3;  // P2 ring depth
+  static constexpr int NSLOT = 3;            // ring depth of P1 and of P2
   static constexpr int XTILE = BM * kBK * 2; // one X tile: 256 rows x 64 columns x 2 bytes = 32 KiB
-  static constexpr bool XREG = (VAR & 256) == 0;  // X straight into registers (two buffers); bit 256: LDS ring instead
-  static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG, X_BASE = (NSLOT + NSLOT2) * IMG;
-  static constexpr int LDS_MAIN = X_BASE + (XREG ? 0 : 2 * XTILE);
+  static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG;
+  static constexpr int LDS_MAIN = 2 * NSLOT * IMG;
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
-  // panel column sums (partials mode): [R_PAD] floats + [4][R_PAD] scratch, parked behind the rings during the loop
-  static constexpr int KL_OFF = LDS_MAIN;
-  static constexpr int LDS_KL = LOSS ? 0 : 5 * R_PAD * 4;
-  static constexpr int LDS_BYTES = (LDS_MAIN + LDS_KL) > LDS_EPI ? (LDS_MAIN + LDS_KL) : LDS_EPI;
+  static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
   static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
   static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
-  static constexpr int PF = (VAR & 512) ? 8 : 4;             // operand prefetch ring depth
-  static constexpr bool SCALED = OPT == kOpBf16 && !(VAR & 4096);   // S' = 2^23 (S + eps), seeded with the inline constant 1.0
+  static constexpr int PF = 4;                               // operand prefetch ring depth
+  static constexpr bool SCALED = OPT == kOpBf16;             // S' = 2^23 (S + eps), seeded with the inline constant 1.0
   static_assert(NSTEP1 >= PF, "ring deeper than G1");
 };
 
-template <int R_PAD, int OPT, int MODE, int VAR>
+template <int R_PAD, int OPT, int MODE>
 __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
-  using C = PPCfg<R_PAD, OPT, MODE, VAR>;
+  using C = PPCfg<R_PAD, OPT, MODE>;
   constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, PF = C::PF;
   constexpr int NSTEP1 = C::NSTEP1, NSTEP2 = C::NSTEP2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,12 +90,16 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   const int m0 = mb * C::BM + wave * 32 + j;
 
   if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: saturate
-  // VAR & 128: stamps of wave 0 / wave 4 of workgroup 0 -- shader clock and the constant 100 MHz clock at kernel entry
-  // (slot 2), at the start (0) and the end (1) of the tile loop and at kernel exit (3): cycles per tile, the core
-  // frequency, and what the prologue / epilogue cost, unperturbed (nothing inside the loop)
-  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.loss_part);
+  // Diagnostic builds (make EXTRA=-DNMFMU_DEBUG_HOOKS; tools/pp_timeline.py): with a.debug set, wave 0 / wave 4 of
+  // workgroup 0 record the shader clock and the constant 100 MHz clock at kernel entry (slot 2), at the start (0) and
+  // the end (1) of the tile loop and at kernel exit (3) -- cycles per tile, the core frequency, what prologue and
+  // epilogue cost, unperturbed (nothing inside the loop); every workgroup records the 100 MHz clock at the four points
+  // ([64 + 5 wg + slot]) and where it ran ([.. + 4]: XCC_ID << 32 | HW_ID).
   auto stamp = [&](int slot) {
-    if constexpr ((VAR & 128) != 0 && MODE == kModeMU) {
+#ifdef NMFMU_DEBUG_HOOKS
+    if constexpr (MODE == kModeMU) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.debug);
+      if (!dbg) return;
       if (blockIdx.x == 0 && (wave & 3) == 0) {
         const unsigned long long c = __builtin_amdgcn_s_memtime();
         const unsigned long long r = __builtin_amdgcn_s_memrealtime();
@@ -125,8 +109,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           dbg[(half * 4 + slot) * 4 + 2] = (unsigned long long)nt;
         }
       }
-      // every workgroup: the 100 MHz clock at the four points ([64 + 5 * wg + slot]) and where it ran ([.. + 4]:
-      // XCC_ID << 32 | HW_ID) -- launch ramp and the spread of the workgroups' finishing times
       if (wave == 0) {
         const unsigned long long r = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
@@ -137,16 +119,9 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         }
       }
     }
+#endif
   };
   stamp(2);
-  auto pstamp = [&](int k) {   // VAR & 128: where the prologue's time goes (workgroup 0, wave 0; 100 MHz clock)
-    if constexpr ((VAR & 128) != 0 && MODE == kModeMU) {
-      if (blockIdx.x == 0 && wave == 0) {
-        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) dbg[40 + k] = r;
-      }
-    }
-  };
 
   // ---- owner fragments (B operand of G1): row m0, rank slice 16*kk + 8*hl .. +7
   // bf16: the fragments are scaled by 2^23 = 1 / eps (exact), so that the "+ eps" of nmf.py:65 becomes "+ 1.0" -- an
@@ -189,26 +164,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) b_base[tt][m2] = j * 128 + (((4 * hl + 2 * tt + m2) << 4) ^ (((j >> 1) & 7) << 4));
   static_assert((KS - 1) * 32 < ROWB, "k-step bits stay inside one P1 row");
-  // TR: ds_read_b64_tr_b16 works on groups of 16 lanes; lane 4a+b of a group receives element b of the 8-byte chunks
-  // addressed by lanes a, a+4, a+8, a+12 (probed on gfx950: tools/ubench/tr_probe.hip).  With source lane s = a + 4i
-  // pointing at (panel row k0 + i, ranks 4 (c0 + a) .. +3) the group reads a [4 rows] x [16 ranks] block and lane l
-  // ends up with rank 4 c0 + l for rows k0 .. k0+3: two such reads (rows +0..3 and +4..7) are the MFMA B operand of
-  // G2, whose lane (j, hl) needs the 8 contraction rows 32 hl + 16 tt + 8 m2 + (0..7) of rank 32 rt + j.
-  // t_base[tt][m2][h]: byte offset of this lane's chunk for rank tile 0; rank tile rt = XOR with rt * 64 (slot bits 2-3).
-  int t_base[2][2][2];
-  if constexpr (C::TR) {
-    const int grp = lane >> 4, s16 = lane & 15;
-    const int cslot = 2 * (grp & 1) + ((s16 & 3) >> 1);
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2);
-          t_base[tt][m2][h] = row * ROWB + ((cslot ^ P1Swz<R_PAD>::of(row)) << 4) + 8 * (s16 & 1);
-        }
-  }
 
   f32x16 acc[C::LOSS ? 1 : RT];
 #pragma unroll
@@ -247,8 +202,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
       for (int i = 0; i < C::ND; ++i) {
         const unsigned pc = (4u * i) % (unsigned)C::NPIECE;       // compile-time part of the piece index
-        const unsigned wpart = C::NPIECE >= 4 ? 0u : 0u;
-        (void)wpart;
         if constexpr (C::NPIECE >= 4)
           dma1k(src_tile + pc * 1024u, pvoff, lds_base + lds_off + pc * 1024u + (unsigned)(wave & 3) * 1024u);
         else
@@ -258,25 +211,16 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     };
     // ring slots advance by one per tile: offsets are carried incrementally (no division in the loop)
     unsigned p1_issue_off = (unsigned)(C::LEAD % C::NSLOT) * IMG;         // slot of P1(t + LEAD) at t = 0
-    constexpr int NS2 = C::NSLOT2 > 0 ? C::NSLOT2 : 1;
-    unsigned p2_issue_off = (unsigned)((C::LEAD - 1) % NS2) * IMG;        // slot of P2(t + LEAD - 1) at t = 0
+    unsigned p2_issue_off = (unsigned)((C::LEAD - 1) % C::NSLOT) * IMG;   // slot of P2(t + LEAD - 1) at t = 0
     auto next_off = [&](unsigned off) { return off == (unsigned)(C::NSLOT - 1) * IMG ? 0u : off + IMG; };
-    auto next_off2 = [&](unsigned off) { return off == (unsigned)(NS2 - 1) * IMG ? 0u : off + IMG; };
     auto issue_panel = [&](int t) {   // called in E(t) by waves 0-3: P1(t + LEAD), P2(t + LEAD - 1)
       dma_img(p1src + (size_t)clampt(t + C::LEAD) * IMG, C::P1_BASE + p1_issue_off);
-      if constexpr (!C::LOSS && !C::TR) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
+      if constexpr (!C::LOSS) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
     };
-    auto issue_x = [&](int t) {       // this wave's 4 KiB of X(t) -> X ring slot t & 1
-      const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
-      const unsigned dst = lds_base + C::X_BASE + (unsigned)(t & 1) * C::XTILE + (unsigned)wave * 4096u;
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) dma1k(src + qq * 1024, lane16, dst + qq * 1024u);
-    };
-    // register path (XREG): this wave's four 1-KiB pieces of X(t), one 16-byte chunk per lane each, loaded by asm so
-    // that hipcc neither counts nor waits for them; wait_x() is the counted wait that makes a buffer readable
-    const char* xsrc_l = xsrc;   // (wave-uniform)
+    // this wave's four 1-KiB pieces of X(t), one 16-byte chunk per lane each, loaded by asm so that hipcc neither
+    // counts nor waits for them; wait_x() is the counted wait that makes a buffer readable
     auto load_x = [&](int t, u32x4(&x)[4]) {
-      const char* src = xsrc_l + (size_t)clampt(t) * (size_t)C::XTILE;
+      const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
       asm volatile(
           "s_nop 4\n\t"
           "global_load_dwordx4 %0, %4, %5 nt\n\t"
@@ -305,57 +249,34 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     // with the ring-slot offset already added (loop variant, so nothing here is hoisted out of the tile loop).
     // They start at the slot of tile 0 (P1) / tile -1 (P2) and are advanced in place by +IMG or -(NSLOT-1)*IMG once per
     // tile (advance_slots), so the lane-only parts a_base / b_base are dead after this point.
+    constexpr int BACK = (C::NSLOT - 1) * IMG;   // slot of "tile -1" at the start
     int sa[2] = {a_base[0] + C::P1_BASE, a_base[1] + C::P1_BASE};
-    int sb[2][2];        // !TR: P2 slot of tile t-1
-    int tb[2][2][2];     //  TR: P1 slot of tile t-1
-    constexpr int BACK = C::TR ? (C::NSLOT - 1) * IMG : (NS2 - 1) * IMG;   // slot of "tile -1" at the start
+    int sb[2][2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        sb[tt][m2] = b_base[tt][m2] + C::P2_BASE + BACK;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) tb[tt][m2][h] = t_base[tt][m2][h] + C::P1_BASE + BACK;
-      }
-    int rd1 = 0, rd2 = BACK;   // current slot offsets of sa / (sb | tb) (uniform)
-    auto advance_slots = [&]() {   // sa -> P1 slot of the next tile, sb / tb -> slot of the tile before it
-      constexpr int LAST1 = (C::NSLOT - 1) * IMG, LAST2 = C::TR ? LAST1 : (NS2 - 1) * IMG;
-      const int d1 = rd1 == LAST1 ? -LAST1 : IMG;
-      const int d2 = rd2 == LAST2 ? -LAST2 : IMG;
+      for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] = b_base[tt][m2] + C::P2_BASE + BACK;
+    int rd1 = 0, rd2 = BACK;   // current slot offsets of sa / sb (uniform)
+    auto advance_slots = [&]() {   // sa -> P1 slot of the next tile, sb -> P2 slot of the tile before it
+      const int d1 = rd1 == BACK ? -BACK : IMG;
+      const int d2 = rd2 == BACK ? -BACK : IMG;
       rd1 += d1, rd2 += d2;
       sa[0] += d1, sa[1] += d1;
       if constexpr (!C::LOSS) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2) {
-            if constexpr (C::TR) {
-              tb[tt][m2][0] += d2, tb[tt][m2][1] += d2;
-            } else {
-              sb[tt][m2] += d2;
-            }
-          }
+          for (int m2 = 0; m2 < 2; ++m2) sb[tt][m2] += d2;
       }
     };
     // The M segment is written instruction by instruction (asm volatile keeps the order): hipcc's scheduler re-orders a
     // builtin MFMA / ds_read stream and degrades the counted LDS waits to lgkmcnt(0).  Entry e of the operand stream
     // lives in ring[e % PF]; LDS returns in order, so "entry e has landed" = at most min(PF-1, NS-1-e) younger reads
     // outstanding.
-    // TR mode: every LDS read is an ordinary (compiler-visible) load, so that hipcc assembles the 128-bit operand from
-    // the two 64-bit transposing reads without copies and counts lgkmcnt itself; the MFMAs stay asm volatile, which
-    // keeps loads and MFMAs in program order.
-    using s16x4 = __attribute__((ext_vector_type(4))) short;
-    using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-    const unsigned smem_u = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto rd = [&](u32x4& dst, int addr, auto offc) {
-      if constexpr (C::TR) dst = ld16(smem + addr + decltype(offc)::value);
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
     };
-    auto rd_tr = [&](int addr) -> u32x2 {
-      auto* p = (__attribute__((address_space(3))) s16x4*)(size_t)(smem_u + (unsigned)addr);
-      return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(p));
-    };
-    auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read(s) of stream entry e
+    auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read of stream entry e
       constexpr int e0 = decltype(ec)::value;
       constexpr bool g1 = decltype(g1c)::value;
       if constexpr (g1 && e0 < NSTEP1) {
@@ -363,12 +284,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       } else {
         constexpr int e = e0 - (g1 ? NSTEP1 : 0);
         constexpr int rt = e % RT, c = e / RT;
-        if constexpr (C::TR) {
-          const u32x2 lo = rd_tr(tb[c >> 1][c & 1][0] ^ (rt * 64)), hi = rd_tr(tb[c >> 1][c & 1][1] ^ (rt * 64));
-          dst = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        } else {
-          rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
-        }
+        rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
       }
     };
     auto prefetch = [&](auto g1c) {   // first PF operands of the next M segment; issued in the preceding E segment
@@ -378,23 +294,14 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
     };
-    auto mma_acc = [&](f32x16& d, const u32x4& x, const u32x4& y) {   // G2: accumulators optionally in AGPRs
-      if constexpr ((VAR & 8192) != 0) {
-        if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(x), "v"(y));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(x), "v"(y));
-      } else {
-        mma(d, x, y);
-      }
-    };
-    // M(t): G1(t) if g1, then G2(t-1) if g2; ends with the counted wait for the panel DMA of the previous E segment
+    // M(t): G1(t) if g1, then G2(t-1) if g2
     auto matrix_segment = [&](auto g1c, auto g2c) {
       constexpr bool g1 = decltype(g1c)::value, g2 = decltype(g2c)::value && !C::LOSS;
       constexpr int N1 = g1 ? NSTEP1 : 0, N2 = g2 ? NSTEP2 : 0, NS = N1 + N2;
-      if constexpr (VAR & 1) asm volatile("s_setprio 3");
       static_for<NS>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         constexpr int younger = (NS - 1 - e) < (PF - 1) ? (NS - 1 - e) : (PF - 1);
-        if constexpr (!C::TR) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
         u32x4& op = ring[e % PF];
         if constexpr (e < N1) {
           constexpr int tt = e & 1, kk = e >> 1;
@@ -402,59 +309,39 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
             if constexpr (SCALED)
               asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=&v"(S[tt]) : "v"(op), "v"(q[0]));
             else
-              if constexpr (OPT == kOpF16)
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
-              else
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
+              asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
           } else {
-            if constexpr (!(VAR & 64)) mma(S[tt], op, q[kk]);
+            mma(S[tt], op, q[kk]);
           }
         } else {
           constexpr int s2 = e - N1;
           constexpr int rt = s2 % RT, c = s2 / RT, tt = c >> 1, m2 = c & 1;
           const u32x4 nh = {gn[tt][4 * m2], gn[tt][4 * m2 + 1], gn[tt][4 * m2 + 2], gn[tt][4 * m2 + 3]};
-          if constexpr (!(VAR & 64)) mma_acc(acc[rt], nh, op);
+          mma(acc[rt], nh, op);
         }
         if constexpr (e + PF < NS) opnd(ring[e % PF], std::integral_constant<int, e + PF>{}, g1c);
       });
-      if constexpr (VAR & 1) asm volatile("s_setprio 0");
       // asm MFMAs are not padded by hipcc: when no G2 follows G1, the S tiles are read by the VALU right after the
       // barrier -- cover the XDL write -> VALU read distance (18 wait states for a 16-pass MFMA) here
       if constexpr (g1 && N2 == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-      if constexpr (VAR & (8 | 16 | 1024 | 2048)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if constexpr (!C::XREG) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
     // E(t): ratios of tile t from S and X(t); operand prefetch for the next M segment, panel DMA (waves 0-3) and this
-    // wave's X piece two tiles ahead
+    // wave's X piece two tiles ahead.  tail (the last two tiles): nothing is prefetched past the end -- an asm load
+    // whose result is never read would land in registers hipcc has already handed to something else
     auto elementwise_segment = [&](int t, auto nextc, u32x4(&x)[4], auto tailc) {
       constexpr bool next_has_g1 = decltype(nextc)::value;
-      // XREG tail (the last two tiles): nothing is prefetched past the end -- an asm load whose result is never read
-      // would land in registers hipcc has already handed to something else
       constexpr bool tail = decltype(tailc)::value;
-      if constexpr (!C::XREG) {
-        const char* xl = smem + C::X_BASE + (t & 1) * C::XTILE + wave * 4096 + lane * 16;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) x[qq] = ld16(xl + qq * 1024);
-      }
       advance_slots();
       if constexpr (next_has_g1) prefetch(std::true_type{});
       else if constexpr (!C::LOSS) prefetch(std::false_type{});
-      if constexpr (!(VAR & 4) && !(VAR & 16)) {
-        if constexpr (!tail) {
-          if (!half) issue_panel(t);
-          if constexpr ((VAR & 1024) != 0) {
-            if (!half) issue_panel(t);
-          }
-        } else if constexpr (next_has_g1 && !C::LOSS && !C::TR) {   // tile nt-2: only P2(nt-1) is still needed
-          if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
-        }
+      if constexpr (!tail) {
+        if (!half) issue_panel(t);
+      } else if constexpr (next_has_g1 && !C::LOSS) {   // tile nt-2: only P2(nt-1) is still needed
+        if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
       }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        if constexpr ((VAR & 32) != 0) {
-#pragma unroll
-          for (int d = 0; d < 8; ++d) gn[tt][d] = x[2 * tt + (d >> 2)][d & 3];
-        } else if constexpr (C::LOSS) {
+        if constexpr (C::LOSS) {
 #pragma unroll
           for (int d = 0; d < 8; ++d) {
             const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
@@ -500,96 +387,46 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           }
         }
       }
-      if constexpr ((VAR & 4) && !(VAR & 16)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!tail) {
-          if (!half) issue_panel(t);
-        } else if constexpr (next_has_g1 && !C::LOSS && !C::TR) {
-          if (!half) dma_img(p2src + (size_t)(t + 1) * IMG, C::P2_BASE + p2_issue_off);
-        }
-      }
       p1_issue_off = next_off(p1_issue_off);
-      p2_issue_off = next_off2(p2_issue_off);
+      p2_issue_off = next_off(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
-      if constexpr (!(VAR & 8) && !tail) {        // ... before its slot / register buffer is refilled
-        if constexpr (C::XREG) load_x(t + 2, x);
-        else issue_x(t + 2);
-        if constexpr ((VAR & 2048) != 0 && C::XREG) load_x(t + 2, x);
-      }
+      if constexpr (!tail) load_x(t + 2, x);   // ... before its register buffer is refilled
     };
 
     // ---- prologue: P1(0), P1(1), P2(0), X(0), X(1); everything landed before the first barrier
-    pstamp(0);
     if (!half) {
 #pragma unroll
       for (int i = 0; i < C::LEAD; ++i) dma_img(p1src + (size_t)clampt(i) * IMG, C::P1_BASE + i * IMG);
-      if constexpr (!C::LOSS && !C::TR) {
+      if constexpr (!C::LOSS) {
 #pragma unroll
         for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
       }
     }
-    // partials mode: the panel's column sums (nmf.py:122-131) arrive as kl_nparts per-stripe partial sums; every
-    // workgroup reduces them itself -- here, in the shadow of the first tiles' DMA latency.  Four interleaved streams
-    // per column, eight loads in flight per thread, combined in a fixed order (identical bits in every workgroup).
-    if constexpr (!C::LOSS) {
-      if (a.fuse_apply && a.kl_part) {
-        float* kls = reinterpret_cast<float*>(smem + C::KL_OFF);   // [R_PAD] sums, then [4][R_PAD] stream sums
-        for (int idx = tid; idx < 4 * R_PAD; idx += C::THREADS) {
-          const int qq = idx / R_PAD, r = idx - qq * R_PAD;
-          const float* src = a.kl_part + (size_t)qq * R_PAD + r;
-          float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          int pp = qq;
-          for (; pp + 28 < a.kl_nparts; pp += 32, src += 32 * R_PAD) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)u * 4 * R_PAD];
-          }
-          for (; pp < a.kl_nparts; pp += 4, src += 4 * R_PAD) s8[0] += src[0];
-          kls[R_PAD + idx] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        }
-        __syncthreads();
-        for (int r = tid; r < R_PAD; r += C::THREADS)
-          kls[r] = (kls[R_PAD + r] + kls[2 * R_PAD + r]) + (kls[3 * R_PAD + r] + kls[4 * R_PAD + r]);
-      }
-    }
-    u32x4 xA[4], xB[4];   // XREG: X(even tiles) / X(odd tiles); otherwise xA is the per-segment scratch copy
-    if constexpr (C::XREG) {
-      load_x(0, xA);
-      load_x(1, xB);
-      load_owner();
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
-    } else {
-      issue_x(0);
-      issue_x(1);
-      load_owner();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    pstamp(1);
+    u32x4 xA[4], xB[4];   // X(even tiles) / X(odd tiles)
+    load_x(0, xA);
+    load_x(1, xB);
+    load_owner();
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
     scale_owner();
-    if constexpr (VAR & 2) {
-      if (half) __builtin_amdgcn_s_setprio(1);
-    }
     barrier();
-    pstamp(2);
     prefetch(std::true_type{});
     if (half) barrier();                       // waves 4-7 run one segment behind
     matrix_segment(std::true_type{}, std::false_type{});
     stamp(0);
-    // one tile = barrier, E(t), barrier, M(t+1).  `xc` holds X(t); with XREG the wait that ends M(t+1) names the
-    // buffer the NEXT elementwise segment reads.  The last tile is peeled (a join of two differently shaped M
-    // segments inside the loop would cost a register copy of every accumulator per tile).
+    // one tile = barrier, E(t), barrier, M(t+1).  `xc` holds X(t); the wait that ends M(t+1) names the buffer the NEXT
+    // elementwise segment reads.  The last tile is peeled (a join of two differently shaped M segments inside the loop
+    // would cost a register copy of every accumulator per tile).
     auto tile_full = [&](int t, u32x4(&xc)[4], u32x4(&xn)[4], auto tailc) {
       constexpr bool tail = decltype(tailc)::value;
       barrier();
       elementwise_segment(t, std::true_type{}, xc, tailc);
       barrier();
       matrix_segment(std::true_type{}, std::true_type{});
-      if constexpr (C::XREG && !(VAR & (8 | 16 | 1024 | 2048))) {
-        if constexpr (tail)   // nothing younger than X(t+1) except tail panel pieces: drain
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
-        else
-          wait_x(xn);
-      }
+      if constexpr (tail)   // nothing younger than X(t+1) except tail panel pieces: drain
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+      else
+        wait_x(xn);
     };
     auto tile_last = [&](int t, u32x4(&xc)[4], auto tailc) {
       barrier();
@@ -597,26 +434,20 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       barrier();
       matrix_segment(std::false_type{}, std::true_type{});
     };
-    if constexpr (C::XREG) {
-      // static register buffers => the tile loop is unrolled by two; the host gives every workgroup an EVEN number of
-      // tiles (tiles_per_split is rounded up to even, the padded contraction length is a multiple of 256), so there is
-      // one straight-line tail and no join of differently shaped paths
-      int t = 0;
-      for (; t + 2 < nt; t += 2) {
-        tile_full(t, xA, xB, std::false_type{});
-        tile_full(t + 1, xB, xA, std::false_type{});
-      }
-      tile_full(t, xA, xB, std::true_type{});
-      tile_last(t + 1, xB, std::true_type{});
-    } else {
-      for (int t = 0; t + 1 < nt; ++t) tile_full(t, xA, xA, std::false_type{});
-      tile_last(nt - 1, xA, std::false_type{});
+    // static register buffers => the tile loop is unrolled by two; the host gives every workgroup an EVEN number of
+    // tiles (tiles_per_split is rounded up to even, the padded contraction length is a multiple of 256), so there is
+    // one straight-line tail and no join of differently shaped paths
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+      tile_full(t, xA, xB, std::false_type{});
+      tile_full(t + 1, xB, xA, std::false_type{});
     }
+    tile_full(t, xA, xB, std::true_type{});
+    tile_last(t + 1, xB, std::true_type{});
     stamp(1);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read of the accumulators (asm MFMAs are not padded)
     if (!half) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches: nothing may land in LDS after this
-    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();               // LDS is reused by the epilogue
 
@@ -653,13 +484,8 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       // 16-byte row-major image store per chunk, denominators and column sums of those 8 ranks in registers
       const int slot_e = lane_e % SP, rl0 = lane_e / SP;
       float den8[8], csum8[8];
-      {
-        const float* dsrc = a.kl_part ? reinterpret_cast<const float*>(smem + C::KL_OFF) : a.kl_den;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { den8[k] = dsrc[slot_e * 8 + k]; csum8[k] = 0.f; }
-        // (beta == 1 partials were reduced in the prologue into LDS beyond the rings; read before the tile is written)
-        if (a.kl_part) __syncthreads();
-      }
+      for (int k = 0; k < 8; ++k) { den8[k] = a.kl_den[slot_e * 8 + k]; csum8[k] = 0.f; }
       // numerators -> the wave's staging tile [32][R_PAD]
       static_for<RT>([&](auto rtc) {
         constexpr int rt = decltype(rtc)::value;
@@ -762,17 +588,17 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       });
     }
   }
-  if constexpr ((VAR & 128) != 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
-    stamp(3);
-  }
+#ifdef NMFMU_DEBUG_HOOKS
+  if (a.debug) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
+  stamp(3);
+#endif
 }
 
-template <int R_PAD, int OPT, int MODE, int VAR>
+template <int R_PAD, int OPT, int MODE>
 int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
-  using C = PPCfg<R_PAD, OPT, MODE, VAR>;
+  using C = PPCfg<R_PAD, OPT, MODE>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
-  auto kern = pp_kernel<R_PAD, OPT, MODE, VAR>;
+  auto kern = pp_kernel<R_PAD, OPT, MODE>;
   static bool done[64] = {};
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -785,8 +611,8 @@ int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// Host-side launcher (nmfmu_inst_pp.hip).  opt = OperandType, mode = kModeMU | kModeLoss, var = experiment bits.
-int launch_pp(int r_pad, int opt, int mode, int var, const FusedArgs& a, int grid, hipStream_t s);
+// Host-side launcher (nmfmu_inst_pp.hip).  opt = OperandType, mode = kModeMU | kModeLoss.
+int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s);
 bool pp_available(int r_pad, int opt, int mode);
 
 }  // namespace nmfmu

@@ -53,7 +53,7 @@ class GemmDesc(C.Structure):
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32)]
 
 
-ABI_VERSION = 3   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 4   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
@@ -77,11 +77,9 @@ SIGNATURES = {
     'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_den_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_mu_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_void_p]),
-    'nmfmu_parts_supported': (C.c_int, [C.POINTER(Step)]),
     'nmfmu_colsum_nparts': (C.c_int, [C.POINTER(Step)]),
     'nmfmu_pack_nparts': (C.c_int, [C.c_int]),
     'nmfmu_colsum_finalize': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_void_p]),
-    'nmfmu_mu_step_parts': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_slab_reduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_mu_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_trainer_apply': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,

@@ -86,7 +86,6 @@ class HipBackend:
         _capi.check(self.lib.nmfmu_pack_factor(C.byref(fac.struct), rank, r_pad, precision, self.stream()),
                     'nmfmu_pack_factor')
         fac.nparts = self.lib.nmfmu_pack_nparts(fac.rows_pad)
-        fac.colsum_stale = False
 
     def mu_partial(self, st: 'StepBuf'):
         _capi.check(self.lib.nmfmu_mu_partial(C.byref(st.struct), self.stream()), 'nmfmu_mu_partial')
@@ -95,21 +94,10 @@ class HipBackend:
         _capi.check(self.lib.nmfmu_mu_step(C.byref(st.struct), _ptr(kl_den), phase, self.stream()), 'nmfmu_mu_step')
         if phase != 1:
             st.owner.nparts = self.lib.nmfmu_colsum_nparts(C.byref(st.struct))
-            st.owner.colsum_stale = False
-
-    def mu_step_parts(self, st: 'StepBuf', panel: 'FactorBuf', phase=0):
-        _capi.check(self.lib.nmfmu_mu_step_parts(C.byref(st.struct), _ptr(panel.colsum_part), panel.nparts, phase,
-                                                 self.stream()), 'nmfmu_mu_step_parts')
-        st.owner.nparts = self.lib.nmfmu_colsum_nparts(C.byref(st.struct))
-        st.owner.colsum_stale = True
-
-    def parts_supported(self, st: 'StepBuf') -> bool:
-        return bool(self.lib.nmfmu_parts_supported(C.byref(st.struct)))
 
     def colsum_finalize(self, fac: 'FactorBuf', r_pad):
         _capi.check(self.lib.nmfmu_colsum_finalize(C.byref(fac.struct), fac.nparts, r_pad, self.stream()),
                     'nmfmu_colsum_finalize')
-        fac.colsum_stale = False
 
     def slab_reduce(self, st, num_out, den_out):
         _capi.check(self.lib.nmfmu_slab_reduce(C.byref(st.struct), _ptr(num_out), _ptr(den_out), self.stream()),
@@ -119,13 +107,11 @@ class HipBackend:
         _capi.check(self.lib.nmfmu_mu_apply(C.byref(st.struct), _ptr(num), _ptr(den), nslab, _ptr(kl_den),
                                             self.stream()), 'nmfmu_mu_apply')
         st.owner.nparts = self.lib.nmfmu_pack_nparts(st.owner.rows_pad)
-        st.owner.colsum_stale = False
 
     def trainer_apply(self, st, kl_den, ortho, grad):
         _capi.check(self.lib.nmfmu_trainer_apply(C.byref(st.struct), None, None, 0, _ptr(kl_den), float(ortho),
                                                  _ptr(grad), self.stream()), 'nmfmu_trainer_apply')
         st.owner.nparts = self.lib.nmfmu_pack_nparts(st.owner.rows_pad)
-        st.owner.colsum_stale = False
 
     def loss(self, st, loss_part, out):
         _capi.check(self.lib.nmfmu_loss(C.byref(st.struct), _ptr(loss_part), _ptr(out), self.stream()), 'nmfmu_loss')
@@ -167,29 +153,6 @@ class KernelTimer:
             self.h = C.c_void_p()
 
 
-def capture_iteration(fn, group=None):
-    """Capture ``fn`` (one MU iteration: a fixed sequence of launches on fixed buffers) into a hipGraph and return
-    the ``torch.cuda.CUDAGraph``.  Opt-in (TORCHNMF_AMD_GRAPH=1): measured on MI355X / ROCm 7 the replay is no
-    faster than eager launches -- 2 439 vs 2 502 it/s at BASELINE configs[1], 39.9k vs 42.7k it/s at configs[0],
-    1 714 vs 1 715 it/s for NMFD configs[3] -- because the gaps between the dependent kernels of an iteration are
-    device-side dispatch latency, not host launch cost (the host is ~3x ahead of the device at configs[1]).
-    Must be called after ``fn`` has run once eagerly (kernel attributes are set on first launch).  Returns None
-    when graphs are not enabled, on the sharded path (the all-reduce stays eager) or if capture fails."""
-    import os
-    import warnings
-    if group is not None or os.environ.get('TORCHNMF_AMD_GRAPH', '0') != '1' or not torch.cuda.is_available():
-        return None
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn()
-        return g
-    except Exception as e:  # pragma: no cover - depends on the runtime
-        warnings.warn(f'torchnmf_amd: hipGraph capture failed ({e}); running launches eagerly')
-        torch.cuda.synchronize()
-        return None
-
-
 class FactorBuf:
     """Device state of one factor: the fp32 master (the nn.Parameter's storage) plus its bf16 images."""
 
@@ -208,7 +171,6 @@ class FactorBuf:
         self.colsum = torch.zeros(r_pad, dtype=torch.float32, device=dev)
         self.colsum_part = torch.zeros((self.rows_pad // 16) * r_pad, dtype=torch.float32, device=dev)
         self.nparts = 0               # valid partial column sums in colsum_part (set by whoever wrote them last)
-        self.colsum_stale = False     # colsum lags behind colsum_part (nmfmu_mu_step_parts skips the finalize launch)
         self.struct = _capi.Factor(_ptr(self.f), _ptr(self.p1_hi), _ptr(self.p1_lo), _ptr(self.p2_hi),
                                    _ptr(self.p2_lo), _ptr(self.colsum), _ptr(self.colsum_part), self.rows,
                                    self.rows_pad)
@@ -291,6 +253,13 @@ class DenseMU:
     F16_MAX_ABS = 3.0e4
     F16_MIN_MEAN = 2.0 ** -10
 
+    @classmethod
+    def f16_in_range(cls, V, W, H) -> bool:
+        """One pass over V, W, H and one host sync: do they sit inside fp16's range with room for the ratios?"""
+        stats = torch.stack([V.max(), V.mean(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
+        vmax, vmean, wmax, hmax, wmean, hmean = stats
+        return max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
+
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
                  update_W=True, update_H=True, block_rows=None, allow_f16=False):
         self.be = backend if backend is not None else DEFAULT_BACKEND_FACTORY()
@@ -305,24 +274,36 @@ class DenseMU:
         self.rank = R
         self.r_pad = self.be.pad_rank(R)
         if precision in (None, 'auto'):
-            precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
-            if (allow_f16 and self.kl and group is None and min(N, Cc) >= self.F16_MIN_DIM
-                    and hasattr(_capi, 'PREC_F16') and self.be.supported(self.r_pad, _capi.PREC_F16)
-                    and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0'):
-                # one pass over V, W, H and one host sync (fit() syncs on the validation flags anyway)
-                stats = torch.stack([V.max(), V.mean(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
-                vmax, vmean, wmax, hmax, wmean, hmean = stats
-                if (max(vmax, wmax, hmax) <= self.F16_MAX_ABS and min(vmean, wmean, hmean) >= self.F16_MIN_MEAN):
+            # 'auto' = the fastest mode that meets the reference's 1e-4 bar -- never the plain bf16 mode:
+            # fp16 operands (1x MFMA work) where the contraction lengths average the rounding errors down and the data
+            # fit fp16's range (sharded: every rank must decide alike, so the range test is all-reduced), else split
+            # bf16 (3x MFMA work, fp32-grade, padded rank <= 128), else an error.
+            precision = None
+            f16_ok = (allow_f16 and min(N, Cc) >= self.F16_MIN_DIM and hasattr(_capi, 'PREC_F16')
+                      and self.be.supported(self.r_pad, _capi.PREC_F16)
+                      and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0')
+            if f16_ok:
+                ok = self.f16_in_range(V, W, H)
+                if group is not None:
+                    import torch.distributed as dist
+                    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=V.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                    ok = int(flag.item()) == 0
+                if ok:
                     precision = 'f16'
+            if precision is None:
+                if not self.be.supported(self.r_pad, _capi.PREC_BF16X3):
+                    raise NotImplementedError(
+                        f"precision='auto' found no mode for rank {R} that meets the 1e-4 parity bar on the fused kernels "
+                        f"(fp16 operands need both dimensions >= {self.F16_MIN_DIM} and data within fp16's range; split "
+                        f"bf16 stops at rank 128); pass precision='bf16' (factors ~1e-3) or 'f16' explicitly")
+                precision = 'bf16x3'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
         self.precision_name = precision
         self.precision = _capi.PRECISIONS[precision]
         if not self.be.supported(self.r_pad, self.precision):
             raise NotImplementedError(f'precision {precision!r} is not available for rank {R} (padded {self.r_pad})')
-        if precision == 'f16' and not self.kl:
-            raise NotImplementedError("precision 'f16' (fp16 operands, ping-pong kernel) is built for beta == 1 only; "
-                                      "use 'bf16x3' (fp32-grade) or 'bf16' for other beta")
         if stage is None:
             stage = _capi.STAGE_DMA
         gamma = mu_gamma(self.beta)
@@ -355,7 +336,6 @@ class DenseMU:
             self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, brw, self.beta,
                                   gamma, l1, l2, need_den=not self.kl)
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
-        self.graphable = isinstance(self.be, HipBackend) and group is None   # an iteration can be replayed as a hipGraph
         self.refresh_images()
         self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -393,36 +373,8 @@ class DenseMU:
         bad, mn = (int(x) for x in fl.tolist())
         return bool(bad), mn == 0
 
-    def _parts_ok(self, st):
-        """Opt-in (NMFMU_PARTS=1): beta == 1 half-steps on the ping-pong kernel hand the column sums over as partials,
-        which removes the two colsum_finalize launches per iteration.  Measured on MI355X: 0.3124 vs 0.3113 ms per
-        iteration at configs[1] -- the 5 us launches were already hidden -- so the finalize path stays the default."""
-        if not (self.kl and self.group is None and hasattr(self.be, 'parts_supported')):
-            return False
-        ok = getattr(st, '_parts_ok', None)
-        if ok is None:
-            ok = st._parts_ok = bool(self.be.parts_supported(st)) and os.environ.get('NMFMU_PARTS', '0') == '1'
-        return ok and st.panel.nparts > 0
-
-    def ensure_colsums(self):
-        """Bring W / H .colsum up to date after half-steps that left only partials behind."""
-        for f in (self.fW, self.fH):
-            if getattr(f, 'colsum_stale', False):
-                self.be.colsum_finalize(f, self.r_pad)
-
     def _local_step(self, st, kl_den, tag):
         """A complete single-device half-step (nmfmu_mu_step); with a timer attached the fused kernel is bracketed."""
-        if self._parts_ok(st):
-            if self.timer is None:
-                self.be.mu_step_parts(st, st.panel, 0)
-            else:
-                self.timer.mark(tag + '<')
-                self.be.mu_step_parts(st, st.panel, 1)
-                self.timer.mark(tag + '>')
-                self.be.mu_step_parts(st, st.panel, 2)
-            return
-        if getattr(st.panel, 'colsum_stale', False):
-            self.be.colsum_finalize(st.panel, self.r_pad)
         if not hasattr(self.be, 'mu_step'):          # stand-in test backend
             self.be.mu_partial(st)
             self.be.mu_apply(st, None, None, 0, kl_den)
@@ -452,7 +404,6 @@ class DenseMU:
         if self.group is None:
             self._local_step(st, self.fW.colsum if self.kl else None, 'h')
             return
-        self.ensure_colsums()
         import torch.distributed as dist
         num = self.xbuf[:st.plane]
         tail = self.xbuf[st.plane:]
@@ -502,7 +453,6 @@ class DenseMU:
             raise NotImplementedError('BetaMu on a column-sharded layer is not implemented')
         st = self.step_w if which == 'W' else self.step_h
         assert st is not None
-        self.ensure_colsums()
         other = self.fH if which == 'W' else self.fW
         self._partial(st, which.lower())
         self.be.trainer_apply(st, other.colsum if self.kl else None, ortho, grad)

@@ -121,9 +121,9 @@ class BaseComponent(nn.Module):
 
         Extra keyword-only arguments (not in the reference):
           precision      None / 'auto' (default): the fastest mode that meets the reference's 1e-4 bar -- 'f16'
-                         (fp16 operands, bf16's MFMA rate) for beta == 1, rank <= 128, both dimensions >= 2048
-                         and data inside fp16's range, otherwise 'bf16x3' (split-bf16 MFMA, matches the fp32
-                         reference to ~1e-5; above rank 128 on the GEMM engine).  Explicit: 'f16', 'bf16x3',
+                         (fp16 operands, bf16's MFMA rate) when both dimensions are >= 2048, rank <= 256 and the data
+                         sit inside fp16's range, otherwise 'bf16x3' (split-bf16 MFMA, matches the fp32 reference to
+                         ~1e-5; above rank 128 on the GEMM engine).  Never plain bf16.  Explicit: 'f16', 'bf16x3',
                          'bf16' (V and operands rounded to bf16: objective within 1e-4, factors ~1e-3).
                          The environment variable TORCHNMF_AMD_PRECISION overrides the default.
           process_group  a torch.distributed group: V and W are then this rank's column shard
@@ -170,22 +170,11 @@ class BaseComponent(nn.Module):
             pbar = tqdm(total=max_iter)
         n_iter = -1
         try:
-            def iteration():
+            for n_iter in range(max_iter):
                 if W.requires_grad:
                     eng.w_step()
                 if H.requires_grad:
                     eng.h_step()
-            graph = None
-            for n_iter in range(max_iter):
-                if graph is not None:
-                    graph.replay()
-                else:
-                    iteration()
-                    if n_iter == 0 and max_iter > 2 and getattr(eng, 'graphable', False):
-                        # the launches of an iteration never change: optionally replay them as one hipGraph
-                        # (TORCHNMF_AMD_GRAPH=1; see capture_iteration for why it is not the default)
-                        from .engine import capture_iteration
-                        graph = capture_iteration(iteration, process_group)
                 if n_iter % 10 == 9:
                     loss = _sqrt2(eng.divergence())
                     if pbar is not None:
@@ -235,16 +224,27 @@ class NMF(BaseComponent):
             if not p.data.is_contiguous():
                 p.data = p.data.contiguous()
         R = self.W.shape[1]
-        # The fused kernel keeps rank-wide accumulators in registers: bf16 operands up to rank 256, the fp32-grade
-        # split-bf16 mode up to rank 128.  Everything else runs on the GEMM engine (NMF = the T = 1 member of the
-        # NMFD family), which has no rank limit.  'auto' means "meets the 1e-4 parity bar", so it leaves the fused
-        # kernel at rank 129 already; precision='bf16' keeps the fast kernel up to rank 256.
-        wide = R > 256 or (R > 128 and precision in (None, 'auto', 'bf16x3'))
+        # The fused kernels keep rank-wide accumulators in registers: single-plane operands (fp16 / bf16) up to rank 256,
+        # the fp32-grade split-bf16 mode up to rank 128.  Everything else runs on the GEMM engine (NMF = the T = 1 member
+        # of the NMFD family), which has no rank limit but is not sharded.  'auto' means "meets the 1e-4 parity bar":
+        # at rank 129..256 that is the fp16 mode of the fused kernel when DenseMU's size / range test admits it, else
+        # (unsharded) the GEMM engine, else (sharded) an error -- never silently the plain bf16 mode.
+        auto = precision in (None, 'auto')
+        wide = R > 256 or (R > 128 and precision == 'bf16x3')
+        if R > 128 and R <= 256 and auto:
+            from .engine import DenseMU as _D
+            f16_ok = (min(V.shape) >= _D.F16_MIN_DIM and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0')
+            if group is None:
+                wide = not (f16_ok and _D.f16_in_range(V, self.W.data, self.H.data))
+                if not wide:
+                    precision = 'f16'
+            elif not f16_ok:
+                raise NotImplementedError(
+                    "precision='auto' on a column-sharded fit at rank 129..256 needs the fp16 mode (both dimensions >= "
+                    f"{_D.F16_MIN_DIM}, data within fp16's range); pass precision='bf16' (factors ~1e-3) explicitly")
         if wide and group is not None:
-            if R > 256 or precision == 'bf16x3':
-                raise NotImplementedError('column sharding is implemented for the fused kernels (rank <= 256; '
-                                          'bf16x3 up to rank 128)')
-            wide, precision = False, 'bf16'           # sharded 'auto' at rank 129..256: the fused bf16 kernel
+            raise NotImplementedError('column sharding is implemented for the fused kernels (rank <= 256; bf16x3 up to '
+                                      'rank 128)')
         if wide:
             from .nmfd_engine import WideRankMU
             return WideRankMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,

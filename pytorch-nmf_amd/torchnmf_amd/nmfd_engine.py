@@ -186,7 +186,6 @@ class ConvMU:
         nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
         self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.graphable = True   # fixed launches on fixed buffers: fit() replays an iteration as one hipGraph
         self.refresh_images()
 
     # ------------------------------------------------------------------ helpers
@@ -360,7 +359,6 @@ class WideRankMU:
     (C, R, 1), H^T as (1, R, N) -- and runs on the GEMM engine, whose effective rank R*T is unbounded.  W shares
     storage with the parameter; H is kept transposed and copied back after every H half-step (N x R floats)."""
 
-    graphable = False
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True):
         assert V.dim() == 2 and W.dim() == 2 and H.dim() == 2

@@ -40,7 +40,6 @@ def _csr(rows: torch.Tensor, cols: torch.Tensor, vals: torch.Tensor, n_rows: int
 class SparseMU:
     """Same interface as ``DenseMU`` (target_flags / w_step / h_step / divergence) for a sparse target."""
 
-    graphable = False
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, update_W=True, update_H=True):
         self.be = DEFAULT_BACKEND_FACTORY()

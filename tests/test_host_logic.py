@@ -118,12 +118,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_static_queries():
     lib = _capi.load()
-    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 3
+    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 4
     assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
     assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
     assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED
     assert [lib.nmfmu_beta_kind(b) for b in (1.0, 2.0, 0.0, 0.5, -1.0)] == [0, 1, 2, 3, 3]
     assert lib.nmfmu_supported(128, _capi.PREC_BF16X3) == 1 and lib.nmfmu_supported(256, _capi.PREC_BF16X3) == 0
+    assert lib.nmfmu_supported(256, _capi.PREC_F16) == 1 and lib.nmfmu_supported(256, _capi.PREC_BF16) == 1
+    # tile heights: the eight-wave ping-pong kernel (256 rows) serves beta == 1 with one operand plane up to rank pad 128
+    assert lib.nmfmu_block_rows(128, _capi.PREC_F16, 1.0) == 256 and lib.nmfmu_block_rows(128, _capi.PREC_BF16, 1.0) == 256
+    assert lib.nmfmu_block_rows(128, _capi.PREC_F16, 2.0) == 128 and lib.nmfmu_block_rows(256, _capi.PREC_F16, 1.0) == 128
+    assert lib.nmfmu_block_rows(128, _capi.PREC_BF16X3, 1.0) == 128
+    assert lib.nmfmu_debug_set_buffer(None) == _capi.ERR_UNSUPPORTED   # diagnostic hook: NMFMU_DEBUG_HOOKS builds only
     assert lib.nmfmu_choose_nsplit(4096, 65536, 128, 256) == 16      # 32 owner blocks x 16 chunks = 512 workgroups
     assert lib.nmfmu_choose_nsplit(65536, 4096, 128, 256) == 1
     assert lib.nmfmu_choose_nsplit(256, 256, 128, 256) == 1          # tiny problems are not split below 4 tiles
@@ -308,29 +314,39 @@ def test_betamu_argument_checks_and_unsupported_graphs(cpu_engine):
     assert rel_err(m2.W.data, W_ref) < 5e-6
 
 
-@pytest.mark.parametrize('unit', ['nmfmu_inst_r128', 'nmfmu_inst_r256'])
+@pytest.mark.parametrize('unit', ['nmfmu_inst_r128', 'nmfmu_inst_r256', 'nmfmu_inst_pp'])
 def test_fused_kernels_do_not_spill_to_scratch(tmp_path, unit):
     """Guard: the fused kernels must keep their accumulators in registers.  A runtime-indexed register array silently
     moves to scratch memory AND is kept up to date from inside the main loop: the padded-rank-256 kernels ran 3x slower
     that way until their epilogue loops became compile-time (static_for).  Checked with the library's own flags for
-    every instantiation of the rank-128 unit and for every LDS-DMA (STAGE = 1, the product path) instantiation of the
-    rank-256 unit; its register-staged debug variants (STAGE = 0) are allowed their few spilled words."""
+    every instantiation: no scratch instruction inside any loop, and at most a handful of spilled words in the
+    prologue / epilogue of the instances that fill the whole 512-register file (padded rank 256, two accumulator sets)."""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
     src = os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', unit + '.hip')
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-Wno-inline-asm',
-                        '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', str(tmp_path / 'x.o')],
-                       capture_output=True, text=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-Wno-inline-asm']
+    r = subprocess.run([hipcc] + flags + ['-Rpass-analysis=kernel-resource-usage', '-S', '--cuda-device-only', src, '-o',
+                                          str(tmp_path / 'x.s')], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = r.stderr.split('Function Name: ')[1:]
-    assert len(blocks) >= 16
+    assert len(blocks) >= 12
+    spilled = set()
     for b in blocks:
+        name = b.split('\n')[0].strip()
         m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b)
-        k = re.search(r'fused_kernelILi(\d+)ELi(\d+)ELb(\d)ELi(\d)ELi(\d)ELi(\d)E', b.split('\n')[0])
-        if k and k.group(1) == '256' and k.group(5) == '0':
-            assert int(m.group(1)) <= 256, b.split('\n')[0]
-            continue
-        assert m and int(m.group(1)) == 0, b.split('\n')[0]
+        assert m, name
+        if int(m.group(1)) > 0:
+            assert unit == 'nmfmu_inst_r256' and int(m.group(1)) <= 64, (name, m.group(1))
+            spilled.add(name)
+    # every scratch access of the spilling instances sits outside the loops (LLVM tags loop blocks in the label comment)
+    asm = open(tmp_path / 'x.s').read()
+    for fn in re.split(r'\n(?=_ZN5nmfmu\w+:)', asm)[1:]:
+        in_loop = False
+        for line in fn.split('\n'):
+            if re.match(r'\.LBB\d+_\d+:', line):
+                in_loop = 'Loop' in line
+            elif 'scratch_' in line:
+                assert not in_loop, (fn.split(':')[0], line)
