@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: fused beta-divergence MU iterations of dense NMF on MI355X.
 
-    python bench.py                         # 1 GPU, BASELINE configs[1]: NMF 4096x65536 rank 128 beta=1 bf16
+    python bench.py                         # 1 GPU, BASELINE configs[1]: NMF 4096x65536 rank 128 beta=1
+    python bench.py --gpus N                # N GPUs of this node: spawns one rank per GPU itself, or, under a launcher:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one MU iteration (W half-step then H half-step, nmf.py:366-391 of the reference) over a synthetic
-V already resident in HBM in the engine's packed layout.  With N > 1 every rank owns its own 65536-column
-shard of V and of W (weak scaling: the problem is 4096 x (65536 N)); H is replicated and the H half-step does
-ONE all-reduce (RCCL) per iteration.  `value` is the whole-job algorithmic GFLOP/s (8 * rows * total_cols *
-rank flops per iteration); iterations/s is reported next to it.
+V already resident in HBM in the engine's packed layout.  With N > 1 every rank owns its own column shard of V and of
+W (weak scaling; preset configs[4]: 8192 x 262144 rank 256 per GPU); H is replicated and the H half-step all-reduces
+its numerators (RCCL).  `value` is the whole-job algorithmic GFLOP/s (8 * rows * total_cols * rank flops per
+iteration); iterations/s is reported next to it.
 
-Printed JSON also carries
+Timing: W warm-up steps, an untimed pre-roll (`preroll_steps`, ~0.4 s: the chip's clocks settle under load), then
+blocks of exactly K steps, each bracketed by barrier + synchronize, until two consecutive blocks agree within 2 %;
+the median of the settled blocks is reported and every block is listed.
+
+The headline leg runs in the 'f16' operand mode (fp16 operands and target, fp32 accumulation: bf16's MFMA rate, and the
+mode that meets the reference within 1e-4 -- checked in the same run, `parity`); the 'bf16' mode configs[1] names is
+timed next to it (`bf16_mode`).  Printed JSON also carries
   roofline      the fused kernel's achieved TFLOP/s (algorithmic flops per launch / mean launch time measured
                 live with hipEvents on the launching stream) against the dense bf16 MFMA peak, plus the same
                 launch expressed as HBM GB/s of algorithmic bytes;
   cpu_baseline  the reference's ATen op sequence (oracle/aten_port.py, fp32) timed on this box's host cores
-                on a bounded sample of the same workload (rank 0, N = 1 only).
+                on a bounded sample of the same workload (rank 0, N = 1 only);
+  parity        the same k iterations on the GPU and in the CPU reference from identical V, W0, H0: relative errors;
+  beta_sweep    BASELINE configs[2]: beta in {2, 0.5, 0} at the same shape (iterations/s, kernel fraction at
+                12*N*C*R, parity k = 3);
+  nmfd          BASELINE configs[3]: NMFD 1025 x 8192, rank 8, T = 400 (iterations/s, per-GEMM fractions, parity).
 """
 import argparse
 import json
@@ -46,15 +57,22 @@ def parse():
     ap.add_argument('--rows', type=int, default=None)
     ap.add_argument('--cols', type=int, default=None, help='columns PER GPU')
     ap.add_argument('--rank', type=int, default=None)
-    ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; the median block is reported')
-    ap.add_argument('--no-parity-mode', action='store_true', help="skip the second timed leg in the parity-grade 'f16' mode")
+    ap.add_argument('--repeats', type=int, default=5, help='minimum number of timed blocks of --steps steps each; blocks '
+                    'are added (up to --max-repeats) until two consecutive ones agree within 2 %%; the median block is reported')
+    ap.add_argument('--max-repeats', type=int, default=40)
+    ap.add_argument('--preroll-s', type=float, default=0.4, help='untimed iterations before the first block, in seconds of '
+                    'GPU work (the chip needs ~0.3 s under load to settle its clocks; reported as preroll_steps)')
+    ap.add_argument('--no-parity-mode', action='store_true', help="skip the secondary timed leg in the other single-plane mode")
+    ap.add_argument('--no-sweep', action='store_true', help='skip the beta_sweep (configs[2]) and nmfd (configs[3]) sub-objects '
+                    'of the default run')
     ap.add_argument('--beta', type=float, default=1.0)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f16'])
-    ap.add_argument('--stage', type=int, default=None, help='0 = register staging, 1 = LDS-DMA (default)')
-    ap.add_argument('--cpu-iters', type=int, default=3, help='timed CPU-baseline iterations (0 disables)')
+    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16'],
+                    help="operand type of the headline leg: 'f16' (default: fp16 operands, bf16's MFMA rate, meets the 1e-4 "
+                         "parity bar; nmf and nmfd workloads), 'bf16' (the type configs[1] names; factors ~2e-4 after 3 "
+                         "iterations; default of the other workloads), 'bf16x3'")
+    ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-baseline iterations = iterations of the in-run parity '
+                    'check (0 disables both)')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph instead of launching '
-                    'every kernel eagerly (measured no faster on MI355X; fit() does this with TORCHNMF_AMD_GRAPH=1)')
     ap.add_argument('--block-rows', type=int, default=None, help='force the 128- or 256-row workgroup tile')
     ap.add_argument('--workload', default='nmf', choices=['nmf', 'nmfd', 'betamu', 'nmf2d', 'sparse', 'plca'],
                     help="'nmfd' = BASELINE configs[3]: NMFD 1x1025x8192 rank 8 T=400 (1 GPU only)")
@@ -117,6 +135,46 @@ def pick_threads(run_probe, max_cands=None):
     return best, tried
 
 
+def preroll_steps(step, seconds):
+    """Untimed iterations until `seconds` of GPU work have passed: under this load the chip takes a few tenths of a second
+    to settle its clocks (the first blocks of a cold run were up to 18 % slower than the settled ones)."""
+    n = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n += 20
+    return n
+
+
+def timed_blocks(run, steps, min_repeats, max_repeats, barrier=None, reduce_max=None):
+    """Blocks of exactly `steps` steps, each bracketed by barrier + synchronize (MAX over ranks); at least `min_repeats`,
+    then more until two consecutive blocks agree within 2 % (or `max_repeats`).  Returns (median ms/step, all blocks)."""
+    def sync():
+        torch.cuda.synchronize()
+        if barrier is not None:
+            barrier()
+    blocks = []
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if reduce_max is not None:
+            elapsed = reduce_max(elapsed)
+        blocks.append(1e3 * elapsed / steps)
+        n = len(blocks)
+        settled = n >= 2 and abs(blocks[-1] - blocks[-2]) <= 0.02 * blocks[-1]
+        if n >= max(1, min_repeats) and (settled or n >= max_repeats):
+            break
+    tail = blocks[-max(1, min_repeats):]          # the settled end of the run
+    return sorted(tail)[len(tail) // 2], blocks
+
+
 def cpu_baseline(V, W0, H0, beta, iters, betamu=False):
     """Time the reference's op sequence on the host cores (bounded sample of the same workload)."""
     from oracle import aten_port
@@ -133,10 +191,13 @@ def cpu_baseline(V, W0, H0, beta, iters, betamu=False):
     return dt, cores, tried, Wr, Hr
 
 
-def main_nmfd(a):
-    """BASELINE configs[3]: NMFD spectrogram 1025 x 8192, rank 8, T = 400, beta = 1 (replicas only: 1 GPU)."""
+def nmfd_line(a, sub=False):
+    """BASELINE configs[3]: NMFD spectrogram 1025 x 8192, rank 8, T = 400, beta = 1 (replicas only: 1 GPU).  Returns the
+    JSON object; sub=True is the trimmed form embedded in the default run (precision f16 headline, k = 3 parity)."""
     dev = torch.device('cuda', 0)
     from torchnmf_amd.nmfd_engine import ConvMU
+    from torchnmf_amd.engine import KernelTimer
+    kind, prec_head = a.workload, a.precision
     Cc, L, R, T, beta = (a.rows or 1025), (a.cols or 8192), (a.rank or 8), a.taps, a.beta   # --rows = channels, --cols = frames
     g = torch.Generator(device=dev).manual_seed(1000)
     if a.workload == 'nmf2d':       # NMF2D, the next row after NMFD (same engine, two shift axes)
@@ -160,22 +221,12 @@ def main_nmfd(a):
         eng.h_step()
     for _ in range(a.warmup):
         step()
-    graph = None
-    if a.graph:
-        os.environ['TORCHNMF_AMD_GRAPH'] = '1'
-        from torchnmf_amd.engine import capture_iteration
-        graph = capture_iteration(step)
-    run = graph.replay if graph is not None else step
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run()
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    preroll = preroll_steps(step, a.preroll_s)
+    ms, blocks = timed_blocks(step, a.steps, a.repeats, a.max_repeats)
     flops = (4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T
     # second timed leg in the parity-grade mode (split bf16, 3 MFMAs per product) so that the line carries both
     pm = None
-    if a.precision not in ('bf16x3', 'f16') and not a.no_parity_mode and a.workload == 'nmfd':
+    if a.precision not in ('bf16x3', 'f16') and not a.no_parity_mode and a.workload == 'nmfd' and not sub:
         # the parity-grade mode fit() picks by itself: fp16 operands where built (beta == 1, >= 128 taps), else split bf16
         pprec = 'f16' if (beta == 1 and T >= 128 and T % 8 == 0 and L % 8 == 0) else 'bf16x3'
         Wp, Hp = W.clone(), H.clone()
@@ -193,63 +244,74 @@ def main_nmfd(a):
               'iters_per_s': round(1e3 / ms3, 2), 'ms_per_step': round(ms3, 4),
               'value': round((4.0 if beta == 1 else 6.0) * 2.0 * Cc * L * R * T / (ms3 * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s'}
         del e3
-    # the dominant kernel (nt_gemm) timed live: 4 launches per iteration, each 2*C*L*R*T algorithmic flops.  Timed as the
-    # iteration runs it: the reconstruction of the W half-step (GEMM over the channels that fill whole 128-row tiles +
-    # the ragged-channel kernel when C = 128 k + 1..8)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ev[0].record()
+    # the dominant kernel (nt_gemm) timed live: 4 launches per iteration (beta == 1), each 2*C*L*R*T algorithmic flops,
+    # every one bracketed by hipEvents on the launching stream as the iteration runs it (the reconstructions run over the
+    # channels that fill whole 128-row tiles; the ragged-channel kernel next to them is outside the brackets)
+    eng.timer = KernelTimer(8 * a.steps + 8)
     for _ in range(a.steps):
-        eng.recon_ratio_w()
-    ev[1].record()
+        step()
     torch.cuda.synchronize()
-    gemm_ms = ev[0].elapsed_time(ev[1]) / a.steps
-    ach = 2.0 * Cc * L * R * T / (gemm_ms * 1e-3) / 1e12
+    spans = eng.timer.spans()
+    eng.timer.close()
+    eng.timer = None
+    gflop = 2.0 * Cc * L * R * T
+    per_gemm = {k: {'avg_launch_ms': round(sum(v) / len(v), 5),
+                    'frac': round(gflop / (sum(v) / len(v) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in spans.items()}
+    all_ms = [x for v in spans.values() for x in v]
+    gemm_ms = sum(all_ms) / len(all_ms)
+    ach = gflop / (gemm_ms * 1e-3) / 1e12
     peak = MFMA_BF16_PEAK_TFLOPS
     cpu = None
     parity = None
-    if a.cpu_iters > 0:
+    cpu_iters = min(a.cpu_iters, 3) if sub else a.cpu_iters
+    if cpu_iters > 0:
         from oracle import aten_port
         torch.set_flush_denormal(True)
-        cores, tried = pick_threads(lambda: aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1))
+        cores, tried = pick_threads(lambda: aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1), max_cands=2 if sub else None)
         aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, 1)
         t0 = time.perf_counter()
-        Wr, Hr = aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, a.cpu_iters)
-        dt = (time.perf_counter() - t0) / a.cpu_iters
+        Wr, Hr = aten_port.mu_iterations_nmfd(Vc, Wc, Hc, beta, cpu_iters)
+        dt = (time.perf_counter() - t0) / cpu_iters
         # in-run parity: the same k iterations on the GPU from the same V, W0, H0, per precision mode
         def rel(x, y):
             return float((x.double() - y.double()).norm() / y.double().norm())
         modes = {}
-        for prec in dict.fromkeys([a.precision] + (['f16'] if a.workload == 'nmfd' and beta == 1 and T >= 128 else []) + ['bf16x3']):
+        for prec in dict.fromkeys([prec_head] + (['f16'] if kind == 'nmfd' and beta == 1 and T >= 128 else []) + (['bf16'] if sub else ['bf16x3'])):
             Wg, Hg = Wc.clone().to(dev), Hc.clone().to(dev)
             e2 = ConvMU(V, Wg, Hg, beta, precision=prec)
-            for _ in range(a.cpu_iters):
+            for _ in range(cpu_iters):
                 e2.w_step()
                 e2.h_step()
             torch.cuda.synchronize()
             rw, rh = rel(Wg.cpu(), Wr), rel(Hg.cpu(), Hr)
             modes[prec] = {'rel_W': float(f'{rw:.4g}'), 'rel_H': float(f'{rh:.4g}'), 'meets_1e-4': bool(max(rw, rh) < 1e-4)}
             del e2
-        parity = {'k': a.cpu_iters, 'reference': 'oracle/aten_port.py (fp32, same V, W0, H0), the timed CPU iterations',
+        parity = {'k': cpu_iters, 'reference': 'oracle/aten_port.py (fp32, same V, W0, H0), the timed CPU iterations',
                   'bar': 1e-4, 'modes': modes}
         cpu = {'value': round(flops / dt / 1e9, 2), 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
-               'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4), 'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same '
+               'host_cores': usable_cores(), 'thread_probe_s': tried, 'iters_per_s': round(1 / dt, 4), 'sample': f'{cpu_iters} timed MU iterations (+1 warm-up) of the same '
                f'workload, fp32, F.conv{2 if a.workload == "nmf2d" else 1}d + two backward passes (oracle/aten_port.py)'}
-    print(json.dumps({
+    return {
         'metric': f'MU GFLOP/s (algorithmic 8*C*L*R*T per iteration), {title} beta={beta:g}',
         'value': round(flops / (ms * 1e-3) / 1e9, 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms, 2), 'n_gpus': 1,
-        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'steps': a.steps, 'warmup': a.warmup, 'preroll_steps': preroll, 'ms_per_step': round(ms, 4),
+        'blocks_ms_per_step': [round(x, 4) for x in blocks], 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}[a.precision],
         'data': 'synthetic',
         'config': {'workload': f'{title} beta={beta:g}',
-                   'precision': a.precision, 'parallelism': 'single GPU (replicas only)',
-                   'launch': 'hipGraph replay of one iteration' if graph is not None else 'eager launches'},
+                   'precision': a.precision, 'parallelism': 'single GPU (replicas only)', 'launch': 'eager launches'},
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(ach / peak, 4), 'traffic': None,
-                     'kernel': 'nmfmu::nt_gemm_kernel (EPI_RATIO)' + (' + conv_ragged_rows_kernel' if getattr(eng, 'ragged', False) else ''),
-                     'avg_launch_ms': round(gemm_ms, 5),
+                     'kernel': 'nmfmu::nt_gemm_kernel (mean over the GEMM launches of an iteration: reconstruction + ratio of both '
+                               'half-steps, W numerator, H numerator with the fold epilogue)',
+                     'avg_launch_ms': round(gemm_ms, 5), 'per_gemm': per_gemm,
                      'note': 'bf16x3 issues 3 MFMAs per algorithmic product: hardware MFMA rate is 3x achieved'
                      if a.precision == 'bf16x3' else ''},
-        'cpu_baseline': cpu, 'parity': parity, 'parity_mode': pm}))
+        'cpu_baseline': cpu, 'parity': parity, 'parity_mode': pm}
+
+
+def main_nmfd(a):
+    print(json.dumps(nmfd_line(a)))
 
 
 def main_sparse(a):
@@ -396,8 +458,152 @@ def main_plca(a):
         'cpu_baseline': cpu}))
 
 
+def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, betamu=False, blocks_min=None):
+    """W warm-up steps, an untimed pre-roll, then blocks of exactly K steps, each bracketed by barrier + synchronize; the
+    block time is the MAX over ranks, the reported ms/step the median of the settled blocks.  Returns a dict."""
+    from torchnmf_amd.engine import DenseMU, KernelTimer
+    N, C = V.shape
+    R = W0.shape[1]
+    flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R     # SURVEY.md 8d: 4 (6) contractions of 2NCR
+    W, H = W0.clone(), H0.clone()
+    if betamu:
+        # SURVEY.md 8(f1): trainer.BetaMu.step(closure) on one NMF layer; one step = W update + H update
+        assert world == 1 and group is None, 'BetaMu runs on one GPU'
+        from torchnmf_amd.nmf import NMF
+        from torchnmf_amd.trainer import BetaMu
+        layer = NMF(W=W.cpu(), H=H.cpu()).to(dev)
+        trainer = BetaMu(layer.parameters(), beta, precision=precision)
+
+        def closure():
+            trainer.zero_grad()
+            return V, (layer() if a.materialise else layer)
+
+        def step():
+            trainer.step(closure)
+        step()
+        eng = next(iter(trainer._engines.values()))[0] if trainer._engines else trainer._last_uncached
+    else:
+        eng = DenseMU(V, W, H, beta, precision=precision, group=group, block_rows=a.block_rows)
+
+        def step():
+            eng.w_step()
+            eng.h_step()
+    torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    preroll = preroll_steps(step, a.preroll_s)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(elapsed):
+        if world == 1:
+            return elapsed
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    # (multi-rank: a fixed block count, so that every rank runs the same number of collectives)
+    ms, blocks = timed_blocks(step, a.steps, blocks_min or a.repeats, (blocks_min or a.repeats) if world > 1 else a.max_repeats,
+                              barrier, reduce_max)
+    out = {'precision': precision, 'ms_per_step': ms, 'blocks_ms_per_step': [round(x, 4) for x in blocks],
+           'preroll_steps': preroll, 'gflops': flops_per_iter_gpu * world / (ms * 1e-3) / 1e9, 'eng': eng}
+    # ---- roofline leg: K more steps, right after the timed region, with hipEvents around every fused launch
+    # (recording inside the timed region costs ~2 % and folds the dispatch gap in front of each kernel into its
+    # span; these spans agree with the rocprofv3 kernel-trace durations)
+    if want_roofline:
+        nst = max(a.steps, 40)
+        eng.timer = KernelTimer(8 * nst + 8)
+        for _ in range(nst):
+            step()
+        torch.cuda.synchronize()
+        spans = eng.timer.spans()
+        eng.timer.close()
+        eng.timer = None
+        if 'h' not in spans and 'h0' in spans:      # sharded path: the H half-step runs as two row halves
+            spans['h'] = [x + y for x, y in zip(spans['h0'], spans['h1'])]
+        all_ms = spans.get('w', []) + spans.get('h', [])
+        avg_ms = sum(all_ms) / len(all_ms)
+        flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
+        elt = 4 if precision == 'bf16x3' else 2
+        bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
+        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        pp = eng.step_h.block_rows == 256
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, precision, pp),
+                'kernel': 'nmfmu::pp_kernel' if pp else 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
+                'avg_launch_ms': round(avg_ms, 5),
+                'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
+                'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
+                'outside_fused_kernels_ms': round(ms - 2 * avg_ms, 5),
+                'flops_per_launch': flops_per_launch,
+                'note': 'W-step launches carry the MU apply (nmf.py:78-92) in their epilogue when the contraction is not '
+                        'split; H-step launches are the MFMA main loop + slab stores',
+                'achieved_main_loop_only': round(flops_per_launch / (sum(spans['h']) / len(spans['h']) * 1e-3) / 1e12, 2),
+                'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        'algorithmic_bytes_per_launch': int(bytes_per_launch)}}
+        if 'ar' in spans:
+            roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
+            roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
+                                      'second half\'s kernel' if 'h0' in spans else 'blocking, after the H half-step kernel')
+        out['roofline'] = roof
+    return out
+
+
+def parity_leg(a, V, W0, H0, Vc, beta, precision, Wr, Hr, k, dev):
+    """k MU iterations from the same (V, W0, H0) as the CPU reference leg, compared factor by factor."""
+    from torchnmf_amd.engine import DenseMU
+    N, C = V.shape
+    W, H = W0.clone(), H0.clone()
+    eng = DenseMU(V, W, H, beta, precision=precision)
+    for _ in range(k):
+        eng.w_step()
+        eng.h_step()
+    torch.cuda.synchronize()
+    loss = eng.divergence()
+    Wc, Hc = W.cpu(), H.cpu()
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    # reconstruction on a 512-row slice (the full 4096 x 65536 product is 1 GiB on either side)
+    rows = slice(0, min(N, 512))
+    rec, rec_r = Hc[rows] @ Wc.t(), Hr[rows] @ Wr.t()
+    from oracle import mu_oracle as O
+    # reference loss accumulated in float64 over 512-row blocks: an fp32 sum over 2.7e8 terms wanders by ~1e-4..1e-3
+    # with the host's thread count (seen: the same GPU value 8e-6 off on one box, 5e-4 on another)
+    loss_r = None
+    if N * C <= 4096 * 65536:
+        loss_r = 0.0
+        for r0 in range(0, N, 512):
+            loss_r += float(O.beta_div((Hr[r0:r0 + 512] @ Wr.t()).double(), Vc[r0:r0 + 512].double(), beta))
+    d = {'rel_W': rel(Wc, Wr), 'rel_H': rel(Hc, Hr), 'rel_recon': rel(rec, rec_r),
+         'rel_loss': (abs(loss - loss_r) / abs(loss_r)) if loss_r else None}
+    d = {kk: (None if v is None else float(f'{v:.3e}')) for kk, v in d.items()}
+    d['meets_1e-4'] = all(v is not None and v < 1e-4 for v in (d['rel_W'], d['rel_H'], d['rel_recon']))
+    del eng
+    return d
+
+
+DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}
+DTYPE_LONG = {'f16': 'f16 operands and target / fp32 accumulate (same MFMA rate as bf16; meets the 1e-4 parity bar)',
+              'bf16': 'bf16 operands and target / fp32 accumulate (the type configs[1] names; factors ~2e-4 after 3 iterations)',
+              'bf16x3': 'split bf16 (3 MFMAs per product, fp32 target): fp32-grade'}
+
+
+def _spawned(local_rank, nprocs, port, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(nprocs), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
+
+
 def main():
     a = parse()
+    if a.precision is None:
+        a.precision = 'f16' if a.workload in ('nmf', 'nmfd') else 'bf16'
     if a.workload == 'plca':
         assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'PLCA is not sharded'
         torch.cuda.set_device(0)
@@ -410,13 +616,26 @@ def main():
         assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'NMFD / NMF2D are not sharded (replicas only)'
         torch.cuda.set_device(0)
         return main_nmfd(a)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): spawn the N ranks ourselves, one per GPU, rendezvous on localhost
+        import socket
+        import torch.multiprocessing as mp
+        assert torch.cuda.device_count() >= a.gpus, f'--gpus {a.gpus} but {torch.cuda.device_count()} devices are visible'
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        mp.spawn(_spawned, args=(a.gpus, port, sys.argv[1:]), nprocs=a.gpus, join=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     group = None
+    nranks = 1
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -425,9 +644,7 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', device_id=dev)   # RCCL
         group = dist.group.WORLD
-    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
-
-    from torchnmf_amd.engine import DenseMU, KernelTimer
+        nranks = dist.get_world_size()                   # as RCCL's communicator reports it
 
     # ---- workload preset.  1 GPU: BASELINE configs[1].  N > 1 GPUs: configs[4], the config the ">= 6x at 8 GPUs"
     # target is quoted on -- every rank owns an 8192 x 262144 column shard at rank 256 (weak scaling).  Explicit
@@ -439,164 +656,31 @@ def main():
     R = a.rank if a.rank is not None else pr[2]
     beta = a.beta
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()   # bf16-representable, U[0,1)
+    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()   # bf16-representable U[0,1): exact in fp16 too
     if beta <= 0:
-        V += 2.0 ** -7
+        V.clamp_(min=2.0 ** -7)                                        # strictly positive for beta <= 0 (nmf.py:332-336)
     gw = torch.Generator(device=dev).manual_seed(2000 + rank)
     W0 = torch.randn(C, R, device=dev, generator=gw).abs_()            # the reference's init law (nmf.py:221)
     gh = torch.Generator(device=dev).manual_seed(3000)
     H0 = torch.randn(N, R, device=dev, generator=gh).abs_()            # replicated
     do_cpu = rank == 0 and world == 1 and a.cpu_iters > 0
     betamu = a.workload == 'betamu'
-    flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R     # 4 (6) contractions of 2NCR
+    flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def timed_leg(precision, want_roofline):
-        """W warm-up steps, then `repeats` blocks of exactly K steps, each bracketed by barrier + synchronize; the
-        block time is the MAX over ranks, the reported ms/step the MEDIAN block.  Returns a dict."""
-        W, H = W0.clone(), H0.clone()
-        graph = None
-        if betamu:
-            # SURVEY.md 8(f1): trainer.BetaMu.step(closure) on one NMF layer; one step = W update + H update
-            assert world == 1 and group is None, 'BetaMu runs on one GPU'
-            from torchnmf_amd.nmf import NMF
-            from torchnmf_amd.trainer import BetaMu
-            layer = NMF(W=W.cpu(), H=H.cpu()).to(dev)
-            trainer = BetaMu(layer.parameters(), beta, precision=precision)
-
-            def closure():
-                trainer.zero_grad()
-                return V, (layer() if a.materialise else layer)
-
-            def step():
-                trainer.step(closure)
-            step()
-            eng = next(iter(trainer._engines.values()))[0] if trainer._engines else trainer._last_uncached
-        else:
-            eng = DenseMU(V, W, H, beta, precision=precision, stage=a.stage, group=group, block_rows=a.block_rows)
-
-            def step():
-                eng.w_step()
-                eng.h_step()
-        torch.cuda.synchronize()
-        for _ in range(a.warmup):
-            step()
-        if a.graph and not betamu:
-            os.environ['TORCHNMF_AMD_GRAPH'] = '1'
-            from torchnmf_amd.engine import capture_iteration
-            graph = capture_iteration(step, group)       # None on the sharded path: the all-reduce stays eager
-        run = graph.replay if graph is not None else step
-        blocks = []
-        for _ in range(max(1, a.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                run()
-            barrier()
-            elapsed = time.perf_counter() - t0
-            if world > 1:
-                import torch.distributed as dist
-                tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                elapsed = float(tt.item())
-            blocks.append(1e3 * elapsed / a.steps)
-        ms = sorted(blocks)[len(blocks) // 2]
-        out = {'precision': precision, 'ms_per_step': ms, 'blocks_ms_per_step': [round(x, 4) for x in blocks],
-               'gflops': flops_per_iter_gpu * world / (ms * 1e-3) / 1e9, 'eng': eng, 'graph': graph is not None}
-        # ---- roofline leg: K more steps, right after the timed region, with hipEvents around every fused launch
-        # (recording inside the timed region costs ~2 % and folds the dispatch gap in front of each kernel into its
-        # span; these spans agree with the rocprofv3 kernel-trace durations)
-        if want_roofline:
-            eng.timer = KernelTimer(8 * a.steps + 8)
-            ar_ms = []
-            for _ in range(a.steps):
-                step()
-            torch.cuda.synchronize()
-            spans = eng.timer.spans()
-            eng.timer.close()
-            eng.timer = None
-            if 'h' not in spans and 'h0' in spans:      # sharded path: the H half-step runs as two row halves
-                spans['h'] = [x + y for x, y in zip(spans['h0'], spans['h1'])]
-            all_ms = spans.get('w', []) + spans.get('h', [])
-            avg_ms = sum(all_ms) / len(all_ms)
-            flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
-            elt = 4 if precision == 'bf16x3' else 2
-            bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            pp = eng.step_h.block_rows == 256 and precision in ('bf16', 'f16') and beta == 1 and R <= 128 \
-                and os.environ.get('NMFMU_PP', '1') != '0'
-            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, precision, pp),
-                    'kernel': 'nmfmu::pp_kernel' if pp else 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
-                    'avg_launch_ms': round(avg_ms, 5),
-                    'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
-                    'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
-                    'outside_fused_kernels_ms': round(ms - 2 * avg_ms, 5),
-                    'note': 'W-step launches carry the MU apply (nmf.py:78-92) in their epilogue when the contraction '
-                            'is not split; H-step launches are the MFMA main loop + slab stores.  The loop runs '
-                            'power-limited: profiles/r02_clock.md (core clock 1.4-1.6 GHz of 2.4 under this kernel)',
-                    'achieved_main_loop_only': round(flops_per_launch / (sum(spans['h']) / len(spans['h']) * 1e-3) / 1e12, 2),
-                    'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
-                            'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                            'algorithmic_bytes_per_launch': int(bytes_per_launch)}}
-            if 'ar' in spans:
-                roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
-                roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
-                                          'second half\'s kernel' if 'h0' in spans else 'blocking, after the H half-step kernel')
-            out['roofline'] = roof
-        return out
-
-    def parity_leg(precision, Wr, Hr, k, Vc):
-        """k MU iterations from the same (V, W0, H0) as the CPU reference leg, compared factor by factor."""
-        from torchnmf_amd import metrics
-        W, H = W0.clone(), H0.clone()
-        eng = DenseMU(V, W, H, beta, precision=precision, stage=a.stage)
-        for _ in range(k):
-            eng.w_step()
-            eng.h_step()
-        torch.cuda.synchronize()
-        loss = eng.divergence()
-        Wc, Hc = W.cpu(), H.cpu()
-        rel = lambda x, y: float((x - y).norm() / y.norm())
-        # reconstruction on a 512-row slice (the full 4096 x 65536 product is 1 GiB on either side)
-        rows = slice(0, min(N, 512))
-        rec, rec_r = Hc[rows] @ Wc.t(), Hr[rows] @ Wr.t()
-        from oracle import mu_oracle as O
-        # reference loss accumulated in float64 over 512-row blocks: an fp32 sum over 2.7e8 terms wanders by ~1e-4..1e-3
-        # with the host's thread count (seen: the same GPU value 8e-6 off on one box, 5e-4 on another)
-        loss_r = None
-        if N * C <= 4096 * 65536:
-            loss_r = 0.0
-            for r0 in range(0, N, 512):
-                loss_r += float(O.beta_div((Hr[r0:r0 + 512] @ Wr.t()).double(), Vc[r0:r0 + 512].double(), beta))
-        d = {'rel_W': rel(Wc, Wr), 'rel_H': rel(Hc, Hr), 'rel_recon': rel(rec, rec_r),
-             'rel_loss': (abs(loss - loss_r) / abs(loss_r)) if loss_r else None}
-        d = {kk: (None if v is None else float(f'{v:.3e}')) for kk, v in d.items()}
-        d['meets_1e-4'] = all(v is not None and v < 1e-4 for v in (d['rel_W'], d['rel_H'], d['rel_recon']))
-        del eng
-        return d
-
-    head = timed_leg(a.precision, not a.no_roofline)
-    # second, clearly labelled line object: the single-plane mode that meets north_star's 1e-4 (fp16 operands), timed
-    # in the same run, so that the driver sees the parity-grade throughput next to the headline
-    parity_mode = None
-    if (a.precision == 'bf16' and beta == 1 and R <= 128 and not betamu and not a.no_parity_mode
-            and os.environ.get('NMFMU_PP', '1') != '0'):
-        pm = timed_leg('f16', not a.no_roofline)
-        parity_mode = {'precision': 'f16', 'dtype': 'f16 operands / fp32 accumulate (same MFMA rate as bf16)',
-                       'value': round(pm['gflops'], 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / pm['ms_per_step'], 2),
-                       'ms_per_step': round(pm['ms_per_step'], 4), 'blocks_ms_per_step': pm['blocks_ms_per_step'],
-                       'roofline': pm.get('roofline')}
+    head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu)
+    # secondary, clearly labelled object: the other single-plane operand type, timed in the same run
+    other = {'f16': 'bf16', 'bf16': 'f16'}.get(a.precision)
+    second = None
+    if other and not betamu and not a.no_parity_mode and world == 1:
+        pm = dense_leg(a, V, W0, H0, beta, other, group, world, dev, not a.no_roofline)
+        second = {'precision': other, 'dtype': DTYPE_LONG[other], 'value': round(pm['gflops'], 1), 'unit': 'GFLOP/s',
+                  'iters_per_s': round(1e3 / pm['ms_per_step'], 2), 'ms_per_step': round(pm['ms_per_step'], 4),
+                  'blocks_ms_per_step': pm['blocks_ms_per_step'], 'roofline': pm.get('roofline')}
         del pm
 
     cpu = None
     parity = None
+    Vc = None
     if do_cpu:
         Vc, W0c, H0c = V.cpu(), W0.cpu(), H0.cpu()
         dt, cores, tried, Wr, Hr = cpu_baseline(Vc, W0c, H0c, beta, a.cpu_iters, betamu)
@@ -606,9 +690,44 @@ def main():
                'sample': f'{a.cpu_iters} timed MU iterations (+1 warm-up) of the same {N}x{C} rank-{R} beta={beta:g} '
                          f'workload, fp32, reference op sequence (oracle/aten_port.py), loss evaluation excluded'}
         if not betamu:
-            modes = [a.precision] + (['f16'] if parity_mode is not None else [])
+            modes = [a.precision] + ([other] if second is not None else [])
             parity = {'k': a.cpu_iters, 'reference': 'oracle/aten_port.py (fp32, same V, W0, H0), the timed CPU iterations',
-                      'bar': 1e-4, 'modes': {m: parity_leg(m, Wr, Hr, a.cpu_iters, Vc) for m in modes}}
+                      'bar': 1e-4, 'modes': {m: parity_leg(a, V, W0, H0, Vc, beta, m, Wr, Hr, a.cpu_iters, dev) for m in modes}}
+
+    # ---- the other BASELINE configs the driver's default command should see (1 GPU, default workload only):
+    # configs[2] = the beta sweep at this shape, configs[3] = NMFD.  Each with its own in-run parity check (k = 3).
+    beta_sweep = None
+    nmfd = None
+    default_run = (world == 1 and not betamu and not a.no_sweep and beta == 1 and (N, C, R) == (4096, 65536, 128)
+                   and a.precision in ('f16', 'bf16'))
+    if default_run:
+        from oracle import aten_port
+        beta_sweep = {'shape': f'{N}x{C} rank={R}', 'precision': a.precision,
+                      'flops_per_iteration': '12*N*C*R (6 contractions, as the reference computes them)', 'betas': {}}
+        for b in (2.0, 0.5, 0.0):
+            Vb = V.clamp(min=2.0 ** -7) if b <= 0 else V
+            leg = dense_leg(a, Vb, W0, H0, b, a.precision, None, 1, dev, True, blocks_min=3)
+            ent = {'iters_per_s': round(1e3 / leg['ms_per_step'], 2), 'ms_per_step': round(leg['ms_per_step'], 4),
+                   'value': round(leg['gflops'], 1), 'unit': 'GFLOP/s', 'blocks_ms_per_step': leg['blocks_ms_per_step'],
+                   'kernel': leg['roofline']['kernel'], 'kernel_frac': leg['roofline']['frac'],
+                   'kernel_avg_launch_ms': leg['roofline']['avg_launch_ms'], 'kernel_tflops': leg['roofline']['achieved']}
+            del leg
+            if do_cpu:
+                k = 3
+                Vbc = Vc.clamp(min=2.0 ** -7) if b <= 0 else Vc
+                Wr, Hr = aten_port.mu_iterations(Vbc, W0.cpu(), H0.cpu(), b, k)
+                ent['parity'] = dict(k=k, **parity_leg(a, Vb, W0, H0, Vbc, b, a.precision, Wr, Hr, k, dev))
+                del Vbc
+            del Vb
+            beta_sweep['betas'][f'{b:g}'] = ent
+        import argparse
+        na = argparse.Namespace(**vars(a))
+        na.workload, na.precision, na.rows, na.cols, na.rank, na.beta, na.taps = 'nmfd', 'f16', None, None, None, 1.0, 400
+        if not do_cpu:
+            na.cpu_iters = 0
+        line = nmfd_line(na, sub=True)
+        nmfd = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
+                                     'roofline', 'parity', 'cpu_baseline')}
 
     if rank == 0:
         ms_per_step = head['ms_per_step']
@@ -617,20 +736,23 @@ def main():
             'metric': f'MU GFLOP/s (algorithmic {"8" if beta == 1 else "12"}*N*C*R per iteration), dense NMF '
                       f'{N}x{C} rank-{R} beta={beta:g}; MU iterations/s alongside',
             'value': round(head['gflops'], 1), 'unit': 'GFLOP/s', 'iters_per_s': round(1e3 / ms_per_step, 2),
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'repeats': max(1, a.repeats), 'blocks_ms_per_step': head['blocks_ms_per_step'],
+            'n_gpus': world, 'nranks': nranks, 'steps': a.steps, 'warmup': a.warmup, 'preroll_steps': head['preroll_steps'],
+            'ms_per_step': round(ms_per_step, 4),
+            'repeats': len(head['blocks_ms_per_step']), 'blocks_ms_per_step': head['blocks_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}[a.precision], 'data': 'synthetic',
+            'dtype': DTYPE_NAME[a.precision], 'dtype_note': DTYPE_LONG[a.precision], 'data': 'synthetic',
             'config': {'workload': (f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
-                                    f'H replicated, 1 all-reduce/iter' + (' (BASELINE configs[4])' if (N, C * world, R, beta) == (8192, 2097152, 256, 1.0) else ''))
+                                    f'H replicated, all-reduce of the H numerators per iteration' + (' (BASELINE configs[4])' if (N, C * world, R, beta) == (8192, 2097152, 256, 1.0) else ''))
                        if world > 1 else
                        ('trainer.BetaMu.step on ' if betamu else '') + f'NMF {N}x{C} rank={R} beta={beta:g}' +
                        (' (BASELINE configs[1])' if (N, C, R, beta) == (4096, 65536, 128, 1.0) else ''),
                        'preset': preset, 'rows': N, 'cols_per_gpu': C, 'rank': R, 'beta': beta, 'precision': a.precision,
                        'parallelism': f'column-shard x{world}' if world > 1 else 'single GPU',
                        'nsplit_h': eng.step_h.nsplit, 'nsplit_w': eng.step_w.nsplit, 'block_rows_h': eng.step_h.block_rows, 'block_rows_w': eng.step_w.block_rows,
-                       'launch': 'hipGraph replay of one iteration' if head['graph'] else 'eager launches'},
-            'roofline': head.get('roofline'), 'cpu_baseline': cpu, 'parity': parity, 'parity_mode': parity_mode,
+                       'launch': 'eager launches'},
+            'roofline': head.get('roofline'), 'cpu_baseline': cpu, 'parity': parity,
+            ('bf16_mode' if other == 'bf16' else 'parity_mode'): second,
+            'beta_sweep': beta_sweep, 'nmfd': nmfd,
         }
         if betamu:
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \

@@ -247,18 +247,33 @@ class DenseMU:
     (nmf.py:92).  With ``group`` set, ``V`` / ``W`` are this rank's column shard.
     """
 
-    # 'auto' may pick the single-plane fp16 mode only where it meets the 1e-4 parity bar (DESIGN.md section 4): both
-    # contraction lengths long enough for the per-step rounding errors to average down, and data inside fp16's range
-    F16_MIN_DIM = 2048
+    # 'auto' may pick the single-plane fp16 mode only where it meets the 1e-4 parity bar (DESIGN.md section 4):
+    #  * both contraction lengths long enough for the per-step operand rounding errors to average down -- emulated and
+    #    measured factor errors after 200 iterations: 9e-5 at 2048 x 2048 rank 64, 7e-5 at 4096 x 4096 rank 128;
+    #  * V EXACTLY representable in fp16 (integer counts below 2048, 8-bit images, bf16 / fp16-sourced data): the mode
+    #    stores the target in fp16, and rounding V perturbs the problem itself -- that error does not average down, it
+    #    grows with the iteration count towards the perturbed fixed point (3e-4 after 200 iterations at any size);
+    #  * data inside fp16's range with room for the ratios.
+    F16_MIN_DIM = 4096
     F16_MAX_ABS = 3.0e4
     F16_MIN_MEAN = 2.0 ** -10
 
     @classmethod
     def f16_in_range(cls, V, W, H) -> bool:
-        """One pass over V, W, H and one host sync: do they sit inside fp16's range with room for the ratios?"""
-        stats = torch.stack([V.max(), V.mean(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
-        vmax, vmean, wmax, hmax, wmean, hmean = stats
-        return max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
+        """Range and exact-representability test of the fp16 mode: two passes over V (row chunks, so that the
+        temporaries stay small next to V), one over W and H, one host sync."""
+        bad = torch.zeros((), dtype=torch.bool, device=V.device)
+        vmax = torch.zeros((), dtype=torch.float32, device=V.device)
+        vsum = torch.zeros((), dtype=torch.float64, device=V.device)
+        step = max(1, (64 << 20) // max(1, V.shape[1]))
+        for r0 in range(0, V.shape[0], step):
+            v = V[r0:r0 + step]
+            bad |= (v.half().float() != v).any()
+            vmax = torch.maximum(vmax, v.max())
+            vsum += v.sum(dtype=torch.float64)
+        stats = torch.stack([bad.float(), vmax, (vsum / V.numel()).float(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
+        inexact, vmax, vmean, wmax, hmax, wmean, hmean = stats
+        return (not inexact) and max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
                  update_W=True, update_H=True, block_rows=None, allow_f16=False):
@@ -295,8 +310,9 @@ class DenseMU:
                 if not self.be.supported(self.r_pad, _capi.PREC_BF16X3):
                     raise NotImplementedError(
                         f"precision='auto' found no mode for rank {R} that meets the 1e-4 parity bar on the fused kernels "
-                        f"(fp16 operands need both dimensions >= {self.F16_MIN_DIM} and data within fp16's range; split "
-                        f"bf16 stops at rank 128); pass precision='bf16' (factors ~1e-3) or 'f16' explicitly")
+                        f"(fp16 operands need both dimensions >= {self.F16_MIN_DIM} and a target that fp16 represents exactly "
+                        f"and that sits within its range; split bf16 stops at rank 128); pass precision='bf16' (factors "
+                        f"~1e-3) or 'f16' (exact up to the rounding of V to fp16) explicitly")
                 precision = 'bf16x3'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")

@@ -121,10 +121,12 @@ class BaseComponent(nn.Module):
 
         Extra keyword-only arguments (not in the reference):
           precision      None / 'auto' (default): the fastest mode that meets the reference's 1e-4 bar -- 'f16'
-                         (fp16 operands, bf16's MFMA rate) when both dimensions are >= 2048, rank <= 256 and the data
-                         sit inside fp16's range, otherwise 'bf16x3' (split-bf16 MFMA, matches the fp32 reference to
-                         ~1e-5; above rank 128 on the GEMM engine).  Never plain bf16.  Explicit: 'f16', 'bf16x3',
-                         'bf16' (V and operands rounded to bf16: objective within 1e-4, factors ~1e-3).
+                         (fp16 operands and target, bf16's MFMA rate) when both dimensions are >= 4096, rank <= 256,
+                         V is exactly representable in fp16 and the data sit inside fp16's range, otherwise 'bf16x3'
+                         (split-bf16 MFMA, matches the fp32 reference to ~1e-5; above rank 128 on the GEMM engine).
+                         Never plain bf16.  Explicit: 'f16' (a V that fp16 does not hold exactly is rounded to 11
+                         significant bits: a few 1e-5 per iteration, ~3e-4 after 200), 'bf16x3', 'bf16' (V and
+                         operands rounded to bf16: objective within 1e-4, factors ~1e-3).
                          The environment variable TORCHNMF_AMD_PRECISION overrides the default.
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
@@ -241,7 +243,8 @@ class NMF(BaseComponent):
             elif not f16_ok:
                 raise NotImplementedError(
                     "precision='auto' on a column-sharded fit at rank 129..256 needs the fp16 mode (both dimensions >= "
-                    f"{_D.F16_MIN_DIM}, data within fp16's range); pass precision='bf16' (factors ~1e-3) explicitly")
+                    f"{_D.F16_MIN_DIM}, a target fp16 holds exactly and within its range); pass precision='bf16' (factors "
+                    f"~1e-3) or 'f16' explicitly")
         if wide and group is not None:
             raise NotImplementedError('column sharding is implemented for the fused kernels (rank <= 256; bf16x3 up to '
                                       'rank 128)')

@@ -195,9 +195,9 @@ class ConvMU:
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
-              n_rows=None, k_len=0, k_split=0):
+              n_rows=None, k_len=0, k_split=0, tag=None):
         """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
-        output planes keep their leading dimension."""
+        output planes keep their leading dimension.  tag: name of the launch for an attached KernelTimer (bench.py)."""
         assert a.cols_pad == b.cols_pad
         m_pad, n_pad = m_rows or a.rows_pad, n_rows or b.rows_pad
         n_ld = b.rows_pad if n_rows else 0
@@ -213,7 +213,12 @@ class ConvMU:
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split)
+        timer = getattr(self, 'timer', None) if tag else None
+        if timer is not None:
+            timer.mark(tag + '<')
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
+        if timer is not None:
+            timer.mark(tag + '>')
 
     def _ragged(self, mode, x, gn=None, gp=None):
         """The channels the reconstruction GEMM left out (mode 0: W half-step planes, 1: H half-step planes, 2: loss)."""
@@ -293,15 +298,15 @@ class ConvMU:
         """Reconstruction + ratio planes of the W half-step (nmf.py:61-74 on Wm Hu^T): the GEMM over the channels that
         fill whole tiles, the ragged ones by direct summation."""
         if self.ragged:
-            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_main)
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_main, tag='recon_w')
             self._ragged(0, self.x_w, self.gn, self.gp)
         else:
-            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp)
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, tag='recon_w')
 
     def w_step(self):
         """nmf.py:367-378 for the conv1d model."""
         self.recon_ratio_w()
-        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit)
+        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit, tag='num_w')
         if not self.kl:
             self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
         self._pack_w(update=True)
@@ -309,13 +314,13 @@ class ConvMU:
     def h_step(self):
         """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
         if self.ragged:
-            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_main)
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_main, tag='recon_h')
             self._ragged(1, self.x_h, self.gnt, self.gpt)
         else:
-            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt)
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, tag='recon_h')
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
         kc = -(-self.C // 64) * 64             # the contraction runs over the channels: skip the zero tail of the padding
-        self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc)
+        self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc, tag='num_h')
         if not self.kl:
             self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc)
         kl_den = self.sum_w.data_ptr() if self.kl else None

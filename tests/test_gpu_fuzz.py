@@ -7,7 +7,7 @@ import random
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -33,13 +33,16 @@ def test_random_dense_fit_matches_oracle(i, N, C, R, beta, reg):
     g = torch.Generator().manual_seed(1000 + i)
     V = torch.rand(N, C, generator=g) + (1e-3 if beta <= 0 else 0.0)
     W0, H0 = torch.randn(C, R, generator=g).abs() + 1e-3, torch.randn(N, R, generator=g).abs() + 1e-3
-    for prec in ('bf16x3', 'bf16'):      # bf16x3 above rank 128 runs on the GEMM engine
-        Vp = V.bfloat16().float() if prec == 'bf16' else V
+    # bf16x3 above rank 128 runs on the GEMM engine.  The single-plane modes see a target their storage type holds
+    # exactly; at these (short) contraction lengths fp16 operands are held to what 11 significant bits give without
+    # averaging -- the 1e-4 bar of that mode is for the BASELINE-sized contractions (test_gpu_parity.py)
+    for prec, tol in (('bf16x3', 1e-4), ('f16', 1e-3), ('bf16', 3e-2)):
+        Vp = V.bfloat16().float() if prec != 'bf16x3' else V
         m = NMF(W=W0, H=H0).to(dev)
         n = m.fit(Vp.to(dev), beta, -1e9, 3, alpha=reg[0], l1_ratio=reg[1], precision=prec)
         Wr, Hr, nr, _, _ = O.fit(Vp, W0, H0, beta, -1e9, 3, reg[0], reg[1])
-        tol = 1e-4 if prec == 'bf16x3' else 3e-2
         ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+        record('fuzz_dense', i=i, shape=(N, C, R), beta=beta, prec=prec, relW=ew, relH=eh)
         assert n == nr == 3 and ew < tol and eh < tol, (prec, N, C, R, beta, ew, eh)
         assert bool(torch.isfinite(m.W.data).all()) and bool(torch.isfinite(m.H.data).all())
 
