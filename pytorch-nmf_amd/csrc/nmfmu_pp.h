@@ -44,6 +44,13 @@
 #pragma once
 #include "nmfmu_fused.h"
 
+#ifndef NMFMU_PP_PREFETCH
+#define NMFMU_PP_PREFETCH 0   // fused apply: pull the owner's fp32 master rows into L2 during the last tiles of the loop
+#endif
+#ifndef NMFMU_PP_EPI_BATCH
+#define NMFMU_PP_EPI_BATCH 0  // fused apply: all master loads of a lane in flight before the numerators are staged
+#endif
+
 namespace nmfmu {
 
 template <int R_PAD, int OPT, int MODE>
@@ -60,7 +67,8 @@ struct PPCfg {
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG;
   static constexpr int LDS_MAIN = 2 * NSLOT * IMG;
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
-  static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static constexpr int LDS_PF = NMFMU_PP_PREFETCH && !LOSS ? WAVES * 256 : 0;   // landing rows of the master prefetch
+  static constexpr int LDS_BYTES = (LDS_MAIN + LDS_PF) > LDS_EPI ? (LDS_MAIN + LDS_PF) : LDS_EPI;
   static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
   static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
   static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
@@ -243,6 +251,22 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     uint32_t gn[2][8];
     f32x16 S[2];
     u32x4 ring[PF];
+#if NMFMU_PP_PREFETCH
+    // (fused apply only) this wave's slice of the fp32 master: base, number of 128-byte lines, last valid dword offset
+    const char* pf_base = reinterpret_cast<const char*>(a.f) + (size_t)(mb * C::BM + wave * 32) * (size_t)a.rank * 4;
+    int pf_lines = 0;
+    unsigned pf_last = 0;
+    if constexpr (!C::LOSS) {
+      if (a.fuse_apply) {
+        const int rows_here = min(32, a.M - (mb * C::BM + wave * 32));
+        if (rows_here > 0) {
+          const unsigned bytes = (unsigned)rows_here * (unsigned)a.rank * 4u;
+          pf_lines = (int)((bytes + 127u) / 128u);
+          pf_last = bytes - 4u;
+        }
+      }
+    }
+#endif
 
     // operand stream of one M segment: entries 0 .. NSTEP1-1 are G1's panel rows (P1 slot of tile t), entries
     // NSTEP1 .. NSTEP1+NSTEP2-1 G2's transposed panel slices (P2 slot of tile t-1).  `sa` / `sb` are the per-lane bases
@@ -390,6 +414,24 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       p1_issue_off = next_off(p1_issue_off);
       p2_issue_off = next_off(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
+#if NMFMU_PP_PREFETCH
+      if constexpr (!tail && !C::LOSS) {
+        // The fused-apply epilogue reads this wave's 32 master rows (one contiguous 32 * rank * 4-byte block) and every
+        // workgroup reaches it at the same time: touch the block's 128-byte lines now, one line per lane and
+        // instruction, so that the reads come out of L2 / MALL then.  Issued BEFORE the X loads of this segment: the
+        // counted vmcnt(4) of the next matrix segment then retires them like the panel DMA.
+        if (pf_lines > 0 && (t == nt - 12 || t == nt - 8)) {
+          const int line = (t == nt - 12 ? 0 : 64) + lane;
+          // (LDS-DMA into a scratch row behind the rings: no destination register that could be re-used while the
+          // load is in flight; lanes past the end re-touch the last line)
+          const unsigned off = min((unsigned)min(line, pf_lines - 1) * 128u, pf_last);
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1"
+                       :
+                       : "v"(off), "s"(pf_base), "s"(lds_base + (unsigned)C::LDS_MAIN + (unsigned)wave * 256u)
+                       : "memory", "m0");
+        }
+      }
+#endif
       if constexpr (!tail) load_x(t + 2, x);   // ... before its register buffer is refilled
     };
 
@@ -486,6 +528,26 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       float den8[8], csum8[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) { den8[k] = a.kl_den[slot_e * 8 + k]; csum8[k] = 0.f; }
+      const bool vec = (a.rank & 3) == 0;
+#if NMFMU_PP_EPI_BATCH
+      // every master load of this lane is issued before the numerators go through LDS: NCH x 32 bytes in flight per lane
+      float fvall[NCH][8];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int row = mrow0 + i * (64 / SP) + rl0, r0 = slot_e * 8;
+        const float* frow = a.f + (size_t)row * a.rank + r0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool in = row < a.M && r0 + 4 * h < a.rank;
+          if (in && vec) {
+            *reinterpret_cast<float4*>(&fvall[i][4 * h]) = *reinterpret_cast<const float4*>(frow + 4 * h);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fvall[i][4 * h + k] = (in && r0 + 4 * h + k < a.rank) ? frow[4 * h + k] : 0.f;
+          }
+        }
+      }
+#endif
       // numerators -> the wave's staging tile [32][R_PAD]
       static_for<RT>([&](auto rtc) {
         constexpr int rt = decltype(rtc)::value;
@@ -493,8 +555,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hl_e) * LDT + rt * 32 + j_e] = acc[rt][e];
       });
       __syncthreads();
-      const bool vec = (a.rank & 3) == 0;
+#if NMFMU_PP_EPI_BATCH
+#pragma unroll
+#else
 #pragma unroll 2
+#endif
       for (int i = 0; i < NCH; ++i) {
         const int rl = i * (64 / SP) + rl0, row = mrow0 + rl, r0 = slot_e * 8;
         float* trow = tile + rl * LDT + r0;
@@ -502,6 +567,10 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         float fv[8], nm[8];
         *reinterpret_cast<float4*>(nm) = *reinterpret_cast<const float4*>(trow);
         *reinterpret_cast<float4*>(nm + 4) = *reinterpret_cast<const float4*>(trow + 4);
+#if NMFMU_PP_EPI_BATCH
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fv[k] = fvall[i][k];
+#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool in = row < a.M && r0 + 4 * h < a.rank;
@@ -512,6 +581,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
             for (int k = 0; k < 4; ++k) fv[4 * h + k] = (in && r0 + 4 * h + k < a.rank) ? frow[4 * h + k] : 0.f;
           }
         }
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float neg = fmaxf(nm[k], 0.f) + kEps;

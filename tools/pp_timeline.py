@@ -1,6 +1,9 @@
-"""Cycles per tile and core frequency of the ping-pong kernel's tile loop (nmfmu_pp.h with NMFMU_PP_VAR bit 128):
-waves 0 and 4 of workgroup 0 stamp the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at the
-start and at the end of the loop.  Usage (GPU box): NMFMU_PP_VAR=384 python tools/pp_timeline.py bf16"""
+"""Cycles per tile and core frequency of the ping-pong kernel's tile loop, prologue / loop / epilogue of every workgroup.
+Needs a diagnostic build of the library (clock stamps compiled in):
+    make -C pytorch-nmf_amd/csrc VARIANT=_dbg EXTRA=-DNMFMU_DEBUG_HOOKS
+    NMFMU_LIB=$PWD/pytorch-nmf_amd/torchnmf_amd/libnmfmu_dbg.so python tools/pp_timeline.py f16
+Waves 0 and 4 of workgroup 0 stamp the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at kernel
+entry, at the start and the end of the loop and at exit; every workgroup stamps the 100 MHz clock at the same points."""
 import os
 import sys
 
@@ -10,7 +13,6 @@ for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd')):
 import numpy as np
 import torch
 
-assert int(os.environ.get('NMFMU_PP_VAR', '0')) & 128, 'set NMFMU_PP_VAR with bit 128'
 from torchnmf_amd import _capi
 from torchnmf_amd.engine import DenseMU
 
@@ -43,9 +45,6 @@ for which in os.environ.get('PP_STEPS', 'h,w').split(','):
         res.append((cyc / nt, cyc / max(ref, 1) * 100.0, ref / nt * 10.0, (st[0, 1] - st[2, 1]) * 0.01, (st[3, 1] - st[1, 1]) * 0.01,
                     (st[3, 1] - st[2, 1]) * 0.01))
     r = np.array(res)
-    pr = buf.cpu().numpy()
-    print(f'   prologue of workgroup 0 (us after entry): loads issued from {(pr[40] - st[2, 1]) * 0.01:.2f}, landed {(pr[41] - st[2, 1]) * 0.01:.2f}, '
-          f'first barrier passed {(pr[42] - st[2, 1]) * 0.01:.2f}, loop starts {(st[0, 1] - st[2, 1]) * 0.01:.2f}')
     # all workgroups of the last launch: entry / loop start / loop end / exit relative to the earliest entry
     grid = (eng.step_h if which == 'h' else eng.step_w)
     nwg = (grid.owner.rows_pad // grid.block_rows) * grid.nsplit
@@ -57,7 +56,7 @@ for which in os.environ.get('PP_STEPS', 'h,w').split(','):
           f'exit {q(tt[:, 3])}; loop length {q(tt[:, 2] - tt[:, 1])}; epilogue {q(tt[:, 3] - tt[:, 2])}')
     print('   per XCC: median loop length ' + ', '.join(f'{int(x)}:{np.median((tt[:, 2] - tt[:, 1])[xcc == x]):.1f}' for x in np.unique(xcc)) +
           ' | max exit ' + ', '.join(f'{int(x)}:{tt[xcc == x, 3].max():.1f}' for x in np.unique(xcc)))
-    print(f'{prec} VAR={os.environ.get("NMFMU_PP_VAR")} {which}-step cols={Cc}: {nt} tiles/WG, cycles/tile {np.median(r[:, 0]):.0f}, '
+    print(f'{prec} lib={os.path.basename(_capi.LIB_PATH)} {which}-step cols={Cc}: {nt} tiles/WG, cycles/tile {np.median(r[:, 0]):.0f}, '
           f'core clock {np.median(r[:, 1]):.0f} MHz, {np.median(r[:, 2]):.1f} ns/tile  '
           f'=> tile loop {np.median(r[:, 2]) * nt / 1e3:.1f} us; prologue {np.median(r[:, 3]):.1f} us, epilogue {np.median(r[:, 4]):.1f} us, '
           f'workgroup 0 entry->exit {np.median(r[:, 5]):.1f} us')
