@@ -208,22 +208,27 @@ class _FactorRows:
 class StepRows:
     """The partial-sum part of a half-step restricted to owner rows [r0, r0 + n): X, owner images and slabs of that row
     range, the whole panel.  Lets the sharded H half-step run as two launches so that the first half's all-reduce
-    travels while the second half computes.  (The apply stays whole: it owns the column-sum finalize.)"""
+    travels while the second half computes.  (The apply stays whole: it owns the column-sum finalize.)
+    ``slab_num`` / ``slab_den``: storage for nsplit * n * r_pad floats each, carved by the caller out of one buffer that
+    the whole half-step shares (the row halves and the single-launch form are never live together)."""
 
-    def __init__(self, st: StepBuf, r0: int, n: int, backend, k_pad: int):
+    def __init__(self, st: StepBuf, r0: int, n: int, backend, k_pad: int, nsplit: int, slab_num, slab_den):
         s0 = st.struct
         self.owner, self.panel = _FactorRows(st.owner, r0, n, st.r_pad), st.panel
         self.xp = backend.xp_rows(st.xp, r0, n, k_pad, s0.precision)
-        dev = st.owner.f.device
-        # its own contraction split: half the row blocks want twice the workgroups per block to fill the chip
-        self.nsplit = max(st.nsplit, backend.choose_nsplit(n, k_pad, st.block_rows, dev))
+        self.nsplit = nsplit
         self.r_pad, self.block_rows = st.r_pad, st.block_rows
         self.r0, self.plane = r0, n * st.r_pad
-        self.slab_num = torch.empty(self.nsplit * self.plane, dtype=torch.float32, device=dev)
-        self.slab_den = None if st.slab_den is None else torch.empty(self.nsplit * self.plane, dtype=torch.float32, device=dev)
+        assert slab_num.numel() == nsplit * self.plane and (slab_den is None or slab_den.numel() == slab_num.numel())
+        self.slab_num, self.slab_den = slab_num, slab_den
         self.struct = _capi.Step(_ptr(self.xp), self.owner.struct, st.panel.struct, _ptr(self.slab_num), _ptr(self.slab_den),
                                  s0.rank, s0.r_pad, self.nsplit, s0.precision, s0.stage, s0.block_rows, s0.beta, s0.gamma,
                                  s0.l1, s0.l2)
+
+    @staticmethod
+    def nsplit_for(st: StepBuf, n: int, backend, k_pad: int, dev) -> int:
+        """Its own contraction split: half the row blocks want twice the workgroups per block to fill the chip."""
+        return max(st.nsplit, backend.choose_nsplit(n, k_pad, st.block_rows, dev))
 
 
 # Factory of the compute backend.  It is HipBackend in the product; the CPU test-suite swaps in an oracle-backed
@@ -360,15 +365,31 @@ class DenseMU:
             tail = self.r_pad if self.kl else self.step_h.plane
             self.xbuf = torch.empty(self.step_h.plane + tail, dtype=torch.float32, device=dev)
             # overlap: the H half-step as two row halves -- the first half's numerators are on the wire while the second
-            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0: one launch, one blocking all-reduce)
+            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0: one launch, one blocking all-reduce).  The split point
+            # defaults to the middle row block; TORCHNMF_AMD_AR_SPLIT=<fraction of the rows in the first part> moves it
+            # (to be swept on a multi-GPU node: the first part's all-reduce should just fit behind the second part's kernel)
             st = self.step_h
-            r0 = (st.owner.rows_pad // 512) * 256
+            nblk = st.owner.rows_pad // 256
+            frac = float(os.environ.get('TORCHNMF_AMD_AR_SPLIT', '0.5'))
+            r0 = min(max(int(frac * nblk + 1e-9), 1), max(nblk - 1, 1)) * 256
             self._h_rows = None
-            if (os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0' and r0 >= 256 and st.owner.rows > r0
+            if (os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0' and nblk >= 2 and st.owner.rows > r0
                     and hasattr(self.be, 'xp_rows')):
                 k_pad = st.panel.rows_pad
-                self._h_rows = [StepRows(st, 0, r0, self.be, k_pad),
-                                StepRows(st, r0, st.owner.rows_pad - r0, self.be, k_pad)]
+                parts = [(0, r0), (r0, st.owner.rows_pad - r0)]
+                ns = [StepRows.nsplit_for(st, n, self.be, k_pad, dev) for _, n in parts]
+                need = sum(k * n * self.r_pad for k, (_, n) in zip(ns, parts))
+                # one slab buffer for both forms of the half-step: re-point the whole-step slabs into it as well
+                big_n = torch.empty(max(need, st.nsplit * st.plane), dtype=torch.float32, device=dev)
+                big_d = None if st.slab_den is None else torch.empty_like(big_n)
+                st.slab_num, st.slab_den = big_n[:st.nsplit * st.plane], (None if big_d is None else big_d[:st.nsplit * st.plane])
+                st.struct.slab_num, st.struct.slab_den = _ptr(st.slab_num), _ptr(st.slab_den)
+                self._h_rows, off = [], 0
+                for k, (a0, n) in zip(ns, parts):
+                    cnt = k * n * self.r_pad
+                    self._h_rows.append(StepRows(st, a0, n, self.be, k_pad, k, big_n[off:off + cnt],
+                                                 None if big_d is None else big_d[off:off + cnt]))
+                    off += cnt
 
     # ------------------------------------------------------------------
     def refresh_images(self):

@@ -80,13 +80,15 @@ def test_column_sharded_fit_world2(tmp_path, beta, alpha):
     assert all(torch.load(tmp_path / f'bad{r}.pt') for r in range(world))
 
 
-def _worker_rows(rank, world, port, beta, overlap, out_dir):
+def _worker_rows(rank, world, port, beta, overlap, out_dir, split=None):
     for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
+    if split is not None:
+        os.environ['TORCHNMF_AMD_AR_SPLIT'] = split
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from cpu_backend import OracleBackend
@@ -137,3 +139,22 @@ def test_sharded_h_step_in_row_halves_world2(tmp_path, beta, overlap):
         assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
     assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5
     assert torch.equal(parts[0]['H'], parts[1]['H'])
+
+
+@pytest.mark.parametrize('beta', [1, 2])
+def test_sharded_fit_world4_uneven_shards_and_moved_split(tmp_path, beta):
+    """Four ranks with uneven column shards (90 columns: 23 / 23 / 22 / 22), the row split of the overlapped H half-step
+    moved with TORCHNMF_AMD_AR_SPLIT (two thirds of the row blocks in the first part): same factors on every rank, the
+    unsharded oracle's result, the same stop decision."""
+    from oracle import mu_oracle as O
+    world = 4
+    mp.spawn(_worker_rows, args=(world, _free_port(), beta, '1', str(tmp_path), '0.67'), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    V, W0, H0 = _tall_problem(beta)
+    assert [e - s for s, e in O.shard_bounds(V.shape[1], world)] == [23, 23, 22, 22]
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 25, 0.05, 0.5)
+    for p in parts:
+        assert p['rows'] == [(0, 512, 512), (512, 188, 256)]
+        assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
+        assert torch.equal(p['H'], parts[0]['H'])
+    assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5
