@@ -481,7 +481,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         def step():
             trainer.step(closure)
         step()
-        eng = next(iter(trainer._engines.values()))[0] if trainer._engines else trainer._last_uncached
+        eng = next(iter(trainer._engines.values()))[0]
     else:
         eng = DenseMU(V, W, H, beta, precision=precision, group=group, block_rows=a.block_rows)
 

@@ -70,8 +70,8 @@ class HipBackend:
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
     # -- device work
-    def pack_x(self, V, transpose, precision, block_rows, m_pad, k_pad, flags):
-        xp = self.alloc(self.lib.nmfmu_xp_bytes(m_pad, k_pad, precision), V.device)
+    def pack_x(self, V, transpose, precision, block_rows, m_pad, k_pad, flags, out=None):
+        xp = out if out is not None else self.alloc(self.lib.nmfmu_xp_bytes(m_pad, k_pad, precision), V.device)
         _capi.check(self.lib.nmfmu_pack_x(V.data_ptr(), V.stride(0), V.shape[0], V.shape[1], int(transpose), precision,
                                           block_rows, xp.data_ptr(), m_pad, k_pad, _ptr(flags), self.stream()),
                     'nmfmu_pack_x')
@@ -392,6 +392,20 @@ class DenseMU:
                     off += cnt
 
     # ------------------------------------------------------------------
+    def repack_target(self, V):
+        """Pack a new target of the same shape into the existing buffers (both orientations) and re-run the validation
+        of nmf.py:329-336; the factors, images and slabs stay.  Used by trainer.BetaMu for targets it has to convert on
+        every step (non-fp32 / strided tensors whose source may have changed in place)."""
+        st = self.step_h
+        assert tuple(V.shape) == (st.owner.rows, st.panel.rows), 'repack_target: shape differs from the bound target'
+        if V.stride(1) != 1 or V.dtype != torch.float32:
+            V = V.float().contiguous()
+        self.flags.copy_(torch.tensor([0, 0x7f800000], dtype=torch.int32))
+        self.be.pack_x(V, False, self.precision, st.block_rows, st.owner.rows_pad, st.panel.rows_pad, self.flags, out=st.xp)
+        if self.step_w is not None:
+            sw = self.step_w
+            self.be.pack_x(V, True, self.precision, sw.block_rows, sw.owner.rows_pad, sw.panel.rows_pad, None, out=sw.xp)
+
     def refresh_images(self):
         """Re-derive bf16 images / column sums from the fp32 masters (after external edits of W / H)."""
         self.be.pack_factor(self.fW, self.rank, self.r_pad, self.precision)

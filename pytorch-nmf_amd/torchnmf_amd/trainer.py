@@ -88,14 +88,19 @@ class BetaMu(Optimizer):
         place.  ``V_user`` is the tensor the closure returned, ``V`` its detached fp32 contiguous form (``converted`` says
         whether that needed a copy).  The cache entry holds a reference to ``V_user`` and is keyed on that object's identity
         and ``_version`` -- never on the address of a converted temporary, whose storage the caching allocator hands out
-        again -- and a target that had to be converted is packed afresh on every step (its source may have been edited
-        in place without bumping anything we can see).  One engine per (target, W, H, beta, l1, l2): param groups with
+        again -- and a target that had to be converted is packed afresh on every step INTO THE SAME
+        BUFFERS (its source may have been edited in place without bumping anything we can see; the engine, its images
+        and slabs are kept).  One engine per (target, W, H, beta, l1, l2): param groups with
         different hyper-parameters keep their own packed target instead of evicting each other."""
         key = (id(V_user), tuple(V.shape), W.data_ptr(), H.data_ptr(), float(beta), float(l1), float(l2))
-        hit = None if converted else self._engines.get(key)
+        hit = self._engines.get(key)
         versions = [V_user._version, W._version, H._version]
-        if hit is not None and hit[2] is V_user and hit[1][0] == versions[0]:
+        if hit is not None and hit[2] is V_user and (converted or hit[1][0] == versions[0]):
             eng, seen, _ = hit
+            if converted:                              # same buffers, fresh contents: pack + validate, nothing else
+                eng.repack_target(V)
+                bad, _ = eng.target_flags()
+                assert not bad, "Target should be non-negative."
             if seen[1:] != versions[1:]:               # someone else edited W / H since our last update
                 eng.refresh_images()
                 seen[1:] = versions[1:]
@@ -107,10 +112,7 @@ class BetaMu(Optimizer):
         eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=self._precision)
         bad, _ = eng.target_flags()
         assert not bad, "Target should be non-negative."
-        if not converted:
-            self._engines[key] = (eng, versions, V_user)
-        else:
-            self._last_uncached = eng                  # (bench / tests look the live engine up)
+        self._engines[key] = (eng, versions, V_user)
         return eng
 
     def _chain_step(self, V, X0, Ws, p, beta, l1, l2, ortho):

@@ -1526,9 +1526,12 @@ def test_betamu_converted_target_is_repacked(dev):
     m = NMF(W=W0, H=H0).to(dev)
     tr = BetaMu(m.parameters(), beta=1, precision='bf16x3')
     tr.step(lambda: (V64, m))
+    eng0 = next(iter(tr._engines.values()))[0]
     V64.mul_(3.0)                                   # same storage, same object, new values
     Wb, Hb = m.W.data.cpu().clone(), m.H.data.cpu().clone()
     tr.step(lambda: (V64, m))
+    # ... and without rebuilding the engine: same buffers, target packed afresh into them
+    assert len(tr._engines) == 1 and next(iter(tr._engines.values()))[0] is eng0
     # the update must have used the NEW target: compare with a fresh optimizer on a fresh fp32 copy
     m2 = NMF(W=Wb, H=Hb).to(dev)
     tr2 = BetaMu(m2.parameters(), beta=1, precision='bf16x3')
