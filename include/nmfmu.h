@@ -87,6 +87,8 @@ typedef struct nmfmu_step {
   float beta;
   float gamma;         /* nmf.py:341-346 */
   float l1, l2;        /* nmf.py:348-349 */
+  uint32_t* status;    /* NULL or one device word (ABI 4): bit 0 is OR-ed in when an update had to clamp a factor value
+                          at 65504 for its fp16 image (NMFMU_PREC_F16) -- the fit has left the mode's range           */
 } nmfmu_step;
 
 /* ---- static queries (host only, no device work) ------------------------------------------------------------ */

@@ -26,6 +26,7 @@ struct ApplyArgs {
   float ortho;
   float* grad;          // [rows][rank] or nullptr
   int f16;              // images in fp16 (clamped to 65504) instead of bf16; no lo planes
+  uint32_t* status;     // or nullptr: bit 0 is set when an fp16 image value had to be clamped
 };
 
 int apply_stripe_rows(int rows_pad);   // rows per apply workgroup (= rows per column-sum partial): 16 or 64

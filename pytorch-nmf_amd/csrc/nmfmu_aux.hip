@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
 
   // P1: ROWS rows x (R_PAD/8) sixteen-byte slots, swizzled inside each row
   constexpr int SP = R_PAD / 8;
+  bool clamped = false;   // fp16 images: a factor value above 65504 is stored as 65504 -- tell the caller (status word)
   for (int idx = tid; idx < ROWS * SP; idx += 256) {
     const int rl = idx / SP, slot = idx - rl * SP;
     const float* src = tile + rl * LDT + slot * 8;
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float x0 = src[2 * i], x1 = src[2 * i + 1];
+      clamped |= fmaxf(x0, x1) > 65504.f;
       const uint32_t h = pack_img(x0, x1, a.f16);
       hi[i] = h;
       lo[i] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_hi) + off) = hi;
     if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p1_lo) + off) = lo;
   }
+  if (a.f16 && a.status && __any(clamped) && (tid & 63) == 0) atomicOr(a.status, 1u);
   // P2: [R_PAD][64] tiles; this block owns ROWS/8 of the 8 slots (8 consecutive factor rows each) of every rank row
   constexpr int NS = ROWS / 8;
   for (int idx = tid; idx < R_PAD * NS; idx += 256) {

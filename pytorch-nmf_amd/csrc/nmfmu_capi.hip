@@ -69,6 +69,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   a.nsplit = st->nsplit;
   a.tiles_per_split = (a.ktiles + st->nsplit - 1) / st->nsplit;
   a.beta = st->beta;
+  a.status = st->status;
   a.cs_owner = st->owner.colsum;   // fp16 operands, beta < 1: typical S -> scale of Gn / Gp (nmfmu_fused.h)
   a.cs_panel = st->panel.colsum;
   if (fuse_kl_den) {  // beta == 1, nsplit == 1: apply in the epilogue
@@ -285,6 +286,7 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   a.trainer = trainer, a.ortho = ortho, a.grad = grad;
   a.f16 = st->precision == NMFMU_PREC_F16;
+  a.status = st->status;
   if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
 }

@@ -44,6 +44,10 @@
 
 #include "nmfmu_layout.h"
 
+#ifndef NMFMU_FUSED_G1_ASM
+#define NMFMU_FUSED_G1_ASM 1
+#endif
+
 namespace nmfmu {
 
 constexpr float kEps = 1.1920928955078125e-07f;  // constants.py:3 of the reference
@@ -102,6 +106,7 @@ struct FusedArgs {
   // fp16 operands, beta < 1: column sums of owner and panel ([R_PAD] each) -> typical S -> power-of-two scale of Gn / Gp
   const float* cs_owner;
   const float* cs_panel;
+  uint32_t* status;       // or nullptr: bit 0 is set when the fused apply had to clamp an fp16 image value at 65504
   void* debug;            // NMFMU_DEBUG_HOOKS builds: clock stamps of the ping-pong kernel (tools/pp_timeline.py)
 };
 
@@ -130,6 +135,8 @@ struct FusedCfg {
   // fp16 operands: Gn / Gp of the branches with negative powers of S carry a power-of-two scale
   static constexpr bool SCALE = F16 && !LOSS && (BETA == kIS || BETA == kGen || BETA == kSqrt);
   static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128) ? 1 : 2;
+  // GEMM1 as asm with VGPR constraints (see compute()): the single-plane instances that run one wave per SIMD
+  static constexpr bool G1_ASM = NMFMU_FUSED_G1_ASM && !X3 && MINW == 1;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -428,16 +435,39 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
           s[tt] = mfma_bf16(al, qh[kk], kk == 0 ? epsv : s[tt]);
           s[tt] = mfma_bf16(ah, ql[kk], s[tt]);
           s[tt] = mfma_bf16(ah, qh[kk], s[tt]);
+        } else if constexpr (C::G1_ASM) {
+          // The one-wave-per-SIMD instances keep their rank-wide accumulators in AGPRs, and hipcc then selects the
+          // AGPR form for EVERY MFMA of the kernel: the S tiles would be seeded with 32 v_accvgpr_write and read back
+          // with 32+ v_accvgpr_read per tile (a quarter of the loop's instructions).  Written as asm with VGPR
+          // constraints the S tiles stay where the elementwise stage needs them.
+          if (kk == 0) {
+            if constexpr (BETA == kEuc) {
+              if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
+              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
+            } else {
+              if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
+              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
+            }
+          } else {
+            if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
+          }
         } else {
           s[tt] = mfma_op<OPT>(ah, qh[kk], kk == 0 ? epsv : s[tt]);
         }
       }
-      // pin the software pipeline: PF reads up front, then one read behind every MFMA group
-      __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 0);
+      // asm MFMAs are not padded by hipcc: the S tiles are read by the VALU next (XDL write -> VALU read, 18 wait states
+      // after a 16-pass MFMA)
+      if constexpr (C::G1_ASM) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]));
+      // pin the software pipeline: PF reads up front, then one read behind every MFMA group (the asm MFMAs keep their
+      // program order by themselves)
+      if constexpr (!C::G1_ASM) {
+        __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 0);
 #pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 3 : 1, 0);
-        if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
+        for (int step = 0; step < NSTEP; ++step) {
+          __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 3 : 1, 0);
+          if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
+        }
       }
     }
     // ---------------- elementwise: Gn / Gp (or the loss terms), packed to 16-bit A operands
@@ -644,6 +674,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         __syncthreads();
         // row-major image from the LDS tile: 32 rows x R_PAD/8 sixteen-byte slots per wave
         constexpr int SP = R_PAD / 8;
+        bool clamped = false;
 #pragma unroll
         for (int i = 0; i < (32 * SP) / 64; ++i) {
           const int chunk = i * 64 + lane, rl = chunk / SP, slot = chunk % SP;
@@ -652,6 +683,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float x0 = src[2 * q], x1 = src[2 * q + 1];
+            if constexpr (C::F16) clamped |= fmaxf(x0, x1) > 65504.f;
             const uint32_t h = pack_op<OPT>(x0, x1);
             hi[q] = h;
             if constexpr (X3) lo[q] = pack_bf16(x0 - bf16_lo(h), x1 - bf16_hi(h));
@@ -659,6 +691,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
           const int64_t off = p1_offset(mrow0 + rl, slot * 8, R_PAD);
           *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + off) = hi;
           if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_lo) + off) = lo;
+        }
+        if constexpr (C::F16) {
+          if (a.status && __any(clamped) && lane == 0) atomicOr(a.status, 1u);
         }
         __syncthreads();
         // partial column sums of this workgroup's rows: lane halves, then the waves (fixed order)

@@ -50,6 +50,9 @@
 #ifndef NMFMU_PP_EPI_BATCH
 #define NMFMU_PP_EPI_BATCH 0  // fused apply: all master loads of a lane in flight before the numerators are staged
 #endif
+#ifndef NMFMU_PP_EPI_PLAIN
+#define NMFMU_PP_EPI_PLAIN 1  // fused apply: branch-free form for the unregularised full-tile case
+#endif
 
 namespace nmfmu {
 
@@ -529,6 +532,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { den8[k] = a.kl_den[slot_e * 8 + k]; csum8[k] = 0.f; }
       const bool vec = (a.rank & 3) == 0;
+      bool clamped = false;   // fp16 images saturate at 65504 (MODE.FP16_OVFL): reported through a.status
 #if NMFMU_PP_EPI_BATCH
       // every master load of this lane is issued before the numerators go through LDS: NCH x 32 bytes in flight per lane
       float fvall[NCH][8];
@@ -555,6 +559,42 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hl_e) * LDT + rt * 32 + j_e] = acc[rt][e];
       });
       __syncthreads();
+      // The common case -- no regularisation (gamma == 1 follows from 1 <= beta <= 2), every row and rank of the tile
+      // valid -- without the per-element branches, bounds tests and IEEE divisions of the general form below: the
+      // denominators are the same for every row, so their reciprocals are taken once (the multiplier then differs from
+      // the correctly rounded quotient by at most one ulp).
+      const bool plain = NMFMU_PP_EPI_PLAIN && a.l1 <= 0.f && a.l2 <= 0.f && a.gamma == 1.f && a.rank == R_PAD &&
+                         mb * C::BM + C::BM <= a.M;
+      if (plain) {
+        float rden8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rden8[k] = 1.f / den8[k];
+#pragma unroll 4
+        for (int i = 0; i < NCH; ++i) {
+          const int rl = i * (64 / SP) + rl0, row = mrow0 + rl, r0 = slot_e * 8;
+          float* trow = tile + rl * LDT + r0;
+          float* frow = a.f + (size_t)row * R_PAD + r0;
+          float fv[8], nm[8];
+          *reinterpret_cast<float4*>(fv) = *reinterpret_cast<const float4*>(frow);
+          *reinterpret_cast<float4*>(fv + 4) = *reinterpret_cast<const float4*>(frow + 4);
+          *reinterpret_cast<float4*>(nm) = *reinterpret_cast<const float4*>(trow);
+          *reinterpret_cast<float4*>(nm + 4) = *reinterpret_cast<const float4*>(trow + 4);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            fv[k] *= (fmaxf(nm[k], 0.f) + kEps) * rden8[k];
+            csum8[k] += fv[k];
+            if constexpr (OPT == kOpF16) clamped |= fv[k] > 65504.f;
+          }
+          *reinterpret_cast<float4*>(frow) = *reinterpret_cast<const float4*>(fv);
+          *reinterpret_cast<float4*>(frow + 4) = *reinterpret_cast<const float4*>(fv + 4);
+          *reinterpret_cast<float4*>(trow) = *reinterpret_cast<const float4*>(fv);
+          *reinterpret_cast<float4*>(trow + 4) = *reinterpret_cast<const float4*>(fv + 4);
+          u32x4 hi;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(fv[2 * qq], fv[2 * qq + 1]);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(row, r0, R_PAD)) = hi;
+        }
+      } else
 #if NMFMU_PP_EPI_BATCH
 #pragma unroll
 #else
@@ -593,6 +633,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           // padding rows / ranks stay exactly 0 (their denominators may be 0: 0 * inf)
           fv[k] = (row < a.M && r0 + k < a.rank) ? fv[k] * mult : 0.f;
           csum8[k] += fv[k];
+          if constexpr (OPT == kOpF16) clamped |= fv[k] > 65504.f;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -611,6 +652,9 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(fv[2 * qq], fv[2 * qq + 1]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(row, r0, R_PAD)) = hi;
+      }
+      if constexpr (OPT == kOpF16) {
+        if (a.status && __any(clamped) && lane_e == 0) atomicOr(a.status, 1u);
       }
       __syncthreads();
       // transposed image from the updated tile: 8 consecutive owner rows of one rank = one sixteen-byte slot

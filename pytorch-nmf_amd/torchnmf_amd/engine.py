@@ -180,7 +180,7 @@ class StepBuf:
     """One half-step: X in fragment order, owner/panel factors, partial-sum slabs."""
 
     def __init__(self, xp, owner: FactorBuf, panel: FactorBuf, rank, r_pad, nsplit, precision, stage, block_rows, beta,
-                 gamma, l1, l2, need_den: bool):
+                 gamma, l1, l2, need_den: bool, status=None):
         self.xp, self.owner, self.panel = xp, owner, panel
         self.nsplit, self.r_pad, self.block_rows = nsplit, r_pad, block_rows
         dev = owner.f.device
@@ -188,7 +188,7 @@ class StepBuf:
         self.slab_num = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev)
         self.slab_den = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev) if need_den else None
         self.struct = _capi.Step(_ptr(xp), owner.struct, panel.struct, _ptr(self.slab_num), _ptr(self.slab_den), rank,
-                                 r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2)
+                                 r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2, _ptr(status))
 
 
 class _FactorRows:
@@ -223,7 +223,7 @@ class StepRows:
         self.slab_num, self.slab_den = slab_num, slab_den
         self.struct = _capi.Step(_ptr(self.xp), self.owner.struct, st.panel.struct, _ptr(self.slab_num), _ptr(self.slab_den),
                                  s0.rank, s0.r_pad, self.nsplit, s0.precision, s0.stage, s0.block_rows, s0.beta, s0.gamma,
-                                 s0.l1, s0.l2)
+                                 s0.l1, s0.l2, s0.status)
 
     @staticmethod
     def nsplit_for(st: StepBuf, n: int, backend, k_pad: int, dev) -> int:
@@ -334,6 +334,8 @@ class DenseMU:
         self.fH = FactorBuf(H, self.r_pad, self.precision, self.be)
         # validation flags of nmf.py:329-336: [any(!(v >= 0)), min bit pattern]
         self.flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
+        # fp16 mode: bit 0 is set by any update that had to clamp a factor value at 65504 for its fp16 image
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         n_pad, c_pad = self.fH.rows_pad, self.fW.rows_pad
         # tile height per half-step (the two packed copies of V are independent): the library's choice, or forced
         def tile_rows(m_pad, k_pad):
@@ -348,14 +350,14 @@ class DenseMU:
         xp_h = self.be.pack_x(V, False, self.precision, br, n_pad, c_pad, self.flags)
         ns_h = self.be.choose_nsplit(n_pad, c_pad, br, dev)
         self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, br, self.beta, gamma,
-                              l1, l2, need_den=not self.kl)
+                              l1, l2, need_den=not self.kl, status=self.status)
         self.step_w = None
         if update_W:
             brw = tile_rows(c_pad, n_pad)
             xp_w = self.be.pack_x(V, True, self.precision, brw, c_pad, n_pad, None)
             ns_w = self.be.choose_nsplit(c_pad, n_pad, brw, dev)
             self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, brw, self.beta,
-                                  gamma, l1, l2, need_den=not self.kl)
+                                  gamma, l1, l2, need_den=not self.kl, status=self.status)
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
         self.refresh_images()
         self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
@@ -507,6 +509,11 @@ class DenseMU:
         other = self.fH if which == 'W' else self.fW
         self._partial(st, which.lower())
         self.be.trainer_apply(st, other.colsum if self.kl else None, ortho, grad)
+
+    def left_f16_range(self) -> bool:
+        """fp16 mode: has any update so far clamped a factor value at 65504 for its image?  (One small device read; fit()
+        asks at its loss checkpoints, where it synchronises anyway.)"""
+        return self.precision == _capi.PREC_F16 and bool(int(self.status.item()) & 1)
 
     def divergence(self) -> float:
         """beta_div(H W^T, V) (nmf.py:360-361 / 400-401), summed over shards.  One host sync."""

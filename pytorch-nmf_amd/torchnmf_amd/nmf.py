@@ -171,6 +171,7 @@ class BaseComponent(nn.Module):
             from tqdm import tqdm
             pbar = tqdm(total=max_iter)
         n_iter = -1
+        warned = False
         try:
             for n_iter in range(max_iter):
                 if W.requires_grad:
@@ -179,6 +180,12 @@ class BaseComponent(nn.Module):
                     eng.h_step()
                 if n_iter % 10 == 9:
                     loss = _sqrt2(eng.divergence())
+                    if not warned and getattr(eng, 'left_f16_range', None) is not None and eng.left_f16_range():
+                        import warnings
+                        warned = True
+                        warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during the fit; its fp16 "
+                                      "operand image is clamped from here on and the updates no longer follow the "
+                                      "reference.  Re-run with precision='bf16x3' (or rescale V).")
                     if pbar is not None:
                         pbar.set_postfix(loss=loss)
                         pbar.update(10)

@@ -35,7 +35,7 @@ class OracleBackend:
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
     # ---- "device" work -----------------------------------------------------------------------
-    def pack_x(self, V, transpose, precision, block_rows, m_pad, k_pad, flags):
+    def pack_x(self, V, transpose, precision, block_rows, m_pad, k_pad, flags, out=None):
         if flags is not None:
             bad = int(not bool(torch.all(V >= 0)))
             mn = int(V.abs().min().view(torch.int32)) if V.numel() else 0x7f800000
