@@ -34,7 +34,8 @@ extern "C" {
 #define NMFMU_ABI_VERSION 4 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
                                3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
-                                  nmfmu_parts_supported removed (measured neutral); NMFMU_STAGE_REG no longer built */
+                                  nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
+                                  NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -242,9 +243,8 @@ typedef struct nmfmu_gemm_desc {
    * window table that is only 8x H.  ops selects which operand is implicit; its hi / lo pointers then address the table. */
   int32_t ops;              /* NMFMU_OPS_* */
   int32_t t_batch, t_rank, t_taps, t_lh; /* B, R, T, Lh of H (implicit operands and NMFMU_EPI_FOLD) */
-  /* Workgroup tile: 0 or 128 = 128 x 128 (every combination); 256 = 256 x 256, half the operand traffic per MFMA
-   * (m_pad and n_pad multiples of 256; BF16 only; RATIO / LOSS at beta == 1, F32, FOLD -- nmfmu_gemm_tile256_supported,
-   * else NMFMU_ERR_UNSUPPORTED). */
+  /* Workgroup tile: 0 or 128 = 128 x 128.  (ABI 3 also had a 256 x 256 tile; without a stream-K scheduler it never
+   * paid at the BASELINE shapes and is no longer built: NMFMU_ERR_UNSUPPORTED.) */
   int32_t tile_rows;
   /* Leading dimension of x / gn / gp / out when the GEMM covers only the first n_pad columns of wider matrices
    * (0 = n_pad).  Together with a reduced m_pad this lets a caller leave a few ragged rows / columns to
@@ -273,7 +273,6 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
                       void* fwd_lo, void* stream);
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
-int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops);
 /* NMFMU_PREC_F16 in the GEMM engine: fp16 operand planes / window tables (nmfmu_conv_tables_f16,
  * nmfmu_conv_apply_pack_w_sums with precision F16) and fp16 ratio planes, one plane each, same MFMA rate as bf16 with
  * 11 significant bits; ratios saturate at 65504.  Built for the combinations of the beta == 1 NMFD iteration on implicit

@@ -32,6 +32,10 @@
 //            bottom of fp16's range, so Gn and Gp are multiplied by a power of two derived from the factors' column
 //            sums (identical in every workgroup) before the conversion; the epilogue scales the accumulators back.
 //
+// Tried and measured slower (round 3, profiles/r03_clock.md): a cross-tile software pipeline for the two-accumulator
+// instances (elementwise of tile t interleaved with GEMM2 of tile t-1 through sched_group_barrier, three LDS stages):
+// hipcc's placement degraded the counted LDS waits to lgkmcnt(0) -- 2 120 instead of 2 330 it/s at beta = 2, rank 128.
+//
 // Workgroup = 4 waves (one per SIMD), wave w owns rows 32w..32w+31 of the
 // block.  The panel tile (64 rows of B, both images) is double-buffered in
 // LDS, filled by LDS-DMA (global_load_lds, issued from inline asm so that hipcc keeps its counted lgkmcnt waits for
@@ -128,15 +132,16 @@ struct FusedCfg {
   static constexpr int P2HI = NPL * IMG;
   static constexpr int P2LO = NPL * IMG + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
   static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
   // fp16 operands: Gn / Gp of the branches with negative powers of S carry a power-of-two scale
   static constexpr bool SCALE = F16 && !LOSS && (BETA == kIS || BETA == kGen || BETA == kSqrt);
   static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128) ? 1 : 2;
-  // GEMM1 as asm with VGPR constraints (see compute()): the single-plane instances that run one wave per SIMD
+  // GEMM1 as asm with VGPR constraints (see gemm1()): the single-plane instances that run one wave per SIMD
   static constexpr bool G1_ASM = NMFMU_FUSED_G1_ASM && !X3 && MINW == 1;
+  static constexpr int NSTAGE = 2;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -379,13 +384,13 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   // Issued from inline asm on purpose: while hipcc knows an LDS-DMA is in flight it turns every LDS wait into
   // lgkmcnt(0), which serialises the operand prefetch rings.  Completion is waited for explicitly (vmcnt(0) before the
   // tile's barrier, see the main loop).  M0 = LDS byte address of the wave's 1 KiB piece.
-  auto stage_issue = [&](int t, int buf) {
+  auto stage_issue = [&](int t, int stage_off) {   // stage_off: byte offset of the LDS stage
 #pragma unroll
     for (int im = 0; im < C::NIMG; ++im) {
       const char* src = img_src[im] + (size_t)t * IMG + tid * 16;
 #pragma unroll
       for (int p = 0; p < C::PASSES; ++p) {
-        const unsigned lds_addr = lds_base + (unsigned)(buf * C::STAGE_BYTES + im * IMG + p * 4096) + wave_lds;
+        const unsigned lds_addr = lds_base + (unsigned)(stage_off + im * IMG + p * 4096) + wave_lds;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                      :
                      : "v"(src + p * 4096), "s"(lds_addr)
@@ -397,81 +402,88 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   f32x16 epsv;
 #pragma unroll
   for (int e = 0; e < 16; ++e) epsv[e] = (BETA == kEuc) ? 0.f : kEps;
+  // asm GEMM1: the seed tile is laundered through an empty asm so that hipcc keeps it resident instead of
+  // re-materialising it with v_mov right in front of the (asm, hence unpadded) MFMA that reads it as its C operand --
+  // a VALU write -> XDL SrcC read hazard (seen at padded rank 32, where nothing else sits between the two)
+  if constexpr (C::G1_ASM && BETA != kEuc) asm volatile("" : "+v"(epsv));
 
-  auto compute = [&](int t, int buf, u32x4(&x)[NQ], int t_next) {
-    const char* sb = smem + buf * C::STAGE_BYTES;
-    // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank.
-    // The panel operands are fetched through a PF-deep register ring so that PF-1 ds_read_b128 are always in
-    // flight behind the MFMA that is issuing (hipcc otherwise emits read -> lgkmcnt(0) -> mfma, one at a time).
-    // The accumulators are seeded with eps through the C operand of each chain's first MFMA (seed tile `epsv`,
-    // loop invariant) instead of being re-initialised with 16 moves per tile.
-    f32x16 s[2];
-    {
-      constexpr int NSTEP = 2 * KS;
-      constexpr int PF = NSTEP < 4 ? NSTEP : 4;
-      u32x4 ring_h[PF];
-      u32x4 ring_l[X3 ? PF : 1];
-      // step -> (kk, tt): the two S^T tiles alternate, so consecutive MFMAs never share an accumulator
-      auto a_off = [&](int step) {
-        const int tt = step & 1, kk = step >> 1;
-        return a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
-      };
+  // The 16-bit A operands of GEMM2 (Gn, Gp; hi / lo planes), one set per tile
+  struct GOps {
+    uint32_t gnh[2][8], gnl[X3 ? 2 : 1][8], gph[C::TWO_ACC ? 2 : 1][8], gpl[(C::TWO_ACC && X3) ? 2 : 1][8];
+  };
+
+  // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank.
+  // The panel operands are fetched through a PF-deep register ring so that PF-1 ds_read_b128 are always in
+  // flight behind the MFMA that is issuing (hipcc otherwise emits read -> lgkmcnt(0) -> mfma, one at a time).
+  // The accumulators are seeded with eps through the C operand of each chain's first MFMA (seed tile `epsv`,
+  // loop invariant) instead of being re-initialised with 16 moves per tile.
+  auto gemm1 = [&](const char* sb, f32x16(&s)[2]) {
+    constexpr int NSTEP = 2 * KS;
+    constexpr int PF = NSTEP < 4 ? NSTEP : 4;
+    u32x4 ring_h[PF];
+    u32x4 ring_l[X3 ? PF : 1];
+    // step -> (kk, tt): the two S^T tiles alternate, so consecutive MFMAs never share an accumulator
+    auto a_off = [&](int step) {
+      const int tt = step & 1, kk = step >> 1;
+      return a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]);
+    };
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        ring_h[p] = ld16(sb + C::P1HI + a_off(p));
-        if constexpr (X3) ring_l[p] = ld16(sb + C::P1LO + a_off(p));
+    for (int p = 0; p < PF; ++p) {
+      ring_h[p] = ld16(sb + C::P1HI + a_off(p));
+      if constexpr (X3) ring_l[p] = ld16(sb + C::P1LO + a_off(p));
+    }
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int tt = step & 1, kk = step >> 1;
+      const u32x4 ah = ring_h[step % PF];
+      u32x4 al;
+      if constexpr (X3) al = ring_l[step % PF];
+      if (step + PF < NSTEP) {
+        ring_h[step % PF] = ld16(sb + C::P1HI + a_off(step + PF));
+        if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P1LO + a_off(step + PF));
       }
-#pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        const int tt = step & 1, kk = step >> 1;
-        const u32x4 ah = ring_h[step % PF];
-        u32x4 al;
-        if constexpr (X3) al = ring_l[step % PF];
-        if (step + PF < NSTEP) {
-          ring_h[step % PF] = ld16(sb + C::P1HI + a_off(step + PF));
-          if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P1LO + a_off(step + PF));
-        }
-        if constexpr (X3) {
-          s[tt] = mfma_bf16(al, qh[kk], kk == 0 ? epsv : s[tt]);
-          s[tt] = mfma_bf16(ah, ql[kk], s[tt]);
-          s[tt] = mfma_bf16(ah, qh[kk], s[tt]);
-        } else if constexpr (C::G1_ASM) {
-          // The one-wave-per-SIMD instances keep their rank-wide accumulators in AGPRs, and hipcc then selects the
-          // AGPR form for EVERY MFMA of the kernel: the S tiles would be seeded with 32 v_accvgpr_write and read back
-          // with 32+ v_accvgpr_read per tile (a quarter of the loop's instructions).  Written as asm with VGPR
-          // constraints the S tiles stay where the elementwise stage needs them.
-          if (kk == 0) {
-            if constexpr (BETA == kEuc) {
-              if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
-              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
-            } else {
-              if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
-              else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
-            }
+      if constexpr (X3) {
+        s[tt] = mfma_bf16(al, qh[kk], kk == 0 ? epsv : s[tt]);
+        s[tt] = mfma_bf16(ah, ql[kk], s[tt]);
+        s[tt] = mfma_bf16(ah, qh[kk], s[tt]);
+      } else if constexpr (C::G1_ASM) {
+        // The one-wave-per-SIMD instances keep their rank-wide accumulators in AGPRs, and hipcc then selects the
+        // AGPR form for EVERY MFMA of the kernel: the S tiles would be seeded with 32 v_accvgpr_write and read back
+        // with 32+ v_accvgpr_read per tile (a quarter of the loop's instructions).  Written as asm with VGPR
+        // constraints the S tiles stay where the elementwise stage needs them.
+        if (kk == 0) {
+          if constexpr (BETA == kEuc) {
+            if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]));
           } else {
-            if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
-            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
+            if constexpr (OPT == kOpF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[tt]) : "v"(ah), "v"(qh[0]), "v"(epsv));
           }
         } else {
-          s[tt] = mfma_op<OPT>(ah, qh[kk], kk == 0 ? epsv : s[tt]);
+          if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
+          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[tt]) : "v"(ah), "v"(qh[kk]));
         }
-      }
-      // asm MFMAs are not padded by hipcc: the S tiles are read by the VALU next (XDL write -> VALU read, 18 wait states
-      // after a 16-pass MFMA)
-      if constexpr (C::G1_ASM) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]));
-      // pin the software pipeline: PF reads up front, then one read behind every MFMA group (the asm MFMAs keep their
-      // program order by themselves)
-      if constexpr (!C::G1_ASM) {
-        __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 0);
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-          __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 3 : 1, 0);
-          if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
-        }
+      } else {
+        s[tt] = mfma_op<OPT>(ah, qh[kk], kk == 0 ? epsv : s[tt]);
       }
     }
-    // ---------------- elementwise: Gn / Gp (or the loss terms), packed to 16-bit A operands
-    uint32_t gnh[2][8], gnl[X3 ? 2 : 1][8], gph[C::TWO_ACC ? 2 : 1][8], gpl[(C::TWO_ACC && X3) ? 2 : 1][8];
+    // asm MFMAs are not padded by hipcc: the S tiles are read by the VALU next (XDL write -> VALU read, 18 wait states
+    // after a 16-pass MFMA)
+    if constexpr (C::G1_ASM) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]));
+    // pin the software pipeline: PF reads up front, then one read behind every MFMA group (the asm MFMAs keep their
+    // program order by themselves)
+    if constexpr (!C::G1_ASM) {
+      __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 0);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 3 : 1, 0);
+        if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 0);
+      }
+    }
+  };
+
+  // ---------------- elementwise: Gn / Gp (or the loss terms) of tile t, packed to 16-bit A operands
+  auto elementwise = [&](int t, const f32x16(&s)[2], const u32x4(&x)[NQ], GOps& g) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
@@ -506,89 +518,98 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
             mu_elem<BETA>(s1, x1, a.beta, n1, p1);
           }
           if constexpr (C::DEN) n0 = p0, n1 = p1;   // denominator-only pass: the one operand set carries Gp
-          const uint32_t nh = pack_op<OPT>(n0, n1);
-          gnh[tt][d] = nh;
-          if constexpr (X3) gnl[tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
+          // (beta == 2 with one operand plane: Gn IS the stored target word -- no unpack / re-pack)
+          const uint32_t nh = (BETA == kEuc && !X3 && !C::DEN) ? x[2 * tt + (d >> 2)][d & 3] : pack_op<OPT>(n0, n1);
+          g.gnh[tt][d] = nh;
+          if constexpr (X3) g.gnl[tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
           if constexpr (C::TWO_ACC) {
             const uint32_t ph = pack_op<OPT>(p0, p1);
-            gph[tt][d] = ph;
-            if constexpr (X3) gpl[tt][d] = pack_bf16(p0 - bf16_lo(ph), p1 - bf16_hi(ph));
+            g.gph[tt][d] = ph;
+            if constexpr (X3) g.gpl[tt][d] = pack_bf16(p0 - bf16_lo(ph), p1 - bf16_hi(ph));
           }
         }
-      }
-    }
-    // X's registers are dead from here on: fetch the next tile into them now (single X buffer; the loads have the
-    // whole GEMM2 + barrier + next GEMM1 to land).
-    if (t_next >= 0) load_x(t_next, x);
-    // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
-    if constexpr (!C::LOSS) {
-      constexpr int NSTEP = RT * 4;
-      constexpr int PF = 4;
-      u32x4 ring_h[PF];
-      u32x4 ring_l[X3 ? PF : 1];
-      // step -> ((tt, m2), rt): rank tiles innermost, so consecutive MFMAs cycle through the RT accumulators
-      auto b_offs = [&](int step) {
-        const int rt = step % RT, c = step / RT;
-        return rt * 4096 + b_row + b_off[c >> 1][c & 1];
-      };
-#pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        ring_h[p] = ld16(sb + C::P2HI + b_offs(p));
-        if constexpr (X3) ring_l[p] = ld16(sb + C::P2LO + b_offs(p));
-      }
-#pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        const int rt = step % RT, c = step / RT;
-        const int tt = c >> 1, m2 = c & 1;
-        const u32x4 bh = ring_h[step % PF];
-        u32x4 bl;
-        if constexpr (X3) bl = ring_l[step % PF];
-        if (step + PF < NSTEP) {
-          ring_h[step % PF] = ld16(sb + C::P2HI + b_offs(step + PF));
-          if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P2LO + b_offs(step + PF));
-        }
-        const u32x4 nh = {gnh[tt][4 * m2], gnh[tt][4 * m2 + 1], gnh[tt][4 * m2 + 2], gnh[tt][4 * m2 + 3]};
-        if constexpr (X3) {
-          const u32x4 nl = {gnl[tt][4 * m2], gnl[tt][4 * m2 + 1], gnl[tt][4 * m2 + 2], gnl[tt][4 * m2 + 3]};
-          on[rt] = mfma_bf16(nl, bh, on[rt]);
-          on[rt] = mfma_bf16(nh, bl, on[rt]);
-        }
-        on[rt] = mfma_op<OPT>(nh, bh, on[rt]);
-        if constexpr (C::TWO_ACC) {
-          const u32x4 ph = {gph[tt][4 * m2], gph[tt][4 * m2 + 1], gph[tt][4 * m2 + 2], gph[tt][4 * m2 + 3]};
-          if constexpr (X3) {
-            const u32x4 pl = {gpl[tt][4 * m2], gpl[tt][4 * m2 + 1], gpl[tt][4 * m2 + 2], gpl[tt][4 * m2 + 3]};
-            op[rt] = mfma_bf16(pl, bh, op[rt]);
-            op[rt] = mfma_bf16(ph, bl, op[rt]);
-          }
-          op[rt] = mfma_op<OPT>(ph, bh, op[rt]);
-        }
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
-#pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (X3 ? 3 : 1) * (C::TWO_ACC ? 2 : 1), 1);
-        if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
       }
     }
   };
 
-  // ---------------- main loop: LDS double buffer for the panel, X in ONE register buffer that compute() refills with
-  // the next tile right after its last use; one drain + barrier per tile.
+  // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
+  auto gemm2 = [&](const char* sb, const GOps& g) {
+    constexpr int NSTEP = RT * 4;
+    constexpr int PF = 4;
+    u32x4 ring_h[PF];
+    u32x4 ring_l[X3 ? PF : 1];
+    // step -> ((tt, m2), rt): rank tiles innermost, so consecutive MFMAs cycle through the RT accumulators
+    auto b_offs = [&](int step) {
+      const int rt = step % RT, c = step / RT;
+      return rt * 4096 + b_row + b_off[c >> 1][c & 1];
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      ring_h[p] = ld16(sb + C::P2HI + b_offs(p));
+      if constexpr (X3) ring_l[p] = ld16(sb + C::P2LO + b_offs(p));
+    }
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int rt = step % RT, c = step / RT;
+      const int tt = c >> 1, m2 = c & 1;
+      const u32x4 bh = ring_h[step % PF];
+      u32x4 bl;
+      if constexpr (X3) bl = ring_l[step % PF];
+      if (step + PF < NSTEP) {
+        ring_h[step % PF] = ld16(sb + C::P2HI + b_offs(step + PF));
+        if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P2LO + b_offs(step + PF));
+      }
+      const u32x4 nh = {g.gnh[tt][4 * m2], g.gnh[tt][4 * m2 + 1], g.gnh[tt][4 * m2 + 2], g.gnh[tt][4 * m2 + 3]};
+      if constexpr (X3) {
+        const u32x4 nl = {g.gnl[tt][4 * m2], g.gnl[tt][4 * m2 + 1], g.gnl[tt][4 * m2 + 2], g.gnl[tt][4 * m2 + 3]};
+        on[rt] = mfma_bf16(nl, bh, on[rt]);
+        on[rt] = mfma_bf16(nh, bl, on[rt]);
+      }
+      on[rt] = mfma_op<OPT>(nh, bh, on[rt]);
+      if constexpr (C::TWO_ACC) {
+        const u32x4 ph = {g.gph[tt][4 * m2], g.gph[tt][4 * m2 + 1], g.gph[tt][4 * m2 + 2], g.gph[tt][4 * m2 + 3]};
+        if constexpr (X3) {
+          const u32x4 pl = {g.gpl[tt][4 * m2], g.gpl[tt][4 * m2 + 1], g.gpl[tt][4 * m2 + 2], g.gpl[tt][4 * m2 + 3]};
+          op[rt] = mfma_bf16(pl, bh, op[rt]);
+          op[rt] = mfma_bf16(ph, bl, op[rt]);
+        }
+        op[rt] = mfma_op<OPT>(ph, bh, op[rt]);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      __builtin_amdgcn_sched_group_barrier(0x008, (X3 ? 3 : 1) * (C::TWO_ACC ? 2 : 1), 1);
+      if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
+    }
+  };
+
+  auto drain = [&]() {   // the asm DMA of this tile's successor has landed; every wave is done with this tile's stage
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0)
+    __syncthreads();
+  };
   if (t0 < t1) {
+    // ---------------- main loop: LDS double buffer for the panel, X in ONE register buffer that is refilled with the
+    // next tile right after its last use; one drain + barrier per tile.
     u32x4 xc[NQ];
     const int nt = t1 - t0;
     stage_issue(t0, 0);
     load_x(t0, xc);
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): the asm DMA landed
-    __syncthreads();
+    drain();
     for (int i = 0; i < nt; ++i) {
       const int t = t0 + i, buf = i & 1;
       const bool more = i + 1 < nt;
-      if (more) stage_issue(t + 1, buf ^ 1);
-      compute(t, buf, xc, more ? t + 1 : -1);
-      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-      __syncthreads();
+      if (more) stage_issue(t + 1, (buf ^ 1) * C::STAGE_BYTES);
+      const char* sb = smem + buf * C::STAGE_BYTES;
+      f32x16 s[2];
+      GOps g;
+      gemm1(sb, s);
+      elementwise(t, s, xc, g);
+      // X's registers are dead from here on: fetch the next tile into them now (single X buffer; the loads have the
+      // whole GEMM2 + barrier + next GEMM1 to land).
+      if (more) load_x(t + 1, xc);
+      if constexpr (!C::LOSS) gemm2(sb, g);
+      drain();
     }
   }
 

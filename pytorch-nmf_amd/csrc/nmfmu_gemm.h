@@ -13,7 +13,7 @@
 //              backward pass wrt H without the 4 * R*T * B*L bytes write + read of Y)
 //
 // Both operands are bf16 planes (hi[, lo]) with k contiguous, zero padded to multiples of 128 in every dimension.
-// 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles) -- or 256x256, 8 waves (4x2, 64x128 each) --
+// 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles),
 // BK = 64, LDS double buffered by LDS-DMA.  The 128-byte LDS rows are XOR-swizzled on the DMA *source* side (linear LDS destination) and on the
 // ds_read side, which makes every ds_read_b128 conflict free (same analysis as the P2 image of nmfmu_layout.h).
 #pragma once
@@ -54,18 +54,17 @@ struct GemmArgs {
 // which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
 enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3 };
 
-// Workgroup tile shapes.  WM x WN waves, each MI x NI MFMA 32x32 blocks.
-//   small: 128 x 128, 256 threads, two workgroups per CU -- every shape, both precisions
-//   big:   256 x 256, 512 threads, one workgroup per CU   -- half the operand bytes per MFMA (64 KiB of LDS-DMA and
-//          192 KiB of fragment reads for 256 MFMAs instead of 64 + 128 KiB for 128): the small tile has the LDS-DMA path,
-//          the LDS reads and the matrix pipe all nominally saturated
+// Workgroup tile shape.  WM x WN waves, each MI x NI MFMA 32x32 blocks: 128 x 128, 256 threads, two workgroups per CU.
+// (A 256 x 256 / eight-wave instance of this template was built and parity-tested in round 2: half the operand bytes
+// per MFMA, 52 instead of 27 % MFMA-busy per CU, but at configs[3] it pads 1025 channels to 1280 and leaves 160 / 416
+// workgroups for 256 CUs -- 2 210 instead of 2 650 it/s without a stream-K scheduler; removed in round 3, see the git
+// history of round 2.)
 template <int WM_, int WN_, int MI_, int NI_>
 struct GemmShape {
   static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
   static constexpr int BM = WM * MI * 32, BN = WN * NI * 32, THREADS = 64 * WM * WN;
 };
 using GemmSmall = GemmShape<2, 2, 2, 2>;
-using GemmBig = GemmShape<4, 2, 2, 4>;
 // (256 x 128 and 128 x 256 with eight 64 x 64 waves were measured too: same time as two 128 x 128 workgroups per CU.)
 
 template <bool X3, class SH>
@@ -433,8 +432,7 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// big != 0: the 256 x 256 tile (bf16 single plane, beta == 1 ratio / loss, F32, FOLD); -2 when that variant is not built
 // f16 != 0: fp16 operand planes / window tables and fp16 ratio planes (single plane; the beta == 1 NMFD path)
-int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, int f16, const GemmArgs& a, hipStream_t s);
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s);
 
 }  // namespace nmfmu

@@ -16,27 +16,16 @@
 
 namespace nmfmu {
 
-int launch_gemm(int x3, int epi, int beta_kind, int ops, int big, int f16, const GemmArgs& a, hipStream_t s) {
+int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s) {
   if (f16) {
     // fp16 operands: the combinations of the beta == 1 NMFD iteration on implicit operands (nmfd_engine.py, precision 'f16')
-    if (x3 || big) return -2;
+    if (x3) return -2;
 #define GF16(E, B, O) \
   if (epi == E && (E == kEpiF32 || E == kEpiFold || beta_kind == B) && ops == O) \
     return launch_gemm_one<false, E, B, O, GemmSmall, kOpF16>(a, s);
     GF16(kEpiRatio, kKL, kOpsBHu) GF16(kEpiRatio, kKL, kOpsAHu) GF16(kEpiLoss, kKL, kOpsBHu)
     GF16(kEpiF32, kEuc, kOpsBHuT) GF16(kEpiFold, kEuc, kOpsPlanes)
 #undef GF16
-    return -2;
-  }
-  if (big) {
-    // 256 x 256 tiles: the combinations NMFD.fit uses at beta == 1 in the single-plane mode (nmfd_engine.py)
-    if (x3) return -2;
-#define GBIG(E, B, O) \
-  if (epi == E && (E == kEpiF32 || E == kEpiFold || beta_kind == B) && ops == O) return launch_gemm_one<false, E, B, O, GemmBig>(a, s);
-    GBIG(kEpiRatio, kKL, kOpsBHu) GBIG(kEpiRatio, kKL, kOpsAHu) GBIG(kEpiRatio, kKL, kOpsPlanes)
-    GBIG(kEpiLoss, kKL, kOpsBHu) GBIG(kEpiLoss, kKL, kOpsPlanes)
-    GBIG(kEpiF32, kEuc, kOpsPlanes) GBIG(kEpiF32, kEuc, kOpsBHuT) GBIG(kEpiFold, kEuc, kOpsPlanes)
-#undef GBIG
     return -2;
   }
   // operand combinations that occur (nmfd_engine.py): RATIO with planes | B = Hu | A = Hu; F32 with planes | B = HuT;
@@ -698,18 +687,6 @@ int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops) {
   }
 }
 
-int nmfmu_gemm_tile256_supported(int precision, float beta, int epilogue, int ops) {
-  if (precision != NMFMU_PREC_BF16) return 0;
-  const int kl = nmfmu_beta_kind(beta) == NMFMU_BETA_KL;
-  switch (epilogue) {
-    case NMFMU_EPI_RATIO: return kl && (ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HU || ops == NMFMU_OPS_A_HU);
-    case NMFMU_EPI_LOSS: return kl && (ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HU);
-    case NMFMU_EPI_F32: return ops == NMFMU_OPS_PLANES || ops == NMFMU_OPS_B_HUT;
-    case NMFMU_EPI_FOLD: return ops == NMFMU_OPS_PLANES;
-    default: return 0;
-  }
-}
-
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
   if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % 128 || d->k_pad % 128)
@@ -754,16 +731,10 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else {
     return NMFMU_ERR_ARG;
   }
-  int big = 0;
-  if (d->tile_rows == 256) {
-    if (x3 || d->m_pad % 256 || d->n_pad % 256) return NMFMU_ERR_ARG;
-    big = 1;
-  } else if (d->tile_rows != 0 && d->tile_rows != 128) {
-    return NMFMU_ERR_ARG;
-  }
+  if (d->tile_rows != 0 && d->tile_rows != 128) return NMFMU_ERR_UNSUPPORTED;   // (the 256 x 256 tile of ABI 3 is gone)
   a.ldn = d->n_ld ? d->n_ld : d->n_pad;
   if (a.ldn < d->n_pad || (a.ldn != d->n_pad && epilogue == NMFMU_EPI_FOLD)) return NMFMU_ERR_ARG;
-  const int rc = launch_gemm(x3, epilogue, kind, d->ops, big, f16, a, S(stream));
+  const int rc = launch_gemm(x3, epilogue, kind, d->ops, f16, a, S(stream));
   return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 

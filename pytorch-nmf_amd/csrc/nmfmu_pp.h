@@ -40,16 +40,17 @@
 // What was tried on this loop and measured not faster (profiles/r02_clock.md; the code is in the git history of
 // round 2): X through an LDS ring, an 8-deep operand ring, s_setprio for the matrix segments or for the younger
 // half, accumulators in AGPRs, ONE panel image with ds_read_b64_tr_b16 gathers for G2 (half the panel stream, +7 %
-// clock, +15 % cycles), column sums handed over as partials instead of finalize launches.
+// clock, +15 % cycles), column sums handed over as partials instead of finalize launches; round 3 (profiles/r03_clock.md):
+// touching the fused apply's fp32 master rows during the last tiles (LDS-DMA prefetch into L2) and issuing all of a
+// lane's master loads before the numerators are staged -- the epilogue got longer, not shorter (29 -> 35 us): it is
+// bound by instruction issue at the loop's low clock, which the branch-free "plain" form below addresses (29 -> 21 us).
+// Two timing-only ablations (NMFMU_PP_ABLATE_*, diagnostic builds) show what the loop is limited by: with half the
+// operand reads skipped OR performed into a sink register -- the same MFMAs seeing stale operands either way -- the
+// cycles per tile stay at 2 430 and the core clock rises from 1.25 to 1.75 GHz: the energy goes into the matrix pipe's
+// operand toggling, not into the LDS reads, so a tiling that halves the reads per MFMA (64 rows per wave) buys nothing.
 #pragma once
 #include "nmfmu_fused.h"
 
-#ifndef NMFMU_PP_PREFETCH
-#define NMFMU_PP_PREFETCH 0   // fused apply: pull the owner's fp32 master rows into L2 during the last tiles of the loop
-#endif
-#ifndef NMFMU_PP_EPI_BATCH
-#define NMFMU_PP_EPI_BATCH 0  // fused apply: all master loads of a lane in flight before the numerators are staged
-#endif
 #ifndef NMFMU_PP_EPI_PLAIN
 #define NMFMU_PP_EPI_PLAIN 1  // fused apply: branch-free form for the unregularised full-tile case
 #endif
@@ -70,8 +71,7 @@ struct PPCfg {
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG;
   static constexpr int LDS_MAIN = 2 * NSLOT * IMG;
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
-  static constexpr int LDS_PF = NMFMU_PP_PREFETCH && !LOSS ? WAVES * 256 : 0;   // landing rows of the master prefetch
-  static constexpr int LDS_BYTES = (LDS_MAIN + LDS_PF) > LDS_EPI ? (LDS_MAIN + LDS_PF) : LDS_EPI;
+  static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static constexpr int NPIECE = IMG / 1024;                 // 1-KiB DMA pieces per image tile
   static constexpr int ND = (NPIECE + 3) / 4;               // pieces per issuing wave (waves 0-3) and image
   static constexpr int NSTEP1 = 2 * KS, NSTEP2 = LOSS ? 0 : 4 * RT;
@@ -254,21 +254,8 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     uint32_t gn[2][8];
     f32x16 S[2];
     u32x4 ring[PF];
-#if NMFMU_PP_PREFETCH
-    // (fused apply only) this wave's slice of the fp32 master: base, number of 128-byte lines, last valid dword offset
-    const char* pf_base = reinterpret_cast<const char*>(a.f) + (size_t)(mb * C::BM + wave * 32) * (size_t)a.rank * 4;
-    int pf_lines = 0;
-    unsigned pf_last = 0;
-    if constexpr (!C::LOSS) {
-      if (a.fuse_apply) {
-        const int rows_here = min(32, a.M - (mb * C::BM + wave * 32));
-        if (rows_here > 0) {
-          const unsigned bytes = (unsigned)rows_here * (unsigned)a.rank * 4u;
-          pf_lines = (int)((bytes + 127u) / 128u);
-          pf_last = bytes - 4u;
-        }
-      }
-    }
+#ifdef NMFMU_PP_ABLATE_STALE_OPERANDS
+    u32x4 abl_sink = {0u, 0u, 0u, 0u};
 #endif
 
     // operand stream of one M segment: entries 0 .. NSTEP1-1 are G1's panel rows (P1 slot of tile t), entries
@@ -306,6 +293,24 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read of stream entry e
       constexpr int e0 = decltype(ec)::value;
       constexpr bool g1 = decltype(g1c)::value;
+#ifdef NMFMU_PP_ABLATE_HALF_READS
+      // timing-only ablation (wrong results): every other operand read is skipped, the MFMA re-uses a stale ring entry --
+      // what a tiling with twice the rows per wave (one read feeding two MFMAs) could gain at best (profiles/r03_clock.md)
+      if constexpr ((e0 & 1) != 0) return;
+#endif
+#ifdef NMFMU_PP_ABLATE_STALE_OPERANDS
+      // control for the ablation above: every read is performed, but every other one lands in a sink register, so the
+      // same MFMAs see the same stale operands -- separates the cost of the LDS reads from that of operand toggling
+      if constexpr ((e0 & 1) != 0) {
+        if constexpr (g1 && e0 < NSTEP1) {
+          asm volatile("ds_read_b128 %0, %1" : "+v"(abl_sink) : "v"(sa[e0 & 1] ^ ((e0 >> 1) * 32)));
+        } else {
+          constexpr int e = e0 - (g1 ? NSTEP1 : 0);
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(abl_sink) : "v"(sb[(e / RT) >> 1][(e / RT) & 1]), "n"((e % RT) * 4096));
+        }
+        return;
+      }
+#endif
       if constexpr (g1 && e0 < NSTEP1) {
         rd(dst, sa[e0 & 1] ^ ((e0 >> 1) * 32), std::integral_constant<int, 0>{});
       } else {
@@ -417,24 +422,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       p1_issue_off = next_off(p1_issue_off);
       p2_issue_off = next_off(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
-#if NMFMU_PP_PREFETCH
-      if constexpr (!tail && !C::LOSS) {
-        // The fused-apply epilogue reads this wave's 32 master rows (one contiguous 32 * rank * 4-byte block) and every
-        // workgroup reaches it at the same time: touch the block's 128-byte lines now, one line per lane and
-        // instruction, so that the reads come out of L2 / MALL then.  Issued BEFORE the X loads of this segment: the
-        // counted vmcnt(4) of the next matrix segment then retires them like the panel DMA.
-        if (pf_lines > 0 && (t == nt - 12 || t == nt - 8)) {
-          const int line = (t == nt - 12 ? 0 : 64) + lane;
-          // (LDS-DMA into a scratch row behind the rings: no destination register that could be re-used while the
-          // load is in flight; lanes past the end re-touch the last line)
-          const unsigned off = min((unsigned)min(line, pf_lines - 1) * 128u, pf_last);
-          asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1"
-                       :
-                       : "v"(off), "s"(pf_base), "s"(lds_base + (unsigned)C::LDS_MAIN + (unsigned)wave * 256u)
-                       : "memory", "m0");
-        }
-      }
-#endif
       if constexpr (!tail) load_x(t + 2, x);   // ... before its register buffer is refilled
     };
 
@@ -493,6 +480,9 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read of the accumulators (asm MFMAs are not padded)
     if (!half) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches: nothing may land in LDS after this
+#ifdef NMFMU_PP_ABLATE_STALE_OPERANDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(abl_sink));
+#endif
   }
   __syncthreads();               // LDS is reused by the epilogue
 
@@ -533,25 +523,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       for (int k = 0; k < 8; ++k) { den8[k] = a.kl_den[slot_e * 8 + k]; csum8[k] = 0.f; }
       const bool vec = (a.rank & 3) == 0;
       bool clamped = false;   // fp16 images saturate at 65504 (MODE.FP16_OVFL): reported through a.status
-#if NMFMU_PP_EPI_BATCH
-      // every master load of this lane is issued before the numerators go through LDS: NCH x 32 bytes in flight per lane
-      float fvall[NCH][8];
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int row = mrow0 + i * (64 / SP) + rl0, r0 = slot_e * 8;
-        const float* frow = a.f + (size_t)row * a.rank + r0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bool in = row < a.M && r0 + 4 * h < a.rank;
-          if (in && vec) {
-            *reinterpret_cast<float4*>(&fvall[i][4 * h]) = *reinterpret_cast<const float4*>(frow + 4 * h);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fvall[i][4 * h + k] = (in && r0 + 4 * h + k < a.rank) ? frow[4 * h + k] : 0.f;
-          }
-        }
-      }
-#endif
       // numerators -> the wave's staging tile [32][R_PAD]
       static_for<RT>([&](auto rtc) {
         constexpr int rt = decltype(rtc)::value;
@@ -595,11 +566,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.o1_hi) + p1_offset(row, r0, R_PAD)) = hi;
         }
       } else
-#if NMFMU_PP_EPI_BATCH
-#pragma unroll
-#else
 #pragma unroll 2
-#endif
       for (int i = 0; i < NCH; ++i) {
         const int rl = i * (64 / SP) + rl0, row = mrow0 + rl, r0 = slot_e * 8;
         float* trow = tile + rl * LDT + r0;
@@ -607,10 +574,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         float fv[8], nm[8];
         *reinterpret_cast<float4*>(nm) = *reinterpret_cast<const float4*>(trow);
         *reinterpret_cast<float4*>(nm + 4) = *reinterpret_cast<const float4*>(trow + 4);
-#if NMFMU_PP_EPI_BATCH
-#pragma unroll
-        for (int k = 0; k < 8; ++k) fv[k] = fvall[i][k];
-#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool in = row < a.M && r0 + 4 * h < a.rank;
@@ -621,7 +584,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
             for (int k = 0; k < 4; ++k) fv[4 * h + k] = (in && r0 + 4 * h + k < a.rank) ? frow[4 * h + k] : 0.f;
           }
         }
-#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float neg = fmaxf(nm[k], 0.f) + kEps;

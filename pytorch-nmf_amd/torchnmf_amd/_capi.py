@@ -135,7 +135,6 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_conv_fold_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    'nmfmu_gemm_tile256_supported': (C.c_int, [C.c_int, C.c_float, C.c_int, C.c_int]),
     'nmfmu_gemm_f16_supported': (C.c_int, [C.c_float, C.c_int, C.c_int]),
     'nmfmu_conv_tables_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_ragged_supported': (C.c_int, [C.c_int, C.c_int]),

@@ -85,8 +85,7 @@ class ConvMU:
         f16_ok = (own_loop and nd == 1 and float(beta) == 1.0 and T % 8 == 0 and L % 8 == 0 and T >= 128 and
                   os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1' and
                   os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0' and
-                  os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0' and
-                  os.environ.get('TORCHNMF_AMD_NMFD_TILE', '128') == '128')
+                  os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
         if precision in (None, 'auto'):
             precision = 'bf16x3'
             if (f16_ok and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0' and min(Cc, B * L) >= self.F16_MIN_DIM
@@ -109,15 +108,7 @@ class ConvMU:
         self.W, self.H = W, H
         self.B, self.C, self.L, self.R, self.T, self.Lh = B, Cc, L, R, T, Lh
         dev = V.device
-        # 256 x 256 GEMM tiles (nmfmu_gemm_desc.tile_rows; single bf16 plane, beta == 1) halve the operand traffic per MFMA:
-        # 52 % instead of 27 % MFMA-busy per CU.  Opt-in (TORCHNMF_AMD_NMFD_TILE=256), because no measured shape gains yet:
-        # at configs[3] the 256-row padding (1025 channels -> 1280) and the 160-workgroup grids eat it (2 210 vs 2 650
-        # it/s), the rank > 256 NMF path is bound by its ratio epilogues, not by the GEMM loop.  It is the building block
-        # for stream-K scheduling.
-        want = os.environ.get('TORCHNMF_AMD_NMFD_TILE', '128')
-        self.tile = 256 if (want == '256' and own_loop and nd == 1 and self.kl and
-                            self.precision == _capi.PREC_BF16) else 128
-        self._tile_forced = want == '256'
+        self.tile = 128                                  # GEMM workgroup tile (rows = columns)
         pad = (lambda n: (n + self.tile - 1) // self.tile * self.tile)
         self.c_pad, self.bl_pad, self.rp_pad = pad(Cc), pad(B * L), pad(R * T)
         cp, blp, rpp = self.c_pad, self.bl_pad, self.rp_pad
@@ -149,7 +140,7 @@ class ConvMU:
         # first 128 k only and nmfmu_conv_ragged_rows sums the rest directly -- a whole tile row (64 of 576 workgroups,
         # i.e. a second scheduling round: 30 us per reconstruction) for one channel otherwise.
         self.c_main = (Cc // 128) * 128
-        self.ragged = (own_loop and nd == 1 and self.tile == 128 and self.c_main >= 128 and 0 < Cc - self.c_main <= 8 and
+        self.ragged = (own_loop and nd == 1 and self.c_main >= 128 and 0 < Cc - self.c_main <= 8 and
                        bool(self.lib.nmfmu_conv_ragged_supported(R, T)) and
                        os.environ.get('TORCHNMF_AMD_NMFD_RAGGED', '1') != '0')
         rz = self.ragged                        # the GEMM then leaves the padding rows / columns of the ratio planes alone
@@ -206,9 +197,6 @@ class ConvMU:
             ops = (_capi.OPS_A_HU if a is self.hu else _capi.OPS_B_HU if b is self.hu else
                    _capi.OPS_B_HUT if b is self.hut else _capi.OPS_PLANES)
         tile = 128
-        if (self.tile == 256 and (self._tile_forced or (a.rows_pad // 256) * (b.rows_pad // 256) >= 128) and
-                self.lib.nmfmu_gemm_tile256_supported(self.precision, self.beta, epi, ops)):
-            tile = 256
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), m_pad, n_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,

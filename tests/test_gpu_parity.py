@@ -685,37 +685,6 @@ def test_nmfd_fold_from_tile_diagonal_sums(dev, shape, beta, prec, monkeypatch):
         assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
 
 
-@pytest.mark.parametrize('shape', [(1, 300, 520, 3, 136), (2, 257, 335, 2, 130), (1, 70, 600, 2, 400), (1, 513, 776, 4, 8),
-                                   (3, 40, 96, 2, 16)])
-def test_nmfd_256x256_gemm_tiles(dev, shape, monkeypatch):
-    """The 256 x 256 workgroup tile of the NMFD GEMMs (single bf16 plane, beta == 1) computes the same bf16 products in
-    the same k order as the 128 x 128 one: every epilogue (ratio planes for both half-steps, fp32 numerator, per-tile
-    diagonal sums, loss) and both implicit Toeplitz operands must agree to fp32 rounding, on shapes that leave ragged
-    256-row padding on every side, with and without the implicit path (T, L multiples of 8) and the fold path (T >= 128)."""
-    from oracle import mu_oracle as O
-    from torchnmf_amd.nmfd_engine import ConvMU
-    B, Cc, L, R, T = shape
-    g = torch.Generator().manual_seed(sum(shape))
-    V = torch.rand(B, Cc, L, generator=g) + 1e-3
-    W0 = torch.randn(Cc, R, T, generator=g).abs()
-    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
-    res = {}
-    for mode in ('128', '256'):
-        monkeypatch.setenv('TORCHNMF_AMD_NMFD_TILE', mode)
-        W, H = W0.clone().to(dev), H0.clone().to(dev)
-        eng = ConvMU(V.to(dev), W, H, 1, precision='bf16')
-        assert eng.tile == int(mode) and eng.c_pad % int(mode) == 0
-        l0 = eng.divergence()
-        for _ in range(2):
-            eng.w_step()
-            eng.h_step()
-        res[mode] = (W.cpu(), H.cpu(), l0, eng.divergence())
-    assert rel_err(res['128'][0], res['256'][0]) < 2e-6 and rel_err(res['128'][1], res['256'][1]) < 2e-6
-    assert res['128'][2] == pytest.approx(res['256'][2], rel=1e-5) and res['128'][3] == pytest.approx(res['256'][3], rel=1e-5)
-    Wr, Hr, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 2, kind='nmfd')
-    assert rel_err(res['256'][0], Wr) < 5e-3 and rel_err(res['256'][1], Hr) < 5e-3
-
-
 @pytest.mark.parametrize('shape', [(1, 129, 304, 4, 8), (2, 257, 200, 3, 24), (1, 136, 600, 2, 400), (1, 1025, 520, 3, 136),
                                    (3, 130, 96, 9, 5)])
 @pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (1, 'bf16')])

@@ -164,8 +164,6 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(1.0, E.EPI_RATIO, O.OPS_PLANES) == 0
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_RATIO, O.OPS_B_HU) == 0
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
-    assert lib.nmfmu_gemm_tile256_supported(_capi.PREC_BF16, 1.0, E.EPI_LOSS, O.OPS_B_HU) == 1
-    assert lib.nmfmu_gemm_tile256_supported(_capi.PREC_BF16X3, 1.0, E.EPI_LOSS, O.OPS_B_HU) == 0
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
     assert [f[0] for f in d._fields_][-4:] == ['tile_rows', 'n_ld', 'k_len', 'k_split']
