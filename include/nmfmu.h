@@ -404,6 +404,25 @@ size_t nmfmu_plca3_part_bytes(int rank);
 int nmfmu_plca3(int mode, float* f, int outer, int rank, int inner, const float* num, int64_t num_pitch, const float* vec,
                 float alpha, int update, float* part, float* colsum_out, float* zgrad_out, void* stream);
 
+/* ---- the collective of the column-sharded path ----------------------------------------------
+ * One process (or host thread) per GPU, or one process driving several: the H half-step sums ONE packed fp32 buffer
+ * [numerators (owner.rows_pad x r_pad) | denominators] over the ranks between nmfmu_mu_partial + nmfmu_slab_reduce and
+ * nmfmu_mu_apply(..., nslab = 1); relu / eps / regularisers are applied after the sum, as on the unsharded matrix
+ * (nmf.py:78-92).  RCCL is resolved at run time (dlopen): NMFMU_ERR_UNSUPPORTED when it is not installed.  RCCL errors
+ * come back as 10000 + ncclResult_t.  (The Python host side of this repository uses torch.distributed, backend "nccl" =
+ * RCCL, for the same exchange.) */
+typedef struct nmfmu_comm nmfmu_comm;
+int nmfmu_comm_available(void);                                   /* 1 when librccl could be loaded                      */
+int nmfmu_comm_unique_id(void* id128);                            /* rank 0: 128 bytes to hand to every rank out of band */
+int nmfmu_comm_init_rank(nmfmu_comm** comm, int nranks, const void* id128, int rank); /* current device = this rank's GPU */
+int nmfmu_comm_init_all(nmfmu_comm** comms, int ndev, const int* devices);  /* one process, ndev GPUs (devices may be NULL) */
+int nmfmu_comm_nranks(const nmfmu_comm* comm);
+int nmfmu_comm_allreduce_sum_f32(nmfmu_comm* comm, float* buf, size_t count, void* stream);  /* in place, asynchronous */
+/* one host thread driving ndev devices: the ndev all-reduces of one exchange inside ncclGroupStart / End */
+int nmfmu_comm_allreduce_sum_f32_multi(nmfmu_comm* const* comms, float* const* bufs, size_t count, void* const* streams,
+                                       int ndev);
+int nmfmu_comm_destroy(nmfmu_comm* comm);
+
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */
 int nmfmu_timer_create(int n_events, void** timer);

@@ -154,6 +154,15 @@ SIGNATURES = {
     'nmfmu_fold_parts_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_fold_parts_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_comm_available': (C.c_int, []),
+    'nmfmu_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'nmfmu_comm_init_rank': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int]),
+    'nmfmu_comm_init_all': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
+    'nmfmu_comm_nranks': (C.c_int, [C.c_void_p]),
+    'nmfmu_comm_allreduce_sum_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'nmfmu_comm_allreduce_sum_f32_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
+                                                     C.POINTER(C.c_void_p), C.c_int]),
+    'nmfmu_comm_destroy': (C.c_int, [C.c_void_p]),
     'nmfmu_timer_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'nmfmu_timer_record': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_timer_elapsed_ms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

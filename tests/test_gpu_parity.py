@@ -961,6 +961,37 @@ def test_sharded_path_world1_rccl(dev):
         dist.destroy_process_group()
 
 
+def test_comm_entries_world1_rccl(dev):
+    """The C entries of the sharded path's collective (include/nmfmu.h: nmfmu_comm_*, RCCL resolved by dlopen): a
+    communicator of one rank by unique id, the in-place fp32 sum of a packed [numerator | denominator] buffer on a side
+    stream, the one-process-many-devices form with one device, teardown."""
+    import ctypes as C
+    from torchnmf_amd import _capi
+    lib = _capi.load()
+    assert lib.nmfmu_comm_available() == 1
+    uid = (C.c_char * 128)()
+    _capi.check(lib.nmfmu_comm_unique_id(uid), 'nmfmu_comm_unique_id')
+    comm = C.c_void_p()
+    _capi.check(lib.nmfmu_comm_init_rank(C.byref(comm), 1, uid, 0), 'nmfmu_comm_init_rank')
+    assert lib.nmfmu_comm_nranks(comm) == 1
+    buf = torch.arange(4096 * 128 + 128, dtype=torch.float32, device=dev)
+    want = buf.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    _capi.check(lib.nmfmu_comm_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), side.cuda_stream), 'allreduce')
+    side.synchronize()
+    assert torch.equal(buf, want)
+    _capi.check(lib.nmfmu_comm_destroy(comm), 'nmfmu_comm_destroy')
+    comms = (C.c_void_p * 1)()
+    _capi.check(lib.nmfmu_comm_init_all(comms, 1, None), 'nmfmu_comm_init_all')
+    bufs, streams = (C.c_void_p * 1)(buf.data_ptr()), (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream)
+    _capi.check(lib.nmfmu_comm_allreduce_sum_f32_multi(comms, bufs, buf.numel(), streams, 1), 'allreduce_multi')
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    _capi.check(lib.nmfmu_comm_destroy(comms[0]), 'nmfmu_comm_destroy')
+    assert lib.nmfmu_comm_allreduce_sum_f32(None, buf.data_ptr(), 4, None) == _capi.ERR_ARG
+
+
 # ----------------------------------------------------------------------------------------------------------
 # wide ranks (padded rank 256, the configs[4] kernel family) and unsupported combinations
 # ----------------------------------------------------------------------------------------------------------
