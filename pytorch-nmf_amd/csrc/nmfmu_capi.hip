@@ -12,6 +12,10 @@
 #include "nmfmu_fused.h"
 #include "nmfmu_pp.h"
 
+#ifndef NMFMU_FUSE_APPLY_TWO_ACC
+#define NMFMU_FUSE_APPLY_TWO_ACC 1   // (A/B switch of round 3; 0 = beta != 1 always goes through slabs + the apply kernel)
+#endif
+
 using namespace nmfmu;
 
 namespace {
@@ -41,7 +45,7 @@ static int kernel_beta_kind(float beta) {
 }
 
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
-                   const float* fuse_kl_den = nullptr) {
+                   const float* fuse_kl_den = nullptr, bool fuse_apply = false) {
   if (!st || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
   if (!st->xp && mode == kModeMU) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
@@ -72,7 +76,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   a.status = st->status;
   a.cs_owner = st->owner.colsum;   // fp16 operands, beta < 1: typical S -> scale of Gn / Gp (nmfmu_fused.h)
   a.cs_panel = st->panel.colsum;
-  if (fuse_kl_den) {  // beta == 1, nsplit == 1: apply in the epilogue
+  if (fuse_apply) {  // nsplit == 1: apply in the epilogue
     a.fuse_apply = 1;
     a.rank = st->rank;
     a.f = st->owner.f;
@@ -228,10 +232,13 @@ int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* st
   if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   if (kl && !kl_den) return NMFMU_ERR_ARG;
-  const bool fuse = kl && st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum && st->owner.colsum_part;
+  // apply in the fused kernel's epilogue when the workgroup owns whole rows: beta == 1 (closed-form denominators) on
+  // both kernels, beta != 1 (two accumulator sets) on the four-wave kernel in the single-plane precisions up to rank pad 128
+  const bool fuse = st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum && st->owner.colsum_part &&
+                    (kl || (NMFMU_FUSE_APPLY_TWO_ACC && st->precision != NMFMU_PREC_BF16X3 && st->r_pad <= 128));
   int e = 0;
   if (phase != 2) {  // the fused kernel (with nmf.py:78-92 in its epilogue when the workgroup owns whole rows)
-    e = fuse ? fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream), kl_den)
+    e = fuse ? fused_dispatch(st, kModeMU, nullptr, st->owner.rows, st->panel.rows, S(stream), kl_den, true)
              : nmfmu_mu_partial(st, stream);
     if (e) return e;
   }

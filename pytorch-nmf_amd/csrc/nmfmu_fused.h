@@ -625,18 +625,22 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   } else {
     // accumulator register e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column 32*rt + j
     bool fused_done = false;
-    if constexpr (BETA == kKL) {
+    if constexpr (BETA == kKL || (C::TWO_ACC && !X3 && R_PAD <= 128)) {   // (rank pad 256 x two sets: no registers left)
       if (a.fuse_apply) {
         // ---- nmf.py:78-92 in the epilogue (the workgroup owns complete rows: nsplit == 1).  The new factor values
         // replace the accumulators, go to the fp32 master, to the transposed image (8-byte pieces straight from
-        // registers) and, through a wave-private LDS tile, to the row-major image (16-byte pieces).
+        // registers) and, through a wave-private LDS tile, to the row-major image (16-byte pieces).  beta == 1: the
+        // denominators are the panel's column sums (closed form); beta != 1: relu(den accumulator) + eps -- no slab round
+        // trip, no apply launch (64 MiB of slab stores + a 160 MiB apply kernel less per W half-step at configs[1]).
         fused_done = true;
         constexpr int LDT = R_PAD;                     // wave tile [32][R_PAD] fp32 = 128*R_PAD bytes per wave
         float* tile = reinterpret_cast<float*>(smem) + wave * (32 * LDT);
         float den[RT], csum[RT];
+        float unsc_f = 1.f;                            // fp16 scale of the elementwise terms (exact power of two)
+        if constexpr (C::SCALE) unsc_f = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 - ki) << 23));
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          den[rt] = a.kl_den[rt * 32 + j];
+          den[rt] = BETA == kKL ? a.kl_den[rt * 32 + j] : 0.f;
           csum[rt] = 0.f;
         }
         const int mrow0 = mb * BM + wave * 32;  // first owner row of this wave
