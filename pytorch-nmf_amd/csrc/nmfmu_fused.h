@@ -667,8 +667,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
               const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl;
               float fv = fold[rc][e];
               if (row < a.M && r < a.rank) {
-                const float neg = fmaxf(on[rt][e], 0.f) + kEps;
+                const float neg = fmaxf(C::SCALE ? on[rt][e] * unsc_f : on[rt][e], 0.f) + kEps;
                 float pos = den[rt];
+                if constexpr (C::TWO_ACC) pos = fmaxf(C::SCALE ? op[rt][e] * unsc_f : op[rt][e], 0.f) + kEps;
                 if (a.l1 > 0.f) pos += a.l1;
                 if (a.l2 > 0.f) pos += a.l2 * fv;
                 float mult = neg / pos;
