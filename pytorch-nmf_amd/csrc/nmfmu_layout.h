@@ -40,7 +40,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NMFMU_HD __host__ __device__ __forceinline__
 #else
 #define NMFMU_HD static inline

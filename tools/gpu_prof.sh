@@ -4,7 +4,7 @@ TAG=${1:-prof}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 5 --cpu-iters 0 --repeats 1 --no-parity-mode ${BENCH_ARGS}"
+BENCH="python $PWD/bench.py --steps 20 --warmup 5 --cpu-iters 0 --repeats 1 --max-repeats 1 --preroll-s 0.1 --no-parity-mode --no-sweep ${BENCH_ARGS}"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 echo "trace rc=$?"
