@@ -253,9 +253,14 @@ typedef struct nmfmu_gemm_desc {
   /* Contraction length actually run (0 = k_pad; a multiple of 64 covering the logical extent): the zero tail of
    * 128-padded planes need not be multiplied. */
   int32_t k_len;
-  /* NMFMU_EPI_F32 only: k_split (> 1) workgroups share the contraction of every tile; partial z goes to
-   * out + z * m_pad * n_ld (the consumer adds them).  For long-k GEMMs with too few tiles to fill the chip. */
+  /* NMFMU_EPI_F32: k_split (> 1) workgroups share the contraction of every tile; partial z goes to
+   * out + z * m_pad * n_ld (the consumer adds them).  For long-k GEMMs with too few tiles to fill the chip.
+   * NMFMU_EPI_FOLD: with tail_rows > 0 the LAST tail_rows tile rows are contraction-split k_split ways (the tail-round
+   * split: when the tile count is N full rounds of the chip plus a few tiles, those few cost a fraction of a round
+   * instead of a whole one); partial z of their diagonal sums goes to out + z * nmfmu_fold_part_bytes() / 4 and
+   * nmfmu_conv_fold_parts_apply_h_tail adds them in a fixed order. */
   int32_t k_split;
+  int32_t tail_rows;   /* (ABI 4, appended) */
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
@@ -342,6 +347,12 @@ int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, in
                                        const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
                                        int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma,
                                        void* stream);
+/* ... and for an EPI_FOLD GEMM that ran with the tail-round split (nmfmu_gemm_desc.tail_rows / k_split; m_pad = the GEMM's):
+ * the superset of the two entries above (kl_wcol / hsum_part may be NULL). */
+int nmfmu_conv_fold_parts_apply_h_tail(float* h, int batch, int rank, int lh, int taps, const float* p_num,
+                                       const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
+                                       int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma, int m_pad,
+                                       int tail_rows, int k_split, void* stream);
 size_t nmfmu_fold_part_bytes(int m_pad, int n_pad);
 int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps);
 int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,

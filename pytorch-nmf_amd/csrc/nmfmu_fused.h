@@ -34,7 +34,10 @@
 //
 // Tried and measured slower (round 3, profiles/r03_clock.md): a cross-tile software pipeline for the two-accumulator
 // instances (elementwise of tile t interleaved with GEMM2 of tile t-1 through sched_group_barrier, three LDS stages):
-// hipcc's placement degraded the counted LDS waits to lgkmcnt(0) -- 2 120 instead of 2 330 it/s at beta = 2, rank 128.
+// hipcc's placement degraded the counted LDS waits to lgkmcnt(0) -- 2 120 instead of 2 330 it/s at beta = 2, rank 128;
+// and the same interleave inside ONE tile with the order fixed in the source and fenced by sched_barrier(0) (elementwise
+// of S^T tile 0 under GEMM1 of tile 1, of tile 1 under the first half of GEMM2): 1 640 instead of 1 790 it/s at
+// beta = 0.5, 191 instead of 199 at the configs[4] shard -- the fences cost more than the overlap returns.
 //
 // Workgroup = 4 waves (one per SIMD), wave w owns rows 32w..32w+31 of the
 // block.  The panel tile (64 rows of B, both images) is double-buffered in
@@ -50,9 +53,6 @@
 
 #ifndef NMFMU_FUSED_G1_ASM
 #define NMFMU_FUSED_G1_ASM 1
-#endif
-#ifndef NMFMU_FUSED_IL
-#define NMFMU_FUSED_IL 1
 #endif
 
 namespace nmfmu {
@@ -143,9 +143,6 @@ struct FusedCfg {
   static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128) ? 1 : 2;
   // GEMM1 as asm with VGPR constraints (see gemm1()): the single-plane instances that run one wave per SIMD
   static constexpr bool G1_ASM = NMFMU_FUSED_G1_ASM && !X3 && MINW == 1;
-  // the elementwise stage interleaved with the MFMAs inside a tile (tile_interleaved): the single-plane MU instances that
-  // run one wave per SIMD
-  static constexpr bool IL = NMFMU_FUSED_IL && G1_ASM && MODE == kModeMU;
   static constexpr int NSTAGE = 2;
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
 };
@@ -591,125 +588,6 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     }
   };
 
-  // ---------------- one tile with the elementwise stage hidden under the MFMAs (C::IL: the single-plane instances that
-  // run ONE wave per SIMD, where nothing else overlaps GEMM1 -> elementwise -> GEMM2).  The order is fixed in the source
-  // and fenced with sched_barrier(0) -- no reliance on the scheduler's heuristics (the sched_group_barrier route to this
-  // degraded the LDS waits):
-  //   G1 chain of S^T tile 0 | G1 chain of tile 1  +  elementwise of tile 0 | first half of G2 (tile-0 columns)  +
-  //   elementwise of tile 1 | second half of G2 (tile-1 columns)  +  the X loads of the next k-tile
-  auto tile_interleaved = [&](const char* sb, int t, u32x4(&x)[NQ], int t_next) {
-    constexpr int PF = 4;
-    f32x16 s[2];
-    GOps g;
-    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-    auto g1_mfma = [&](f32x16& acc, const u32x4& ah, int kk) {
-      if (kk == 0) {
-        if constexpr (BETA == kEuc) {
-          if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(ah), "v"(qh[0]));
-          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(ah), "v"(qh[0]));
-        } else {
-          if constexpr (OPT == kOpF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(ah), "v"(qh[0]), "v"(epsv));
-          else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(ah), "v"(qh[0]), "v"(epsv));
-        }
-      } else {
-        if constexpr (OPT == kOpF16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah), "v"(qh[kk]));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah), "v"(qh[kk]));
-      }
-    };
-    // one element pair, pinned where it is written (an empty asm on its results: pure code would otherwise be free to
-    // sink towards its use)
-    auto pin_pair = [&](int tt, int d) {
-      elem_pair(t, s[tt], x, tt, d, g);
-      asm volatile("" : "+v"(g.gnh[tt][d]));
-      if constexpr (C::TWO_ACC) asm volatile("" : "+v"(g.gph[tt][d]));
-    };
-    // ---- GEMM1: operand stream e = tt * KS + kk through a PF-deep ring
-    u32x4 ring[PF];
-    auto rd1 = [&](int e) {
-      const int tt = e / KS, kk = e % KS;
-      ring[e % PF] = ld16(sb + C::P1HI + a_row[tt] + ((kk * 32 + hl * 16) ^ a_sw[tt]));
-    };
-    constexpr int N1 = 2 * KS;
-#pragma unroll
-    for (int p = 0; p < PF && p < N1; ++p) rd1(p);
-    fence();
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {          // chain of S^T tile 0
-      g1_mfma(s[0], ring[kk % PF], kk);
-      if (kk + PF < N1) rd1(kk + PF);
-      fence();
-    }
-    // chain of tile 1; from its third MFMA on (S tile 0 has left the matrix pipe by then: explicit wait states, the asm
-    // MFMAs are not padded) every step carries its share of tile 0's eight element pairs
-    constexpr int E0 = KS > 2 ? 2 : KS;        // first step that carries elementwise work
-    constexpr int ESTEPS = KS - E0;            // (0 at padded rank 32: the pairs follow the chain)
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      g1_mfma(s[1], ring[(KS + kk) % PF], kk);
-      if (KS + kk + PF < N1) rd1(KS + kk + PF);
-      fence();
-      if constexpr (ESTEPS > 0) {
-        if (kk == E0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]));
-        if (kk >= E0) {
-#pragma unroll
-          for (int d = (kk - E0) * 8 / ESTEPS; d < (kk - E0 + 1) * 8 / ESTEPS; ++d) pin_pair(0, d);
-          fence();
-        }
-      }
-    }
-    if constexpr (ESTEPS == 0) {
-      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]));
-#pragma unroll
-      for (int d = 0; d < 8; ++d) pin_pair(0, d);
-      fence();
-    }
-    // ---- GEMM2, first half: the steps that contract over tile 0's columns (c = 0, 1), with tile 1's element pairs
-    constexpr int NSTEP = RT * 4, HALF = RT * 2;
-    u32x4 r2[PF];
-    auto b_offs = [&](int step) {
-      const int rt = step % RT, c = step / RT;
-      return rt * 4096 + b_row + b_off[c >> 1][c & 1];
-    };
-    auto g2_step = [&](int step) {
-      const int rt = step % RT, c = step / RT;
-      const int tt = c >> 1, m2 = c & 1;
-      const u32x4 bh = r2[step % PF];
-      if (step + PF < NSTEP) r2[step % PF] = ld16(sb + C::P2HI + b_offs(step + PF));
-      const u32x4 nh = {g.gnh[tt][4 * m2], g.gnh[tt][4 * m2 + 1], g.gnh[tt][4 * m2 + 2], g.gnh[tt][4 * m2 + 3]};
-      on[rt] = mfma_op<OPT>(nh, bh, on[rt]);
-      if constexpr (C::TWO_ACC) {
-        const u32x4 ph = {g.gph[tt][4 * m2], g.gph[tt][4 * m2 + 1], g.gph[tt][4 * m2 + 2], g.gph[tt][4 * m2 + 3]};
-        op[rt] = mfma_op<OPT>(ph, bh, op[rt]);
-      }
-    };
-#pragma unroll
-    for (int p = 0; p < PF; ++p) r2[p] = ld16(sb + C::P2HI + b_offs(p));
-    fence();
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[1]));   // S tile 1: last asm MFMA -> VALU read
-#pragma unroll
-    for (int step = 0; step < HALF; ++step) {
-      g2_step(step);
-      fence();
-#pragma unroll
-      for (int d = step * 8 / HALF; d < (step + 1) * 8 / HALF; ++d) pin_pair(1, d);
-      fence();
-    }
-    // X's registers are dead from here on: fetch the next tile into them (single X buffer).  Unconditional -- the last
-    // tile re-reads itself -- so that the whole tile stays ONE basic block: with a branch here LLVM sinks the pure
-    // elementwise code of tile 1 into the block behind it, i.e. out from under the MFMAs above.
-    {
-      const char* p = xbase + (size_t)t_next * (4 * NQ * 1024);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) x[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + q * 1024));
-    }
-    fence();
-#pragma unroll
-    for (int step = HALF; step < NSTEP; ++step) {
-      g2_step(step);
-      fence();
-    }
-  };
-
   auto drain = [&]() {   // the asm DMA of this tile's successor has landed; every wave is done with this tile's stage
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0)
     __syncthreads();
@@ -727,11 +605,6 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       const bool more = i + 1 < nt;
       if (more) stage_issue(t + 1, (buf ^ 1) * C::STAGE_BYTES);
       const char* sb = smem + buf * C::STAGE_BYTES;
-      if constexpr (C::IL) {
-        tile_interleaved(sb, t, xc, more ? t + 1 : t);
-        drain();
-        continue;
-      }
       f32x16 s[2];
       GOps g;
       gemm1(sb, s);

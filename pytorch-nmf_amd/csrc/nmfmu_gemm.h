@@ -36,7 +36,9 @@ struct GemmArgs {
   const uint16_t* b_lo;
   int m_pad, n_pad, k_pad;
   int k_len;             // contraction length actually run (multiple of 64, <= k_pad = the planes' row pitch)
-  int k_split;           // EPI_F32 only: gridDim.z workgroups share the contraction; slab z of out = its partial sum
+  int k_split;           // EPI_F32: gridDim.z workgroups share the contraction; slab z of out = its partial sum
+  int tail_rows;         // EPI_FOLD: the last tail_rows tile rows are contraction-split k_split ways (tail-round split:
+                         // a grid of 3.1 rounds then costs 3.1 + a fraction instead of 4); slab z of out = partial sums
   // epilogue operands
   const float* x;        // [m_pad][n_pad] fp32 (ratio / loss)
   uint16_t* gn_hi;       // ratio outputs, [m_pad][n_pad]
@@ -91,11 +93,22 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hl = lane >> 5;
   const int wm = wave / SH::WN, wn = wave % SH::WN;
-  const int bm = blockIdx.y, bn = blockIdx.x;
+  int bm = blockIdx.y, zz = blockIdx.z, nsp = a.k_split;
+  const int bn = blockIdx.x;
+  if constexpr (EPI == kEpiFold) {
+    // tail-round split: tile rows >= m_tiles - tail_rows appear k_split times along grid y (the hardware dispatches them
+    // last), each instance running one part of the contraction; their diagonal sums are linear, the gather adds them
+    nsp = 1;
+    const int row0 = a.m_pad / C::BM - a.tail_rows;
+    if (a.tail_rows > 0 && bm >= row0) {
+      const int q = bm - row0;
+      zz = q % a.k_split, bm = row0 + q / a.k_split, nsp = a.k_split;
+    }
+  }
   const int ktiles_all = a.k_len / C::BK;
-  // split-K (EPI_F32): workgroup z runs k-tiles [kt0, kt0 + ktiles) and stores its partial into slab z
-  const int kt_per = (ktiles_all + a.k_split - 1) / a.k_split;
-  const int kt0 = blockIdx.z * kt_per;
+  // split-K: part zz runs k-tiles [kt0, kt0 + ktiles) and stores its partial into slab zz
+  const int kt_per = (ktiles_all + nsp - 1) / nsp;
+  const int kt0 = zz * kt_per;
   const int ktiles = max(0, min(kt_per, ktiles_all - kt0));
   const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
 
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
           const float s1 = run(max(lo, bsw), rsw);        // first r, second b
           const float s2 = run(rsw, max(rsw, bsw));       // second r, first b   (rows [rsw, bsw))
           const float s3 = run(max(rsw, bsw), hi1);       // second r, second b
-          float* po = a.out + ((size_t)(tm * tiles_n + tn) * 4) * 256 + dd;
+          float* po = a.out + (size_t)zz * ((size_t)(a.m_pad / 128) * tiles_n * 1024) + ((size_t)(tm * tiles_n + tn) * 4) * 256 + dd;
           po[0] = s0, po[256] = s1, po[512] = s2, po[768] = s3;
         }
       }
@@ -377,7 +390,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         const size_t idx = (size_t)m * a.ldn + n;
         const float s = acc[mi][ni][e];
         if constexpr (EPI == kEpiF32) {
-          a.out[(size_t)blockIdx.z * a.m_pad * a.ldn + idx] = s;
+          a.out[(size_t)zz * a.m_pad * a.ldn + idx] = s;
         } else if constexpr (EPI == kEpiLoss) {
           const float x = a.x[idx];
           lacc += (m < a.m_valid && n < a.n_valid) ? loss_elem<BETA>(s, x, a.beta) : 0.f;
@@ -427,8 +440,9 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     *flag = true;
   }
-  if (a.k_split > 1 && EPI != kEpiF32) return -3;
-  hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, a.m_pad / C::BM, a.k_split), dim3(SH::THREADS), kLds, s, a);
+  if (a.k_split > 1 && EPI != kEpiF32 && !(EPI == kEpiFold && a.tail_rows > 0)) return -3;
+  const int grid_y = a.m_pad / C::BM + (EPI == kEpiFold ? a.tail_rows * (a.k_split - 1) : 0);
+  hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, grid_y, EPI == kEpiFold ? 1 : a.k_split), dim3(SH::THREADS), kLds, s, a);
   return (int)hipGetLastError();
 }
 

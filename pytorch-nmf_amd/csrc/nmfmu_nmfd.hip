@@ -364,7 +364,8 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
                                                                       const float* __restrict__ kl_den,
                                                                       const float* __restrict__ kl_wcol, int c_tiles,
                                                                       int rp_pad, float* __restrict__ hsum_part,
-                                                                      int tiles_n, float l1, float l2, float gamma) {
+                                                                      int tiles_n, float l1, float l2, float gamma,
+                                                                      int tail_tm0, int tail_split, size_t slab) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
   const int L = Lh + T - 1;
@@ -412,8 +413,11 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
         const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
         const int dd = diag - 128 * (tn - tm) + 127;
         const size_t i = ((size_t)(tm * tiles_n + tn) * 4 + seg) * 256 + dd;
-        neg += pnum[i];
-        if (!kl) pos += pden[i];
+        const int nz = tm >= tail_tm0 ? tail_split : 1;   // tile rows of the GEMM's tail-round split: one slab per part
+        for (int z = 0; z < nz; ++z) {
+          neg += pnum[i + z * slab];
+          if (!kl) pos += pden[i + z * slab];
+        }
       }
     }
     if (kl) pos = den;
@@ -701,7 +705,14 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   a.k_len = d->k_len ? d->k_len : d->k_pad;
   if (a.k_len <= 0 || a.k_len > d->k_pad || a.k_len % 64) return NMFMU_ERR_ARG;
   a.k_split = d->k_split > 1 ? d->k_split : 1;
-  if (a.k_split > 1 && (epilogue != NMFMU_EPI_F32 || (a.k_len / 64) % a.k_split)) return NMFMU_ERR_ARG;
+  a.tail_rows = 0;
+  if (epilogue == NMFMU_EPI_FOLD) {
+    a.tail_rows = a.k_split > 1 ? d->tail_rows : 0;
+    if (a.tail_rows < 0 || a.tail_rows > d->m_pad / 128 || (a.k_split > 1 && a.tail_rows == 0)) return NMFMU_ERR_ARG;
+    if (a.tail_rows == 0) a.k_split = 1;
+  } else if (a.k_split > 1 && (epilogue != NMFMU_EPI_F32 || (a.k_len / 64) % a.k_split)) {
+    return NMFMU_ERR_ARG;
+  }
   a.x = d->x;
   a.gn_hi = (uint16_t*)d->gn_hi, a.gn_lo = (uint16_t*)d->gn_lo, a.gp_hi = (uint16_t*)d->gp_hi, a.gp_lo = (uint16_t*)d->gp_lo;
   a.out = d->out;
@@ -907,13 +918,21 @@ int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps) {
 
 static int fold_parts_apply(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
                             const float* kl_den, const float* kl_wcol, int c_tiles, int rp_pad, float* hsum_part, int bl_pad,
-                            float l1, float l2, float gamma, void* stream) {
+                            float l1, float l2, float gamma, void* stream, int m_pad = 0, int tail_rows = 0, int k_split = 1) {
   if (!h || !p_num || (!p_den && !kl_den && !kl_wcol) || bl_pad % 128 || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
   if (kl_wcol && (c_tiles <= 0 || rp_pad < rank * taps)) return NMFMU_ERR_ARG;
   if (!nmfmu_fold_parts_supported(batch, rank, lh, taps)) return NMFMU_ERR_UNSUPPORTED;
   const int grid = batch * rank * ((lh + 255) / 256);
+  // the GEMM's tail-round split: tile rows >= m_pad / 128 - tail_rows come as k_split partial slabs
+  int tail_tm0 = 1 << 30;
+  size_t slab = 0;
+  if (tail_rows > 0 && k_split > 1) {
+    if (m_pad % 128 || tail_rows > m_pad / 128) return NMFMU_ERR_ARG;
+    tail_tm0 = m_pad / 128 - tail_rows;
+    slab = nmfmu_fold_part_bytes(m_pad, bl_pad) / sizeof(float);
+  }
   hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps, p_num,
-                     p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma);
+                     p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma, tail_tm0, k_split, slab);
   return (int)hipGetLastError();
 }
 
@@ -923,6 +942,14 @@ int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int tap
 }
 
 int nmfmu_fold_hsum_parts(int batch, int lh) { return batch * ((lh + 255) / 256); }
+
+int nmfmu_conv_fold_parts_apply_h_tail(float* h, int batch, int rank, int lh, int taps, const float* p_num,
+                                       const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
+                                       int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma, int m_pad,
+                                       int tail_rows, int k_split, void* stream) {
+  return fold_parts_apply(h, batch, rank, lh, taps, p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad, l1, l2,
+                          gamma, stream, m_pad, tail_rows, k_split);
+}
 
 int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,
                                        const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,

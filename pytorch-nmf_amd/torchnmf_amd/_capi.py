@@ -50,7 +50,8 @@ class GemmDesc(C.Structure):
                 ('beta', C.c_float), ('x', C.c_void_p), ('gn_hi', C.c_void_p), ('gn_lo', C.c_void_p),
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
-                ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32)]
+                ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
+                ('tail_rows', C.c_int32)]
 
 
 ABI_VERSION = 4   # include/nmfmu.h: NMFMU_ABI_VERSION
@@ -150,6 +151,9 @@ SIGNATURES = {
     'nmfmu_conv_fold_parts_apply_h_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                      C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_conv_fold_parts_apply_h_tail': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                     C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'nmfmu_fold_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'nmfmu_fold_parts_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_fold_parts_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -153,7 +153,24 @@ class ConvMU:
         # (NMFMU_EPI_FOLD, 4 KiB per tile) instead of storing Y (4 R T B L bytes, 105 MB at configs[3])
         self.fold_parts = (own_loop and nd == 1 and bool(self.lib.nmfmu_fold_parts_supported(B, R, Lh, T)) and
                            os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0')
-        ny = self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4 if self.fold_parts else rpp * blp
+        # tail-round split of the H-numerator GEMM (fold epilogue): its (rp_pad / 128) x (bl_pad / 128) tiles run two per CU;
+        # when they make N full rounds of the chip plus at most a quarter round that is whole tile rows (configs[3]: 1600
+        # tiles on 512 slots = 3 rounds + the last row of 64), those rows are contraction-split so that the last round
+        # costs a fraction of a tile time.  The parts add up in the gather (fixed order).
+        self.h_tail_rows, self.h_tail_split = 0, 1
+        want = os.environ.get('TORCHNMF_AMD_NMFD_TAIL_SPLIT', '1')      # '0' off, '1' automatic, 'rows,split' forced (tests)
+        if self.fold_parts and want != '0':
+            slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+            mt, nt = rpp // 128, blp // 128
+            rem = (mt * nt) % slots
+            k_tiles = -(-Cc // 64)
+            if ',' in want:
+                self.h_tail_rows, self.h_tail_split = (int(v) for v in want.split(','))
+                assert 0 < self.h_tail_rows <= mt and 2 <= self.h_tail_split <= k_tiles
+            elif mt * nt > slots and 0 < rem <= slots // 4 and rem % nt == 0 and k_tiles >= 8:
+                self.h_tail_rows = rem // nt
+                self.h_tail_split = max(2, min(slots // rem, k_tiles // 2, 8))
+        ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
         self.y = torch.empty(ny, dtype=torch.float32, device=dev)
         self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
@@ -186,7 +203,7 @@ class ConvMU:
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
-              n_rows=None, k_len=0, k_split=0, tag=None):
+              n_rows=None, k_len=0, k_split=0, tail_rows=0, tag=None):
         """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
         output planes keep their leading dimension.  tag: name of the launch for an attached KernelTimer (bench.py)."""
         assert a.cols_pad == b.cols_pad
@@ -200,7 +217,8 @@ class ConvMU:
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), m_pad, n_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
-                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split)
+                           _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split,
+                           tail_rows)
         timer = getattr(self, 'timer', None) if tag else None
         if timer is not None:
             timer.mark(tag + '<')
@@ -308,23 +326,24 @@ class ConvMU:
             self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, tag='recon_h')
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
         kc = -(-self.C // 64) * 64             # the contraction runs over the channels: skip the zero tail of the padding
-        self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc, tag='num_h')
+        tail = dict(k_split=self.h_tail_split, tail_rows=self.h_tail_rows) if self.h_tail_rows else {}
+        self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc, tag='num_h', **tail)
         if not self.kl:
-            self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc)
+            self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc, **tail)
         kl_den = self.sum_w.data_ptr() if self.kl else None
         if self.fused_sums:
-            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_sums(
+            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_tail(
                 self.H.data_ptr(), self.B, self.R, self.Lh, self.T, self.y.data_ptr(), None, None, self.wcol.data_ptr(),
-                self.c_pad // 64, self.rp_pad, self.hpart.data_ptr(), self.bl_pad, self.l1, self.l2, self.gamma, _stream()),
-                'nmfmu_conv_fold_parts_apply_h_sums')
+                self.c_pad // 64, self.rp_pad, self.hpart.data_ptr(), self.bl_pad, self.l1, self.l2, self.gamma,
+                self.rp_pad, self.h_tail_rows, self.h_tail_split, _stream()), 'nmfmu_conv_fold_parts_apply_h_tail')
             self._h_parts_valid = True
             self._pack_h(sums=False)
             return
         if self.fold_parts:
-            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
-                                                               self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,
-                                                               self.l1, self.l2, self.gamma, _stream()),
-                        'nmfmu_conv_fold_parts_apply_h')
+            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_tail(
+                self.H.data_ptr(), self.B, self.R, self.Lh, self.T, self.y.data_ptr(), _ptr(self.y_den), kl_den, None, 0, 0,
+                None, self.bl_pad, self.l1, self.l2, self.gamma, self.rp_pad, self.h_tail_rows, self.h_tail_split,
+                _stream()), 'nmfmu_conv_fold_parts_apply_h_tail')
         elif self.nd == 1:
             _capi.check(self.lib.nmfmu_conv_fold_apply_h(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
                                                          self.y.data_ptr(), _ptr(self.y_den), kl_den, self.bl_pad,

@@ -685,6 +685,38 @@ def test_nmfd_fold_from_tile_diagonal_sums(dev, shape, beta, prec, monkeypatch):
         assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
 
 
+@pytest.mark.parametrize('shape,tail', [((1, 520, 600, 2, 136), '1,3'), ((2, 600, 335, 3, 130), '2,2'), ((1, 1025, 776, 1, 400), '4,8')])
+@pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (1, 'f16')])
+def test_nmfd_h_numerator_tail_round_split(dev, shape, tail, beta, prec, monkeypatch):
+    """Tail-round split of the H-numerator GEMM (round 3): its last tile rows run contraction-split, their per-tile
+    diagonal sums arrive as partial slabs and the gather adds them in a fixed order.  Forced here on small shapes
+    (configs[3] selects it by itself: 1600 tiles on 512 slots): must agree with the unsplit launch to fp32 rounding and
+    with the oracle."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    if prec == 'f16' and (T % 8 or L % 8):
+        pytest.skip('fp16 operands need implicit Toeplitz operands (taps and frames multiples of 8)')
+    res = {}
+    for mode in ('0', tail):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_TAIL_SPLIT', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, 0.01, 0.02, precision=prec)
+        assert eng.fold_parts and (eng.h_tail_rows, eng.h_tail_split) == ((0, 1) if mode == '0' else tuple(int(v) for v in tail.split(',')))
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu())
+    assert rel_err(res[tail][0], res['0'][0]) < 2e-6 and rel_err(res[tail][1], res['0'][1]) < 2e-6
+    if prec == 'bf16x3':
+        Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
+        assert rel_err(res[tail][0], Wr) < TOL and rel_err(res[tail][1], Hr) < TOL
+
+
 @pytest.mark.parametrize('shape', [(1, 129, 304, 4, 8), (2, 257, 200, 3, 24), (1, 136, 600, 2, 400), (1, 1025, 520, 3, 136),
                                    (3, 130, 96, 9, 5)])
 @pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (1, 'bf16')])

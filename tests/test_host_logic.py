@@ -166,7 +166,7 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
-    assert [f[0] for f in d._fields_][-4:] == ['tile_rows', 'n_ld', 'k_len', 'k_split']
+    assert [f[0] for f in d._fields_][-5:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows']
     # argument checking happens before any device work
     assert lib.nmfmu_gemm(None, 0, None) == _capi.ERR_ARG
     assert lib.nmfmu_conv_ragged_rows(None, 1, 1, 1, None, 1, 1, 0, 0, 1.0, 0, None, 0, None, None, None, None, None,
