@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int b_rowoff = (wn * NI * 32 + j) * 128;
   const int swz = ((j >> 1) & 7) << 4;
 
-  stage_issue(0, 0);
+  if (ktiles > 0) stage_issue(0, 0);   // (an empty contraction part -- split factor not dividing the k-tiles -- stores zeros)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // one k-tile; the staging buffer index is a compile-time constant (the loop below is unrolled by two), so every LDS

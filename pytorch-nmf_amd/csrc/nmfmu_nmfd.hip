@@ -709,6 +709,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (epilogue == NMFMU_EPI_FOLD) {
     a.tail_rows = a.k_split > 1 ? d->tail_rows : 0;
     if (a.tail_rows < 0 || a.tail_rows > d->m_pad / 128 || (a.k_split > 1 && a.tail_rows == 0)) return NMFMU_ERR_ARG;
+    if (a.tail_rows > 0 && a.k_split > a.k_len / 64) return NMFMU_ERR_ARG;   // more parts than k-tiles
     if (a.tail_rows == 0) a.k_split = 1;
   } else if (a.k_split > 1 && (epilogue != NMFMU_EPI_F32 || (a.k_len / 64) % a.k_split)) {
     return NMFMU_ERR_ARG;

@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           if (a.l1 > 0.f) pos += a.l1;
           if (a.l2 > 0.f) pos += a.l2 * fv[k];
           float mult = neg / pos;
-          if (a.gamma != 1.f) mult = powf(mult, a.gamma);
+          if (a.gamma != 1.f) mult = mu_pow(mult, a.gamma);
           // padding rows / ranks stay exactly 0 (their denominators may be 0: 0 * inf)
           fv[k] = (row < a.M && r0 + k < a.rank) ? fv[k] * mult : 0.f;
           csum8[k] += fv[k];

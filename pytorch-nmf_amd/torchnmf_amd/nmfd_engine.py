@@ -170,6 +170,11 @@ class ConvMU:
             elif mt * nt > slots and 0 < rem <= slots // 4 and rem % nt == 0 and k_tiles >= 8:
                 self.h_tail_rows = rem // nt
                 self.h_tail_split = max(2, min(slots // rem, k_tiles // 2, 8))
+            if self.h_tail_rows:                       # every part non-empty: parts of ceil(k_tiles / split) k-tiles
+                per = -(-k_tiles // self.h_tail_split)
+                self.h_tail_split = -(-k_tiles // per)
+                if self.h_tail_split < 2:
+                    self.h_tail_rows, self.h_tail_split = 0, 1
         ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
         self.y = torch.empty(ny, dtype=torch.float32, device=dev)
         self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)

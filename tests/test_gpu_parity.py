@@ -320,6 +320,37 @@ def test_f16_range_handling(dev):
     assert rel_err(H1[keep], Hr[keep]) < 5e-3, rel_err(H1[keep], Hr[keep])
 
 
+def test_f16_factor_leaving_the_range_is_reported(dev):
+    """the fp16 range gate looks at the initial data only.  A factor that grows beyond 65504 during the fit is
+    clamped in its fp16 image; every kernel that clamps sets bit 0 of nmfmu_step.status, fit() reads it at its loss
+    checkpoints and warns (the update no longer follows the reference from there on)."""
+    import warnings
+    from torchnmf_amd.engine import DenseMU
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(4)
+    N, C, R = 300, 520, 8
+    V = (torch.rand(N, C, generator=g) * 2.0e4).half().float()
+    W0 = torch.rand(C, R, generator=g) + 0.5
+    H0 = (torch.rand(N, R, generator=g) + 0.5) * 1e-3          # W <- W * (V / (H W^T)) H / sum(H)  ~ 2e4 / 1e-3: far outside
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = DenseMU(V.to(dev), W, H, 1.0, precision='f16')
+    assert not eng.left_f16_range()
+    eng.w_step()
+    torch.cuda.synchronize()
+    assert float(W.max()) > 65504.0 and eng.left_f16_range()
+    # in range: the flag stays clear
+    W2, H2 = W0.clone().to(dev), (H0 * 1e3).to(dev)
+    eng2 = DenseMU((V / 2.0e4).to(dev), W2, H2, 1.0, precision='f16')
+    eng2.w_step(); eng2.h_step()
+    torch.cuda.synchronize()
+    assert not eng2.left_f16_range()
+    m = NMF(W=W0, H=H0).to(dev)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        m.fit(V.to(dev), 1, NO_STOP, 10, precision='f16')
+    assert any("fp16's range" in str(w.message) for w in rec), [str(w.message) for w in rec]
+
+
 def test_fit_f16_meets_parity_bar(dev):
     """north_star's bar (1e-4 relative on the factors after N iterations) in the single-plane fp16 mode at a size where
     the per-step rounding errors average down: 2048 x 4096, rank 64, 50 iterations."""
