@@ -519,12 +519,23 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       lacc += (rowok && k0 + 1 < a.K) ? loss_elem<LB>(s1, x1, a.beta) : 0.f;
     } else {
       float n0, n1, p0, p1;
+      // fp16 target: the factor of Gn that does not depend on x first, then ONE v_fma_mix_f32 per element multiplies it
+      // by the fp16 half of the stored word (no separate conversion of x)
+      constexpr bool MIX = C::F16 && BETA != kEuc;
+      const float xa = MIX ? 1.f : x0, xb = MIX ? 1.f : x1;
       if constexpr (C::SCALE) {
-        mu_elem_scaled<BETA>(s0, x0, a.beta, ki, n0, p0);
-        mu_elem_scaled<BETA>(s1, x1, a.beta, ki, n1, p1);
+        mu_elem_scaled<BETA>(s0, xa, a.beta, ki, n0, p0);
+        mu_elem_scaled<BETA>(s1, xb, a.beta, ki, n1, p1);
       } else {
-        mu_elem<BETA>(s0, x0, a.beta, n0, p0);
-        mu_elem<BETA>(s1, x1, a.beta, n1, p1);
+        mu_elem<BETA>(s0, xa, a.beta, n0, p0);
+        mu_elem<BETA>(s1, xb, a.beta, n1, p1);
+      }
+      if constexpr (MIX) {
+        const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
+        float m0, m1;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(m0) : "v"(w), "v"(n0));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(m1) : "v"(w), "v"(n1));
+        n0 = m0, n1 = m1;
       }
       if constexpr (C::DEN) n0 = p0, n1 = p1;   // denominator-only pass: the one operand set carries Gp
       // (beta == 2 with one operand plane: Gn IS the stored target word -- no unpack / re-pack)
