@@ -716,7 +716,7 @@ def test_nmfd_fold_from_tile_diagonal_sums(dev, shape, beta, prec, monkeypatch):
         assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
 
 
-@pytest.mark.parametrize('shape,tail', [((1, 520, 600, 2, 136), '1,3'), ((2, 600, 335, 3, 130), '2,2'), ((1, 1025, 776, 1, 400), '4,8')])
+@pytest.mark.parametrize('shape,tail', [((1, 520, 600, 2, 136), '1,3'), ((2, 600, 335, 3, 130), '2,2'), ((1, 1025, 776, 1, 400), '4,6')])
 @pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (1, 'f16')])
 def test_nmfd_h_numerator_tail_round_split(dev, shape, tail, beta, prec, monkeypatch):
     """Tail-round split of the H-numerator GEMM (round 3): its last tile rows run contraction-split, their per-tile
