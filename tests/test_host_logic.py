@@ -312,6 +312,91 @@ def test_betamu_argument_checks_and_unsupported_graphs(cpu_engine):
     assert rel_err(m2.W.data, W_ref) < 5e-6
 
 
+def test_f16_admission_test_of_auto_precision():
+    """'auto' takes the fp16 mode only for targets fp16 holds EXACTLY and data inside its range:
+    the host-side test, on CPU tensors (it is plain torch code)."""
+    from torchnmf_amd.engine import DenseMU
+    g = torch.Generator().manual_seed(0)
+    V = torch.rand(300, 500, generator=g)
+    W, H = torch.rand(500, 8, generator=g) + 0.1, torch.rand(300, 8, generator=g) + 0.1
+    assert not DenseMU.f16_in_range(V, W, H)                          # plain floats: fp16 would round them
+    assert DenseMU.f16_in_range(V.bfloat16().float(), W, H)           # bf16-sourced data is exact in fp16
+    assert DenseMU.f16_in_range(V.half().float(), W, H)
+    assert DenseMU.f16_in_range(torch.randint(0, 2048, (300, 500), generator=g).float(), W, H)   # counts below 2^11
+    assert not DenseMU.f16_in_range(torch.randint(0, 4096, (300, 500), generator=g).float() + 2049, W, H)
+    assert not DenseMU.f16_in_range(V.half().float() * 2.0 ** 17, W, H)   # exact, but beyond the range gate
+    assert not DenseMU.f16_in_range(V.half().float() * 2.0 ** -20, W, H)  # mostly subnormal
+    assert not DenseMU.f16_in_range(V.half().float(), W * 1e5, H)
+    Vb = V.half().float()
+    Vb[:, 250:] = V[:, 250:]                                              # inexact values in a later row chunk's columns
+    assert not DenseMU.f16_in_range(Vb, W, H)
+
+
+def test_auto_precision_policy_on_the_standin_backend(cpu_engine):
+    """The decision tree of 'auto' without a GPU (the stand-in backend supports every single-plane rank and split bf16 up
+    to rank 128, like the library): fp16 needs both dimensions >= F16_MIN_DIM and an admissible target; otherwise split
+    bf16; above rank 128 an error from the fused engine -- never plain bf16."""
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import DenseMU
+    g = torch.Generator().manual_seed(1)
+    old = DenseMU.F16_MIN_DIM
+    DenseMU.F16_MIN_DIM = 64
+    try:
+        def pick(N, C, R, exact=True, allow=True):
+            V = torch.rand(N, C, generator=g)
+            V = V.half().float() if exact else V
+            return DenseMU(V, torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1, 1.0,
+                           precision='auto', allow_f16=allow).precision_name
+        assert pick(64, 80, 8) == 'f16'
+        assert pick(64, 80, 8, exact=False) == 'bf16x3'
+        assert pick(64, 80, 8, allow=False) == 'bf16x3'
+        assert pick(63, 80, 8) == 'bf16x3'
+        assert pick(64, 80, 200) == 'f16'
+        with pytest.raises(NotImplementedError):
+            pick(63, 80, 200)
+        with pytest.raises(NotImplementedError):
+            pick(64, 80, 200, exact=False)
+    finally:
+        DenseMU.F16_MIN_DIM = old
+    assert _capi.PRECISIONS['f16'] == _capi.PREC_F16 == 2
+
+
+def test_bench_block_timing_rules(monkeypatch):
+    """bench.py's timed_blocks: at least --repeats blocks of exactly K steps, more until two consecutive blocks agree within
+    2 % (or --max-repeats); the median of the settled tail is reported.  Driven with a fake clock, no GPU."""
+    import importlib
+    import sys as _sys
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    _sys.modules.pop('bench', None)
+    bench = importlib.import_module('bench')
+    calls = {'n': 0}
+    durations = iter([1.30, 1.20, 1.10, 1.00, 0.99, 0.985, 0.98, 0.98, 0.98])   # seconds per block: still falling at first
+    now = {'t': 0.0}
+    pending = {'d': None}
+
+    def perf_counter():
+        return now['t']
+
+    def run():
+        calls['n'] += 1
+        if calls['n'] % 10 == 1:                     # first step of a block: advance the clock by that block's duration
+            pending['d'] = next(durations)
+            now['t'] += pending['d']
+    monkeypatch.setattr(bench.time, 'perf_counter', perf_counter)
+    ms, blocks = bench.timed_blocks(run, 10, 3, 40)
+    assert calls['n'] == 10 * len(blocks)            # exactly K steps per block
+    assert len(blocks) == 5                          # 1.30, 1.20, 1.10 (3 = --repeats), 1.00, 0.99: the last two agree
+    assert ms == pytest.approx(sorted(blocks[-3:])[1]) and blocks[0] == pytest.approx(130.0)
+    calls['n'] = 0
+    durations = iter([1.0] * 50)
+    ms, blocks = bench.timed_blocks(run, 10, 5, 40)
+    assert len(blocks) == 5 and ms == pytest.approx(100.0)
+    calls['n'] = 0
+    durations = iter([2.0 ** -i for i in range(50)])  # never settles: stops at --max-repeats
+    ms, blocks = bench.timed_blocks(run, 10, 2, 6)
+    assert len(blocks) == 6
+
+
 @pytest.mark.parametrize('unit', ['nmfmu_inst_r128', 'nmfmu_inst_r256', 'nmfmu_inst_pp'])
 def test_fused_kernels_do_not_spill_to_scratch(tmp_path, unit):
     """Guard: the fused kernels must keep their accumulators in registers.  A runtime-indexed register array silently

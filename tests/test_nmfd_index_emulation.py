@@ -149,3 +149,52 @@ def test_implicit_toeplitz_chunk_index(B, R, T, Lh):
                 for l0 in range(0, L - 7, 8):
                     soff = 1 + b * R * JJ + l0
                     assert np.array_equal(fwd[trow + soff], Hu[b * L + l0:b * L + l0 + 8, r * T + t])
+
+
+@pytest.mark.parametrize('B,R,T,Lh,C,tail_rows,k_split', [(1, 2, 136, 200, 600, 1, 3), (2, 2, 130, 77, 520, 2, 2), (1, 1, 400, 201, 1025, 4, 6)])
+def test_tail_round_split_grid_mapping_and_gather(B, R, T, Lh, C, tail_rows, k_split):
+    """Round 3: the tail-round split of the H-numerator GEMM.  Grid row y of nt_gemm_kernel<EPI_FOLD> -> (tile row, contraction
+    part): rows below m_tiles - tail_rows appear once, the last tail_rows rows k_split times (dispatched last); part z
+    runs k-tiles [z * per, min((z + 1) * per, ktiles)) and writes slab z; the gather adds the slabs of those rows.  The
+    mapping must cover every (tile row, k-tile) exactly once and the gathered sums must equal the unsplit ones."""
+    L = Lh + T - 1
+    rng = np.random.default_rng(T + C)
+    m_pad, n_pad = -(-R * T // 128) * 128, -(-B * L // 128) * 128
+    tiles_m, tiles_n = m_pad // 128, n_pad // 128
+    tail_rows = min(tail_rows, tiles_m)
+    ktiles = -(-C // 64)
+    per = -(-ktiles // k_split)
+    assert (k_split - 1) * per < ktiles, 'the host normalises the split so that every part is non-empty'
+    # operands of Y = Wm^T-planes [m_pad][C] x Gn^T-planes [n_pad][C], zero padded
+    A = np.zeros((m_pad, ktiles * 64)); A[:R * T, :C] = rng.random((R * T, C))
+    Bm = np.zeros((n_pad, ktiles * 64)); Bm[:B * L, :C] = rng.random((B * L, C))
+    covered = np.zeros((tiles_m, ktiles), dtype=int)
+    slabs = [[None] * (tiles_m * tiles_n) for _ in range(k_split)]
+    row0 = tiles_m - tail_rows
+    for y in range(tiles_m + tail_rows * (k_split - 1)):            # gridDim.y of the launch
+        bm, zz, nsp = y, 0, 1
+        if tail_rows > 0 and y >= row0:
+            q = y - row0
+            zz, bm, nsp = q % k_split, row0 + q // k_split, k_split
+        kt_per = -(-ktiles // nsp)
+        kt0 = zz * kt_per
+        kts = max(0, min(kt_per, ktiles - kt0))
+        covered[bm, kt0:kt0 + kts] += 1
+        Ypart = A[bm * 128:(bm + 1) * 128, kt0 * 64:(kt0 + kts) * 64] @ Bm[:, kt0 * 64:(kt0 + kts) * 64].T    # this part's tile row of Y
+        Yfull = np.zeros((m_pad, n_pad)); Yfull[bm * 128:(bm + 1) * 128] = Ypart
+        for tn in range(tiles_n):
+            slabs[zz][bm * tiles_n + tn] = fold_parts_of_tile(Yfull, bm, tn, T, L)
+    assert (covered == 1).all()
+    Y = A @ Bm.T
+    want_parts = [fold_parts_of_tile(Y, tm, tn, T, L) for tm in range(tiles_m) for tn in range(tiles_n)]
+    # the gather of conv_fold_parts_apply_h_kernel with (tail_tm0, tail_split): slab 0 everywhere, slabs 1.. for the tail rows
+    summed = []
+    for tm in range(tiles_m):
+        for tn in range(tiles_n):
+            nz = k_split if tm >= row0 else 1
+            summed.append(sum(slabs[z][tm * tiles_n + tn] for z in range(nz)))
+    for i in range(len(summed)):
+        np.testing.assert_allclose(summed[i], want_parts[i], rtol=1e-12, atol=1e-9)
+    for (b, r, jx) in [(0, 0, 0), (B - 1, R - 1, Lh - 1), (0, R - 1, Lh // 2)]:
+        direct = sum(Y[r * T + t, b * L + jx + t] for t in range(T))
+        assert gather(summed, tiles_n, b, r, jx, T, L) == pytest.approx(direct, rel=1e-10)
