@@ -491,7 +491,14 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
-    preroll = preroll_steps(step, a.preroll_s)
+    if world > 1:
+        # every rank must run the SAME number of steps (each holds collectives): a fixed pre-roll instead of a timed one
+        preroll = 60
+        for _ in range(preroll):
+            step()
+        torch.cuda.synchronize()
+    else:
+        preroll = preroll_steps(step, a.preroll_s)
 
     def barrier():
         if world > 1:
