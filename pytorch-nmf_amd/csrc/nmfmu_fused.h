@@ -671,6 +671,15 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         // master loads first (independent, fully pipelined), then the dependent compute + stores -- in chunks of at
         // most four 32-wide rank tiles so that the staging array stays at 64 registers
         constexpr int RC = RT > 4 ? 4 : RT;
+        // unregularised full tiles (the usual case) take a branch-free form: no bounds tests, no per-element uniform
+        // branches, a reciprocal instead of the IEEE division (<= 1 ulp apart; as in the ping-pong kernel's epilogue)
+        // (beta = 2 only: +2 % there; at beta = 0.5 / 0 the second copy of the epilogue cost the W half-step 5 % -- r3pl)
+        const bool plain = BETA == kEuc && a.l1 <= 0.f && a.l2 <= 0.f && a.gamma == 1.f && a.rank == R_PAD && mrow0 + 32 <= a.M;
+        auto update = [&](auto plain_c) {
+        constexpr bool PL = decltype(plain_c)::value;
+        float rden[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rden[rt] = PL && !C::TWO_ACC ? 1.f / den[rt] : 0.f;
         static_for<RT / RC>([&](auto chunk) {
           constexpr int rt0 = decltype(chunk)::value * RC;
           float fold[RC][16];
@@ -680,7 +689,8 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-              fold[rc][e] = (row < a.M && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
+              if constexpr (PL) fold[rc][e] = a.f[(size_t)row * R_PAD + r];
+              else fold[rc][e] = (row < a.M && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
             }
           });
           static_for<RC>([&](auto rcc) {
@@ -690,7 +700,14 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
             for (int e = 0; e < 16; ++e) {
               const int row = mrow0 + (e & 3) + 8 * (e >> 2) + 4 * hl;
               float fv = fold[rc][e];
-              if (row < a.M && r < a.rank) {
+              if constexpr (PL) {
+                const float neg = fmaxf(C::SCALE ? on[rt][e] * unsc_f : on[rt][e], 0.f) + kEps;
+                if constexpr (C::TWO_ACC)
+                  fv *= neg * __builtin_amdgcn_rcpf(fmaxf(C::SCALE ? op[rt][e] * unsc_f : op[rt][e], 0.f) + kEps);
+                else
+                  fv *= neg * rden[rt];
+                a.f[(size_t)row * R_PAD + r] = fv;
+              } else if (row < a.M && r < a.rank) {
                 const float neg = fmaxf(C::SCALE ? on[rt][e] * unsc_f : on[rt][e], 0.f) + kEps;
                 float pos = den[rt];
                 if constexpr (C::TWO_ACC) pos = fmaxf(C::SCALE ? op[rt][e] * unsc_f : op[rt][e], 0.f) + kEps;
@@ -721,6 +738,13 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
             }
           });
         });
+        };
+        if constexpr (BETA == kEuc) {
+          if (plain) update(std::integral_constant<bool, true>{});
+          else update(std::integral_constant<bool, false>{});
+        } else {
+          update(std::integral_constant<bool, false>{});
+        }
         __syncthreads();
         // row-major image from the LDS tile: 32 rows x R_PAD/8 sixteen-byte slots per wave
         constexpr int SP = R_PAD / 8;

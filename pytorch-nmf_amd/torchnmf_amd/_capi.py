@@ -51,10 +51,11 @@ class GemmDesc(C.Structure):
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
-                ('tail_rows', C.c_int32)]
+                ('tail_rows', C.c_int32), ('rag_w', C.c_void_p), ('rag_h', C.c_void_p), ('rag_c0', C.c_int32),
+                ('rag_channels', C.c_int32)]
 
 
-ABI_VERSION = 4   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 5   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
