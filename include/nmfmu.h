@@ -36,7 +36,7 @@ extern "C" {
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
                                   NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status;
-                               5: nmfmu_gemm_desc.rag_* (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported */
+                               5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -263,12 +263,11 @@ typedef struct nmfmu_gemm_desc {
   int32_t k_split;
   int32_t tail_rows;   /* (ABI 4, appended) */
   /* (ABI 5, appended) Ragged channels inside the grid of a reconstruction GEMM (NMFMU_EPI_RATIO with ops B_HU or A_HU):
-   * channels [rag_c0, rag_channels) -- those beyond the GEMM's own m_pad (B_HU) resp. n_pad (A_HU) rows -- are summed
-   * directly from the fp32 masters rag_w (C, R, T) and rag_h (B, R, Lh), a 16-frame slice per workgroup after its tile,
-   * with the same elementwise epilogue into the same planes (row / column rag_c0.. of x / gn / gp at pitch n_ld).
-   * Replaces a separate nmfmu_conv_ragged_rows launch (modes 0 / 1) when nmfmu_gemm_ragged_supported().  NULL: off. */
-  const float* rag_w;
-  const float* rag_h;
+   * channels [rag_c0, rag_channels), at most 16 -- those beyond the GEMM's own m_pad (B_HU) resp. n_pad (A_HU) rows of
+   * the explicit operand, whose planes must hold rows rag_c0 .. rag_c0 + 15 (zero beyond the logical extent) -- ride
+   * along as one extra 16 x 16 x 32 MFMA block per workgroup, with the same elementwise epilogue into the same planes
+   * (row / column rag_c0.. of x / gn / gp at pitch n_ld).  Replaces a separate nmfmu_conv_ragged_rows launch (modes
+   * 0 / 1) when nmfmu_gemm_ragged_supported().  rag_channels == 0: off. */
   int32_t rag_c0, rag_channels;
 } nmfmu_gemm_desc;
 
@@ -303,9 +302,9 @@ int nmfmu_conv_tables_f16(const float* h, int batch, int rank, int lh, int taps,
  * x has the layout of the outputs.  BF16 / BF16X3 / F16. */
 int nmfmu_conv_ragged_supported(int rank, int taps);
 int nmfmu_conv_ragged_blocks(int batch, int lh, int taps);
-/* 1 if nmfmu_gemm can take the ragged channels into its own grid (nmfmu_gemm_desc.rag_*): the W row and the H windows of a
- * 16-frame slice must fit the kernel's staging buffers (64 KiB; 128 KiB for BF16X3). */
-int nmfmu_gemm_ragged_supported(int rank, int taps, int precision);
+/* 1 if nmfmu_gemm can take `extra` (1..16) ragged channels into its own grid (nmfmu_gemm_desc.rag_*): eight workgroups
+ * share out the 128 frames of an implicit-operand tile, so the explicit operand needs >= 8 whole 128-row tiles. */
+int nmfmu_gemm_ragged_supported(int ops, int m_pad, int n_pad, int extra);
 int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, const float* h, int batch, int lh, int c0,
                            int precision, float beta, int mode, const float* x, int64_t ld, void* gn_hi, void* gn_lo,
                            void* gp_hi, void* gp_lo, float* loss_part, void* stream);

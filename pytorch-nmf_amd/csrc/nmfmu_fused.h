@@ -177,6 +177,19 @@ __device__ __forceinline__ f32x16 mfma_op(u32x4 a, u32x4 b, f32x16 c) {
     return mfma_bf16(a, b, c);
 }
 
+// 16 x 16 x 32 (gfx950): A / B lane = (row lane & 15, k = 8 (lane >> 4) + i), C / D lane = (column lane & 15, rows 4 (lane >> 4) + i)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int OPT>
+__device__ __forceinline__ f32x4 mfma16_op(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (OPT == kOpF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return mfma16_bf16(a, b, c);
+}
+
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
   f32x2 v = {a, b};
   f16x2 r = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE; saturates under MODE.FP16_OVFL)

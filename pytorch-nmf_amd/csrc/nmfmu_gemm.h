@@ -51,19 +51,11 @@ struct GemmArgs {
   float beta;
   // implicit Toeplitz operand (OPS != kOpsPlanes): the operand's *_hi / *_lo point to a window table
   int tB, tR, tT, tLh;   // H is (B, R, Lh), T taps
-  // ragged channels shared out over the grid (EPI_RATIO with an implicit Hu operand): channels [rag_c0, rag_C) are not
-  // part of the GEMM (one or two rows would cost a whole tile row); every workgroup sums a 16-frame slice of them
-  // directly from the fp32 masters after its own tile (ragged_share below).  rag_w == nullptr: off.
-  const float* rag_w;    // (C, R, T)
-  const float* rag_h;    // (B, R, Lh)
+  // ragged channels inside the grid (EPI_RATIO with an implicit Hu operand): channels [rag_c0, rag_C), at most 16, are
+  // not part of the GEMM's own tiles (one or two rows would cost a whole tile row, i.e. a second scheduling round);
+  // every workgroup carries one extra 16 x 16 MFMA block for them (see nt_gemm_kernel).  rag_C <= rag_c0: off.
   int rag_c0, rag_C;
 };
-
-constexpr int kRagFrames = 16, kRagParts = 64;   // frames per slice, (r,t)-parts per slice: 4 x 64 = 256 threads
-// LDS floats of ragged_share: W row, R windows of H (pitch T + 16), the partial sums
-constexpr size_t ragged_share_lds_bytes(int R, int T) {
-  return ((((size_t)R * T + 3) & ~(size_t)3) + (size_t)R * (T + kRagFrames) + kRagParts * kRagFrames) * sizeof(float);
-}
 
 // which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
 enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3 };
@@ -88,112 +80,12 @@ struct GemmCfg {
   static constexpr int NPL = X3 ? 2 : 1;
   static constexpr int STAGE = NPL * (A_TILE + B_TILE);               // A planes then B planes
   static constexpr int LDS_BYTES = 2 * STAGE;
+  // ragged channels: 16 rows of the explicit operand per k-tile, one 2 KiB tile per plane and stage behind the stages
+  static constexpr int RAG_TILE = 16 * BK * 2, RAG_BYTES = 2 * NPL * RAG_TILE;
   static constexpr int PA = BM * 8 / SH::THREADS, PB = BN * 8 / SH::THREADS;   // DMA passes per plane tile
   static_assert(PA * SH::THREADS == BM * 8 && PB * SH::THREADS == BN * 8, "whole DMA passes");
   static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
 };
-
-// Ragged channels inside the reconstruction GEMM's grid (round 3).  S[c][(b,l)] = sum_{r,t} W[c][r][t] H[b][r][l-t]
-// (nmf.py:776-779) for the one or two channels beyond the last whole 128-row tile was a launch of its own (8.5 us of a
-// 52 us GEMM, latency-bound: 135 blocks).  Here workgroup w of the GEMM, once its tile is stored, takes slice w of the
-// ragged rows: 16 frames of one batch entry.  W[c][:][:] and the R windows H[b][r][l0-(T-1) .. l0+15] go to LDS (the
-// staging buffers are free), rounded like the GEMM's operand planes; thread (part, q) of 64 x 4 sums part's 1/64 of the
-// (r,t) range for frames 4q .. 4q+3 -- the window slides by one per tap, so a tap costs one W and one H read for four
-// FMAs; the 64 partials per frame are added in a fixed order and the frame gets the same elementwise epilogue as the
-// tile.  MODE 0: planes [c][(b,l)] (W half-step), 1: [(b,l)][c] (H half-step).  Needs blockDim.x == 256.
-template <int BETA, bool X3, int OPT, int MODE>
-__device__ __forceinline__ void ragged_share(const GemmArgs& a, float* lds) {
-  constexpr int FG = kRagFrames, NP = kRagParts;
-  const int tid = threadIdx.x;
-  const int R = a.tR, T = a.tT, Lh = a.tLh, L = Lh + T - 1, K = R * T;
-  const int HS = T + FG - 1, HSP = HS + 1;
-  float* wl = lds;
-  float* hs = wl + ((K + 3) & ~3);
-  float* red = hs + R * HSP;
-  const int lgroups = (L + FG - 1) / FG, ngroups = a.tB * lgroups;
-  const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-  const int per = (K + NP - 1) / NP;
-  const int part = tid >> 2, f0 = (tid & 3) * 4;
-  auto rnd = [](float v) -> float {   // what the GEMM's operand planes hold
-    if constexpr (X3) return v;
-    else if constexpr (OPT == kOpF16) return unpack_lo<kOpF16>(pack_img(v, 0.f, 1));
-    else return bf16_lo(pack_bf16(v, 0.f));
-  };
-  for (int g = wg; g < ngroups; g += nwg) {
-    const int b = g / lgroups, l0 = (g - b * lgroups) * FG;
-    for (int c = a.rag_c0; c < a.rag_C; ++c) {
-      // the target element of this thread's frame, fetched now so that its latency hides behind the summation
-      const int lx = l0 + tid;
-      const bool own = tid < FG && lx < L;
-      const size_t idx = MODE == 1 ? ((size_t)b * L + lx) * a.ldn + c : (size_t)c * a.ldn + (size_t)b * L + lx;
-      const float xval = own ? a.x[idx] : 0.f;
-      __syncthreads();   // everybody is done with the previous contents of the LDS (k loop / previous slice)
-      {
-        const float* wp = a.rag_w + (size_t)c * K;
-        for (int k0 = 0; k0 < K; k0 += 8 * 256) {   // eight loads in flight per thread, then the LDS writes
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = (k0 + u * 256 + tid < K) ? wp[k0 + u * 256 + tid] : 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (k0 + u * 256 + tid < K) wl[k0 + u * 256 + tid] = rnd(v[u]);
-        }
-      }
-      if (c == a.rag_c0) {
-        const int n = R * HS;
-        for (int i0 = 0; i0 < n; i0 += 8 * 256) {
-          float v[8];
-          int dst[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256 + tid, r = i / HS, q = i - r * HS, jx = l0 - (T - 1) + q;
-            dst[u] = i < n ? r * HSP + q : -1;
-            v[u] = (i < n && jx >= 0 && jx < Lh) ? a.rag_h[((size_t)b * R + r) * Lh + jx] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (dst[u] >= 0) hs[dst[u]] = rnd(v[u]);
-        }
-      }
-      __syncthreads();
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      {
-        int k = part * per;
-        const int kend = min(K, k + per);
-        while (k < kend) {
-          const int r = k / T, t0 = k - r * T, t1 = min(T, t0 + (kend - k));
-          const float* hq = hs + r * HSP + f0 + (T - 1);   // frame f0 + u, tap t: hq[u - t]
-          const float* wq = wl + r * T;
-          float h1 = hq[1 - t0], h2 = hq[2 - t0], h3 = hq[3 - t0];
-#pragma unroll 4
-          for (int t = t0; t < t1; ++t) {
-            const float h0 = hq[-t], w = wq[t];
-            s0 = fmaf(w, h0, s0), s1 = fmaf(w, h1, s1), s2 = fmaf(w, h2, s2), s3 = fmaf(w, h3, s3);
-            h3 = h2, h2 = h1, h1 = h0;
-          }
-          k += t1 - t0;
-        }
-      }
-      *reinterpret_cast<float4*>(red + part * FG + f0) = make_float4(s0, s1, s2, s3);
-      __syncthreads();
-      if (own) {
-        float S = (BETA != kEuc) ? kEps : 0.f;   // the GEMM seeds its accumulators the same way
-#pragma unroll 8
-        for (int p = 0; p < NP; ++p) S += red[p * FG + tid];
-        float gn, gp;
-        mu_elem<BETA>(S, xval, a.beta, gn, gp);
-        const uint32_t nh = pack_op<OPT>(gn, 0.f);
-        a.gn_hi[idx] = (uint16_t)nh;
-        if constexpr (X3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
-        if constexpr (BETA != kKL) {
-          const uint32_t ph = pack_op<OPT>(gp, 0.f);
-          a.gp_hi[idx] = (uint16_t)ph;
-          if constexpr (X3) a.gp_lo[idx] = (uint16_t)pack_bf16(gp - bf16_lo(ph), 0.f);
-        }
-      }
-    }
-  }
-}
 
 template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT>
 __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
@@ -225,6 +117,24 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   const int kt0 = zz * kt_per;
   const int ktiles = max(0, min(kt_per, ktiles_all - kt0));
   const size_t ldk = (size_t)a.k_pad * 2;  // bytes per operand row
+  // Ragged channels (round 3): the reconstruction GEMMs cover whole 128-channel tiles; the 1 .. 16 channels beyond them
+  // (the 1025th bin of a spectrogram) ride along as ONE extra 16 x 16 x 32 MFMA block per workgroup: the 128 frames of a
+  // tile column (resp. tile row) are shared out 16 apiece over eight workgroups that hold that implicit-operand tile in
+  // LDS anyway; 16 rows of the explicit operand (W planes, rows rag_c0 ..) come with every stage as a 2 KiB tile of their
+  // own.  Wave 0 issues 2 (6 with split operands) small MFMAs and 4 (8) fragment reads per k-tile and runs the same
+  // elementwise epilogue on its 16 x 16 block.  (A 16-frame direct-summation slice per workgroup after the tile was
+  // measured first: +8.4 us per GEMM -- as much as the separate nmfmu_conv_ragged_rows launch it replaced.)
+  constexpr bool RAGK = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256 && C::BM == 128 && C::BN == 128;
+  bool rag_on = false;
+  int rag_sub0 = 0;
+  const char* rag_src[C::NPL] = {};
+  if constexpr (RAGK) {
+    const int sub = OPS == kOpsBHu ? bm : bn;      // which 16 of the tile's 128 frames this workgroup takes
+    rag_on = a.rag_C > a.rag_c0 && sub < 8;
+    rag_sub0 = 16 * sub;
+    rag_src[0] = reinterpret_cast<const char*>(OPS == kOpsBHu ? a.a_hi : a.b_hi) + (size_t)a.rag_c0 * ldk;
+    if constexpr (X3) rag_src[1] = reinterpret_cast<const char*>(OPS == kOpsBHu ? a.a_lo : a.b_lo) + (size_t)a.rag_c0 * ldk;
+  }
 
   // DMA source pointers: thread handles chunk c = p*THREADS + tid of a tile: row = c >> 3, LDS slot = c & 7,
   // source slot = slot ^ ((row >> 1) & 7)
@@ -337,9 +247,21 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
           }
         }
       }
+    if constexpr (RAGK) {
+      // rows rag_c0 .. rag_c0 + 15 of the explicit operand: 128 chunks = one more pass of waves 0 and 1 (same source
+      // swizzle as pass 0 of the tiles: row = tid >> 3)
+      if (rag_on && wave < 2) {
+#pragma unroll
+        for (int pl = 0; pl < C::NPL; ++pl)
+          dma1k(rag_src[pl] + (size_t)(kt0 + kt) * (C::BK * 2), voff_exp[0],
+                lds_base + 2 * C::STAGE + (buf * C::NPL + pl) * C::RAG_TILE + wave * 1024);
+      }
+    }
     if constexpr (OPS != kOpsPlanes) toep_advance();
   };
   (void)TP; (void)KPP;
+  f32x4 racc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (RAGK && BETA != kEuc) racc = f32x4{kEps, kEps, kEps, kEps};
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -409,6 +331,30 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
           if constexpr (ks + 1 < 4 && nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
         });
       });
+    }
+    if constexpr (RAGK) {
+      if (rag_on && wave == 0) {
+        // 16 x 16 x 32 fragments: lane = (row r16, k-chunk g4 of the 32-wide step); the ragged tile is row-major with the
+        // tiles' XOR swizzle, the implicit operand's tile is chunk-major (no swizzle)
+        const int r16 = lane & 15, g4 = lane >> 4;
+        const char* rt = smem + 2 * C::STAGE + buf * C::NPL * C::RAG_TILE;
+        const char* it = sb + (TOP == 0 ? 0 : C::NPL * C::A_TILE);
+        constexpr int IT_PLANE = TOP == 0 ? C::A_TILE : C::B_TILE;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const int q = 4 * ks2 + g4;
+          const int eo = r16 * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
+          const int io = (q * TROWS + rag_sub0 + r16) * 16;
+          const u32x4 eh = ld16(rt + eo), ih = ld16(it + io);
+          // D[m][n] = sum_k A[m][k] B[n][k]: B_HU -> the ragged rows are rows of A; A_HU -> rows of B
+          if constexpr (X3) {
+            const u32x4 el = ld16(rt + C::RAG_TILE + eo), il = ld16(it + IT_PLANE + io);
+            racc = OPS == kOpsBHu ? mfma16_bf16(el, ih, racc) : mfma16_bf16(il, eh, racc);
+            racc = OPS == kOpsBHu ? mfma16_bf16(eh, il, racc) : mfma16_bf16(ih, el, racc);
+          }
+          racc = OPS == kOpsBHu ? mfma16_op<OPT>(eh, ih, racc) : mfma16_op<OPT>(ih, eh, racc);
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed (this wave's share of it)
     __syncthreads();
@@ -523,8 +469,31 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         }
       }
     }
-  if constexpr (EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && THREADS == 256) {
-    if (a.rag_w) ragged_share<BETA, X3, OPT, OPS == kOpsAHu ? 1 : 0>(a, reinterpret_cast<float*>(smem));
+  if constexpr (RAGK) {
+    if (rag_on && wave == 0) {
+      // C/D of the 16 x 16 block: column lane & 15, rows 4 (lane >> 4) + i
+      const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 4 * g4 + i;
+        const int c = a.rag_c0 + (OPS == kOpsBHu ? row : r16);
+        const size_t idx = OPS == kOpsBHu ? (size_t)c * a.ldn + bn * C::BN + rag_sub0 + r16
+                                          : (size_t)(bm * C::BM + rag_sub0 + row) * a.ldn + c;
+        if (c < a.rag_C) {
+          const float x = a.x[idx];
+          float gn, gp;
+          mu_elem<BETA>(racc[i], x, a.beta, gn, gp);
+          const uint32_t nh = pack_op<OPT>(gn, 0.f);
+          a.gn_hi[idx] = (uint16_t)nh;
+          if constexpr (X3) a.gn_lo[idx] = (uint16_t)pack_bf16(gn - bf16_lo(nh), 0.f);
+          if constexpr (BETA != kKL) {
+            const uint32_t ph = pack_op<OPT>(gp, 0.f);
+            a.gp_hi[idx] = (uint16_t)ph;
+            if constexpr (X3) a.gp_lo[idx] = (uint16_t)pack_bf16(gp - bf16_lo(ph), 0.f);
+          }
+        }
+      }
+    }
   }
   if constexpr (EPI == kEpiLoss) {
 #pragma unroll
@@ -545,7 +514,8 @@ template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3, SH>;
   constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
-  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES;
+  constexpr bool kRag = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256;
+  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
   auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT>;
@@ -558,9 +528,8 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
     *flag = true;
   }
   if (a.k_split > 1 && EPI != kEpiF32 && !(EPI == kEpiFold && a.tail_rows > 0)) return -3;
-  if (a.rag_w) {
-    if (!(EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256)) return -3;
-    if (ragged_share_lds_bytes(a.tR, a.tT) > (size_t)kLds) return -2;
+  if (a.rag_C > a.rag_c0) {   // eight workgroups share out a tile's 128 frames: the other dimension needs >= 8 tiles
+    if (!kRag || a.rag_C - a.rag_c0 > 16 || (OPS == kOpsBHu ? a.m_pad : a.n_pad) < 8 * 128) return -3;
   }
   const int grid_y = a.m_pad / C::BM + (EPI == kEpiFold ? a.tail_rows * (a.k_split - 1) : 0);
   hipLaunchKernelGGL(kern, dim3(a.n_pad / C::BN, grid_y, EPI == kEpiFold ? 1 : a.k_split), dim3(SH::THREADS), kLds, s, a);

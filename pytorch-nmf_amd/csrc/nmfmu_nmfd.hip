@@ -743,14 +743,13 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else {
     return NMFMU_ERR_ARG;
   }
-  if (d->rag_w || d->rag_h) {   // ragged channels summed inside this launch's grid
-    if (!d->rag_w || !d->rag_h || epilogue != NMFMU_EPI_RATIO || (d->ops != NMFMU_OPS_B_HU && d->ops != NMFMU_OPS_A_HU))
-      return NMFMU_ERR_ARG;
-    const int own = d->ops == NMFMU_OPS_B_HU ? d->m_pad : d->n_pad;    // channels the GEMM itself covers
+  if (d->rag_channels > 0) {   // ragged channels as an extra MFMA block inside this launch's grid
+    if (epilogue != NMFMU_EPI_RATIO || (d->ops != NMFMU_OPS_B_HU && d->ops != NMFMU_OPS_A_HU)) return NMFMU_ERR_ARG;
+    const int own = d->ops == NMFMU_OPS_B_HU ? d->m_pad : d->n_pad;    // channels the GEMM's own tiles cover
     if (d->rag_c0 != own || d->rag_channels <= d->rag_c0) return NMFMU_ERR_ARG;
     if (d->ops == NMFMU_OPS_A_HU && d->rag_channels > (d->n_ld ? d->n_ld : d->n_pad)) return NMFMU_ERR_ARG;
-    if (!nmfmu_gemm_ragged_supported(d->t_rank, d->t_taps, d->precision)) return NMFMU_ERR_UNSUPPORTED;
-    a.rag_w = d->rag_w, a.rag_h = d->rag_h, a.rag_c0 = d->rag_c0, a.rag_C = d->rag_channels;
+    if (!nmfmu_gemm_ragged_supported(d->ops, d->m_pad, d->n_pad, d->rag_channels - d->rag_c0)) return NMFMU_ERR_UNSUPPORTED;
+    a.rag_c0 = d->rag_c0, a.rag_C = d->rag_channels;
   }
   if (d->tile_rows != 0 && d->tile_rows != 128) return NMFMU_ERR_UNSUPPORTED;   // (the 256 x 256 tile of ABI 3 is gone)
   a.ldn = d->n_ld ? d->n_ld : d->n_pad;
@@ -892,10 +891,12 @@ int nmfmu_conv_ragged_supported(int rank, int taps) {
 
 int nmfmu_conv_ragged_blocks(int batch, int lh, int taps) { return batch * ((lh + taps - 1 + 63) / 64); }
 
-int nmfmu_gemm_ragged_supported(int rank, int taps, int precision) {
-  if (rank <= 0 || taps <= 0) return 0;
-  const size_t lds = precision == NMFMU_PREC_BF16X3 ? GemmCfg<true, GemmSmall>::LDS_BYTES : GemmCfg<false, GemmSmall>::LDS_BYTES;
-  return ragged_share_lds_bytes(rank, taps) <= lds;
+int nmfmu_gemm_ragged_supported(int ops, int m_pad, int n_pad, int extra) {
+  // eight workgroups share out the 128 frames of an implicit-operand tile: >= 8 tiles along the explicit operand
+  if (extra < 1 || extra > 16) return 0;
+  if (ops == NMFMU_OPS_B_HU) return m_pad >= 8 * 128 && m_pad % 128 == 0;
+  if (ops == NMFMU_OPS_A_HU) return n_pad >= 8 * 128 && n_pad % 128 == 0;
+  return 0;
 }
 
 int nmfmu_conv_ragged_rows(const float* w, int channels, int rank, int taps, const float* h, int batch, int lh, int c0,

@@ -51,8 +51,7 @@ class GemmDesc(C.Structure):
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
-                ('tail_rows', C.c_int32), ('rag_w', C.c_void_p), ('rag_h', C.c_void_p), ('rag_c0', C.c_int32),
-                ('rag_channels', C.c_int32)]
+                ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32)]
 
 
 ABI_VERSION = 5   # include/nmfmu.h: NMFMU_ABI_VERSION
@@ -141,6 +140,7 @@ SIGNATURES = {
     'nmfmu_conv_tables_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_ragged_supported': (C.c_int, [C.c_int, C.c_int]),
     'nmfmu_conv_ragged_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'nmfmu_gemm_ragged_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_ragged_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -143,6 +143,13 @@ class ConvMU:
         self.ragged = (own_loop and nd == 1 and self.c_main >= 128 and 0 < Cc - self.c_main <= 8 and
                        bool(self.lib.nmfmu_conv_ragged_supported(R, T)) and
                        os.environ.get('TORCHNMF_AMD_NMFD_RAGGED', '1') != '0')
+        # ... or ride inside the reconstruction GEMMs' own grids as one extra 16 x 16 MFMA block per workgroup
+        # (nmfmu_gemm_desc.rag_c0 / rag_channels: no launch of their own; needs >= 1024 whole channels and frames; '0'
+        # keeps the separate nmfmu_conv_ragged_rows launches)
+        self.ragged_in_grid = (self.ragged and self.implicit and
+                               bool(self.lib.nmfmu_gemm_ragged_supported(_capi.OPS_B_HU, self.c_main, blp, Cc - self.c_main)) and
+                               bool(self.lib.nmfmu_gemm_ragged_supported(_capi.OPS_A_HU, blp, self.c_main, Cc - self.c_main)) and
+                               os.environ.get('TORCHNMF_AMD_NMFD_RAGGED_IN_GRID', '1') != '0')
         rz = self.ragged                        # the GEMM then leaves the padding rows / columns of the ratio planes alone
         self.gn = _Planes(cp, blp, x3, dev, rz)     # W half-step ratio, [c][(b,l)]
         self.gnt = _Planes(blp, cp, x3, dev, rz)    # H half-step ratio, [(b,l)][c]
@@ -208,7 +215,7 @@ class ConvMU:
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
-              n_rows=None, k_len=0, k_split=0, tail_rows=0, tag=None):
+              n_rows=None, k_len=0, k_split=0, tail_rows=0, ragged=False, tag=None):
         """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
         output planes keep their leading dimension.  tag: name of the launch for an attached KernelTimer (bench.py)."""
         assert a.cols_pad == b.cols_pad
@@ -223,7 +230,7 @@ class ConvMU:
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split,
-                           tail_rows)
+                           tail_rows, self.c_main if ragged else 0, self.C if ragged else 0)
         timer = getattr(self, 'timer', None) if tag else None
         if timer is not None:
             timer.mark(tag + '<')
@@ -309,8 +316,10 @@ class ConvMU:
         """Reconstruction + ratio planes of the W half-step (nmf.py:61-74 on Wm Hu^T): the GEMM over the channels that
         fill whole tiles, the ragged ones by direct summation."""
         if self.ragged:
-            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_main, tag='recon_w')
-            self._ragged(0, self.x_w, self.gn, self.gp)
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_main,
+                       ragged=self.ragged_in_grid, tag='recon_w')
+            if not self.ragged_in_grid:
+                self._ragged(0, self.x_w, self.gn, self.gp)
         else:
             self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, tag='recon_w')
 
@@ -325,8 +334,10 @@ class ConvMU:
     def h_step(self):
         """nmf.py:380-391 for the conv1d model (uses the freshly updated W)."""
         if self.ragged:
-            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_main, tag='recon_h')
-            self._ragged(1, self.x_h, self.gnt, self.gpt)
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_main,
+                       ragged=self.ragged_in_grid, tag='recon_h')
+            if not self.ragged_in_grid:
+                self._ragged(1, self.x_h, self.gnt, self.gpt)
         else:
             self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, tag='recon_h')
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32

@@ -786,6 +786,49 @@ def test_nmfd_ragged_channels(dev, shape, beta, prec, monkeypatch):
         assert rel_err(res['1'][0][cm:], Wr[cm:]) < TOL
 
 
+@pytest.mark.parametrize('shape', [(1, 1025, 304, 4, 8), (2, 1026, 200, 3, 24), (1, 1025, 520, 3, 136), (1, 1032, 328, 2, 40),
+                                   (1, 1153, 648, 2, 400)])
+@pytest.mark.parametrize('beta,prec', [(1, 'f16'), (1, 'bf16'), (1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (0, 'bf16')])
+def test_nmfd_ragged_channels_inside_the_gemm_grid(dev, shape, beta, prec, monkeypatch):
+    """The 1 .. 8 channels beyond the last whole 128-channel tile ride inside the reconstruction GEMMs' grids
+    (nmfmu_gemm_desc.rag_c0 / rag_channels: one extra 16 x 16 x 32 MFMA block per workgroup, eight workgroups sharing out
+    the 128 frames of an implicit-operand tile) instead of in nmfmu_conv_ragged_rows launches.  Same rounded operands,
+    MFMA instead of fp32 FMA summation: must agree with the separate-launch path and with the oracle -- one, two and
+    eight ragged channels, eight and nine channel tiles (the ninth takes no part), batches, frame counts that leave
+    padding columns, every beta branch and operand mode, both half-steps."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    if prec == 'f16' and T < 128:
+        pytest.skip("NMFD 'f16' needs >= 128 taps")
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_RAGGED_IN_GRID', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, 0.01, 0.02, precision=prec)
+        assert eng.ragged and eng.ragged_in_grid == (mode == '1')
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), eng.divergence())
+    single = prec != 'bf16x3'
+    tol = 2e-5 if single else 2e-6      # single plane: a ratio that rounds the other way moves an element by 2^-8 / 2^-11
+    assert rel_err(res['0'][0], res['1'][0]) < tol and rel_err(res['0'][1], res['1'][1]) < tol
+    cm = (Cc // 128) * 128
+    assert rel_err(res['0'][0][cm:], res['1'][0][cm:]) < (5e-3 if single else 1e-5)
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5)
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
+    bar = TOL if prec == 'bf16x3' else 1e-4 if prec == 'f16' else 3e-3
+    assert rel_err(res['1'][0], Wr) < bar and rel_err(res['1'][1], Hr) < bar
+    assert rel_err(res['1'][0][cm:], Wr[cm:]) < (bar if prec != 'bf16' else 1e-2)
+    record('nmfd_ragged_in_grid', shape=list(shape), beta=beta, precision=prec, rel_W=rel_err(res['1'][0], Wr),
+           rel_H=rel_err(res['1'][1], Hr), rel_W_ragged_rows=rel_err(res['1'][0][cm:], Wr[cm:]))
+
+
 @pytest.mark.parametrize('shape', [(1, 40, 520, 3, 136), (2, 33, 335, 2, 130), (1, 129, 600, 2, 400), (3, 70, 300, 5, 128)])
 @pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
 def test_nmfd_rank_sums_ride_in_their_producers(dev, shape, prec, monkeypatch):

@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_static_queries():
     lib = _capi.load()
-    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 4
+    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 5
     assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
     assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
     assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED
@@ -166,7 +166,14 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
-    assert [f[0] for f in d._fields_][-5:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows']
+    assert [f[0] for f in d._fields_][-7:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels']
+    # ragged channels inside the GEMM grid: eight workgroups share out a tile's frames -> >= 8 tiles of the explicit operand
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 1) == 1           # configs[3], W half-step
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_A_HU, 8192, 1024, 1) == 1           # ... H half-step
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 896, 8192, 1) == 0
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_A_HU, 8192, 896, 1) == 0
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 17) == 0 and lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 0) == 0
+    assert lib.nmfmu_gemm_ragged_supported(O.OPS_PLANES, 1024, 8192, 1) == 0 and lib.nmfmu_gemm_ragged_supported(O.OPS_B_HUT, 1024, 8192, 1) == 0
     # argument checking happens before any device work
     assert lib.nmfmu_gemm(None, 0, None) == _capi.ERR_ARG
     assert lib.nmfmu_conv_ragged_rows(None, 1, 1, 1, None, 1, 1, 0, 0, 1.0, 0, None, 0, None, None, None, None, None,

@@ -198,3 +198,64 @@ def test_tail_round_split_grid_mapping_and_gather(B, R, T, Lh, C, tail_rows, k_s
     for (b, r, jx) in [(0, 0, 0), (B - 1, R - 1, Lh - 1), (0, R - 1, Lh // 2)]:
         direct = sum(Y[r * T + t, b * L + jx + t] for t in range(T))
         assert gather(summed, tiles_n, b, r, jx, T, L) == pytest.approx(direct, rel=1e-10)
+
+
+@pytest.mark.parametrize('ops', ['B_HU', 'A_HU'])
+def test_ragged_channels_as_an_extra_mfma_block(ops):
+    """Round 3: ragged channels inside the reconstruction GEMM's grid (nmfmu_gemm.h, RAGK).  Per k-tile a 16-row tile of
+    the explicit operand (rows rag_c0 .. rag_c0 + 15 of the W planes) lands in LDS row-major with the tiles' source-side
+    XOR swizzle (slot s of row r holds chunk s ^ ((r >> 1) & 7)); the implicit operand's tile is chunk-major
+    [8 chunks][128 rows].  Wave 0 reads 16 x 16 x 32 fragments -- lane = (row lane & 15, chunk 4 ks2 + (lane >> 4)) -- and
+    workgroup (bm, bn) takes frames 16 sub .. 16 sub + 15 of its implicit tile (sub = bm for B_HU, bn for A_HU, < 8).
+    Emulated with the kernel's address arithmetic and the MFMA's documented lane mapping: the eight workgroups of a tile
+    column / row cover its 128 frames exactly once and every output equals the plain contraction."""
+    rng = np.random.default_rng(5)
+    k_tiles, tiles_other = 3, 9                       # contraction 192; nine tiles along the explicit operand (eight take part)
+    K = 64 * k_tiles
+    E = rng.integers(-4, 5, size=(16, K)).astype(np.float64)          # explicit rows rag_c0 .. +15 (only some are real channels)
+    n_imp_tiles = 2
+    I = rng.integers(-4, 5, size=(128 * n_imp_tiles, K)).astype(np.float64)   # implicit operand rows (b,l)
+    want = E @ I.T                                                    # [16 channels][(b,l)]
+    got = np.full_like(want, np.nan)
+    hits = np.zeros_like(want, dtype=int)
+    for it in range(n_imp_tiles):                     # tile column (B_HU: bn) resp. tile row (A_HU: bm) of the implicit operand
+        for other in range(tiles_other):              # B_HU: bm, A_HU: bn
+            sub = other
+            if sub >= 8:
+                continue
+            acc = np.zeros((16, 16))                  # D[row][col] of the 16 x 16 block
+            for kt in range(k_tiles):
+                # LDS images of this stage
+                rag = np.zeros((16, 8, 8))            # [row][slot][8 elements]
+                for tid in range(128):                # waves 0, 1: one dwordx4 each, LDS offset = tid * 16 (linear)
+                    row, slot = tid >> 3, tid & 7
+                    sslot = slot ^ ((row >> 1) & 7)
+                    rag[row, slot] = E[row, kt * 64 + sslot * 8: kt * 64 + sslot * 8 + 8]
+                imp = np.zeros((8, 128, 8))           # chunk-major [chunk][row][8 elements]
+                for q in range(8):
+                    imp[q] = I[it * 128:(it + 1) * 128, kt * 64 + q * 8: kt * 64 + q * 8 + 8]
+                for ks2 in range(2):
+                    Af = np.zeros((16, 32)); Bf = np.zeros((16, 32))
+                    for lane in range(64):
+                        r16, g4 = lane & 15, lane >> 4
+                        q = 4 * ks2 + g4
+                        eo = r16 * 128 + ((q ^ ((r16 >> 1) & 7)) << 4)            # byte offset in the ragged tile
+                        e = rag[eo // 128, (eo % 128) // 16]
+                        io = (q * 128 + 16 * sub + r16) * 16                      # byte offset in the chunk-major tile
+                        i = imp[io // (128 * 16), (io // 16) % 128]
+                        a, b = (e, i) if ops == 'B_HU' else (i, e)
+                        Af[r16, 8 * g4: 8 * g4 + 8] = a                           # A / B lane = (row lane & 15, k = 8 (lane >> 4) + i)
+                        Bf[r16, 8 * g4: 8 * g4 + 8] = b
+                    acc += Af @ Bf.T
+            for lane in range(64):                    # C / D lane = (column lane & 15, rows 4 (lane >> 4) + i)
+                r16, g4 = lane & 15, lane >> 4
+                for i in range(4):
+                    row = 4 * g4 + i
+                    if ops == 'B_HU':                 # rows = channels, columns = frames
+                        c, frame = row, it * 128 + 16 * sub + r16
+                    else:                             # rows = frames, columns = channels
+                        c, frame = r16, it * 128 + 16 * sub + row
+                    got[c, frame] = acc[row, r16]
+                    hits[c, frame] += 1
+    assert (hits == 1).all()
+    np.testing.assert_array_equal(got, want)
