@@ -36,7 +36,8 @@ extern "C" {
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
                                   NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status;
-                               5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported */
+                               5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported,
+                                  nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -364,6 +365,19 @@ int nmfmu_conv_fold_parts_apply_h_tail(float* h, int batch, int rank, int lh, in
                                        const float* p_den, const float* kl_den, const float* kl_wcol, int c_tiles,
                                        int rp_pad, float* hsum_part, int bl_pad, float l1, float l2, float gamma, int m_pad,
                                        int tail_rows, int k_split, void* stream);
+/* ... and rewriting the window tables of the new H in the same launch (ABI 5; replaces the nmfmu_conv_tables call that
+ * would follow).  A table entry spans eight consecutive j, so blocks recompute a halo of their neighbours' elements and
+ * need the OLD values while the neighbours overwrite theirs: h_old is a copy of h that this launch only reads, h_next a
+ * second buffer that receives the new values beside h itself; the caller swaps the two every iteration (and refreshes
+ * h_old from h whenever h was changed by anything else).  The tables must have been built by nmfmu_conv_tables[_f16]
+ * once: entries whose windows lie outside [0, lh) are never touched.  hsum_part holds
+ * nmfmu_fold_hsum_parts_tables(batch, lh) partial sums per rank.  rev_lo / fwd_lo: NMFMU_PREC_BF16X3 only. */
+int nmfmu_fold_hsum_parts_tables(int batch, int lh);
+int nmfmu_conv_fold_parts_apply_h_tables(float* h, const float* h_old, float* h_next, int batch, int rank, int lh, int taps,
+                                         const float* p_num, const float* p_den, const float* kl_den, const float* kl_wcol,
+                                         int c_tiles, int rp_pad, float* hsum_part, int bl_pad, float l1, float l2,
+                                         float gamma, int m_pad, int tail_rows, int k_split, int precision, void* rev_hi,
+                                         void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream);
 size_t nmfmu_fold_part_bytes(int m_pad, int n_pad);
 int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps);
 int nmfmu_conv_fold_parts_apply_h(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,

@@ -358,6 +358,23 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
 // tiles of Y, seg = 2 * (second r of the tile row) + (second b of the tile column), dd = (n - m) - 128 (tn - tm) + 127.
 // A (b, r, j) collects one value per tile its diagonal crosses: <= ceil(T/128)+1 tile rows x <= 2 tile columns, always
 // in the same order.  One thread per j: consecutive threads read consecutive dd.
+//
+// TAB (round 3): the same launch also rewrites the window tables of the new H (nmfmu_conv_tables: a launch of its own
+// before, 5 us of a 250 us iteration).  A table entry spans eight consecutive j, so a block owns kTabOwn = 242 positions
+// and recomputes a halo of 7 on either side (the update is cheap; 6 % more blocks).  Recomputing a neighbour's element
+// needs its OLD value while the neighbour overwrites it: the old values are therefore read from a shadow copy of H that
+// nobody writes during this launch, and the new ones go to the master and to a second shadow, the two shadows swapping
+// roles every iteration (tb.h_old / tb.h_next).  Positions run over [-7, Lh + 6]: the entries whose windows reach into
+// [0, Lh) -- all others are zero for ever and are written once by nmfmu_conv_tables.
+struct FoldTables {
+  const float* h_old;
+  float* h_next;
+  u32x4 *rev_hi, *rev_lo, *fwd_hi, *fwd_lo;
+  int f16;
+};
+constexpr int kTabOwn = 256 - 14;
+
+template <bool TAB>
 __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __restrict__ H, int B, int R, int Lh, int T,
                                                                       const float* __restrict__ pnum,
                                                                       const float* __restrict__ pden,
@@ -365,14 +382,16 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
                                                                       const float* __restrict__ kl_wcol, int c_tiles,
                                                                       int rp_pad, float* __restrict__ hsum_part,
                                                                       int tiles_n, float l1, float l2, float gamma,
-                                                                      int tail_tm0, int tail_split, size_t slab) {
+                                                                      int tail_tm0, int tail_split, size_t slab,
+                                                                      FoldTables tb) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
   const int L = Lh + T - 1;
-  const int jblocks = (Lh + 255) / 256;
+  const int jblocks = TAB ? (Lh + 14 + kTabOwn - 1) / kTabOwn : (Lh + 255) / 256;
   const int jb = blockIdx.x % jblocks, r = (blockIdx.x / jblocks) % R, b = blockIdx.x / (jblocks * R);
-  const int jx = jb * 256 + tid;
-  const bool valid = jx < Lh;
+  const int jx = TAB ? jb * kTabOwn + tid - 14 : jb * 256 + tid;
+  const bool valid = jx >= 0 && jx < Lh;
+  const bool owned = !TAB || (tid >= 7 && tid < 7 + kTabOwn);
   auto block_sum = [&](float v) {   // fixed-order tree: identical bits in every block that sums the same values
     red[tid] = v;
     __syncthreads();
@@ -422,12 +441,51 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
     }
     if (kl) pos = den;
     const size_t i = ((size_t)b * R + r) * Lh + jx;
-    hv = mu_update(H[i], neg, pos, kl, l1, l2, gamma);
-    H[i] = hv;
+    hv = mu_update(TAB ? tb.h_old[i] : H[i], neg, pos, kl, l1, l2, gamma);
+    if (owned) {
+      H[i] = hv;
+      if constexpr (TAB) tb.h_next[i] = hv;
+    }
   }
   if (hsum_part) {   // partial sum_{b,j} H[b][r][j] of the NEW H for the next W half-step: [r][b * jblocks + jb]
-    const float tot = block_sum(hv);
+    const float tot = block_sum(owned ? hv : 0.f);
     if (tid == 0) hsum_part[(size_t)r * (B * jblocks) + b * jblocks + jb] = tot;
+  }
+  if constexpr (TAB) {
+    // window tables (layout: nmfmu_conv_tables): entry 1 + (b R + r) JJ + j + (T - 1) holds {H[j], H[j-1], .., H[j-7]}
+    // (reversed) resp. {H[j], .., H[j+7]} (forward), zeros outside [0, Lh)
+    red[tid] = hv;                     // (0 where not valid; every block_sum ended with a barrier)
+    __syncthreads();
+    if (owned) {
+      const int JJ = Lh + 2 * T - 2;
+      const size_t e = 1 + ((size_t)b * R + r) * JJ + (size_t)(jx + T - 1);
+      if (jx <= Lh + 6) {              // jx >= -7 always; reversed windows with j in [0, Lh + 6]
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = red[tid - q];
+        u32x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t h = pack_img(v[2 * q], v[2 * q + 1], tb.f16);
+          hi[q] = h, lo[q] = pack_bf16(v[2 * q] - bf16_lo(h), v[2 * q + 1] - bf16_hi(h));
+        }
+        if (jx >= 0) {
+          tb.rev_hi[e] = hi;
+          if (tb.rev_lo) tb.rev_lo[e] = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = red[tid + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t h = pack_img(v[2 * q], v[2 * q + 1], tb.f16);
+          hi[q] = h, lo[q] = pack_bf16(v[2 * q] - bf16_lo(h), v[2 * q + 1] - bf16_hi(h));
+        }
+        if (jx <= Lh - 1) {            // forward windows with j in [-7, Lh - 1]
+          tb.fwd_hi[e] = hi;
+          if (tb.fwd_lo) tb.fwd_lo[e] = lo;
+        }
+      }
+    }
   }
 }
 
@@ -935,11 +993,12 @@ int nmfmu_fold_parts_supported(int batch, int rank, int lh, int taps) {
 
 static int fold_parts_apply(float* h, int batch, int rank, int lh, int taps, const float* p_num, const float* p_den,
                             const float* kl_den, const float* kl_wcol, int c_tiles, int rp_pad, float* hsum_part, int bl_pad,
-                            float l1, float l2, float gamma, void* stream, int m_pad = 0, int tail_rows = 0, int k_split = 1) {
+                            float l1, float l2, float gamma, void* stream, int m_pad = 0, int tail_rows = 0, int k_split = 1,
+                            const FoldTables* tb = nullptr) {
   if (!h || !p_num || (!p_den && !kl_den && !kl_wcol) || bl_pad % 128 || bl_pad < batch * (lh + taps - 1)) return NMFMU_ERR_ARG;
   if (kl_wcol && (c_tiles <= 0 || rp_pad < rank * taps)) return NMFMU_ERR_ARG;
   if (!nmfmu_fold_parts_supported(batch, rank, lh, taps)) return NMFMU_ERR_UNSUPPORTED;
-  const int grid = batch * rank * ((lh + 255) / 256);
+  const int grid = batch * rank * (tb ? (lh + 14 + kTabOwn - 1) / kTabOwn : (lh + 255) / 256);
   // the GEMM's tail-round split: tile rows >= m_pad / 128 - tail_rows come as k_split partial slabs
   int tail_tm0 = 1 << 30;
   size_t slab = 0;
@@ -948,8 +1007,14 @@ static int fold_parts_apply(float* h, int batch, int rank, int lh, int taps, con
     tail_tm0 = m_pad / 128 - tail_rows;
     slab = nmfmu_fold_part_bytes(m_pad, bl_pad) / sizeof(float);
   }
-  hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps, p_num,
-                     p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma, tail_tm0, k_split, slab);
+  if (tb)
+    hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel<true>, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                       p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma, tail_tm0,
+                       k_split, slab, *tb);
+  else
+    hipLaunchKernelGGL(conv_fold_parts_apply_h_kernel<false>, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh, taps,
+                       p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad / 128, l1, l2, gamma, tail_tm0,
+                       k_split, slab, FoldTables{});
   return (int)hipGetLastError();
 }
 
@@ -966,6 +1031,23 @@ int nmfmu_conv_fold_parts_apply_h_tail(float* h, int batch, int rank, int lh, in
                                        int tail_rows, int k_split, void* stream) {
   return fold_parts_apply(h, batch, rank, lh, taps, p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad, l1, l2,
                           gamma, stream, m_pad, tail_rows, k_split);
+}
+
+int nmfmu_fold_hsum_parts_tables(int batch, int lh) { return batch * ((lh + 14 + kTabOwn - 1) / kTabOwn); }
+
+int nmfmu_conv_fold_parts_apply_h_tables(float* h, const float* h_old, float* h_next, int batch, int rank, int lh, int taps,
+                                         const float* p_num, const float* p_den, const float* kl_den, const float* kl_wcol,
+                                         int c_tiles, int rp_pad, float* hsum_part, int bl_pad, float l1, float l2,
+                                         float gamma, int m_pad, int tail_rows, int k_split, int precision, void* rev_hi,
+                                         void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream) {
+  if (!h_old || !h_next || h_old == h_next || h_old == h || h_next == h || !rev_hi || !fwd_hi) return NMFMU_ERR_ARG;
+  if (taps % 8 || (lh + taps - 1) % 8) return NMFMU_ERR_ARG;                       // (what nmfmu_conv_tables asks for)
+  const bool x3 = precision == NMFMU_PREC_BF16X3;
+  if (precision != NMFMU_PREC_BF16 && precision != NMFMU_PREC_F16 && !x3) return NMFMU_ERR_UNSUPPORTED;
+  if (x3 != (rev_lo != nullptr) || x3 != (fwd_lo != nullptr)) return NMFMU_ERR_ARG;
+  const FoldTables tb{h_old, h_next, (u32x4*)rev_hi, (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo, precision == NMFMU_PREC_F16};
+  return fold_parts_apply(h, batch, rank, lh, taps, p_num, p_den, kl_den, kl_wcol, c_tiles, rp_pad, hsum_part, bl_pad, l1, l2,
+                          gamma, stream, m_pad, tail_rows, k_split, &tb);
 }
 
 int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, int taps, const float* p_num,

@@ -155,6 +155,12 @@ SIGNATURES = {
     'nmfmu_conv_fold_parts_apply_h_tail': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                      C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'nmfmu_fold_hsum_parts_tables': (C.c_int, [C.c_int, C.c_int]),
+    'nmfmu_conv_fold_parts_apply_h_tables': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                       C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p]),
     'nmfmu_fold_part_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'nmfmu_fold_parts_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'nmfmu_conv_fold_parts_apply_h': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -190,8 +190,18 @@ class ConvMU:
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
         # beta == 1 on the fold-parts path: the rank sums ride in the kernels that produce / consume them
         self.fused_sums = (self.kl and self.fold_parts and os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
+        # ... and the H update rewrites the window tables of the new H itself (no nmfmu_conv_tables launch per iteration).
+        # Its blocks recompute a halo of their neighbours' elements, for which they need the old values while the
+        # neighbours overwrite theirs: two shadow copies of H alternate as "old, read-only" and "new" (see
+        # nmfmu_conv_fold_parts_apply_h_tables); _pack_h -- the path every outside change of H takes -- refreshes them.
+        self.fused_tables = (self.fused_sums and self.implicit and
+                             os.environ.get('TORCHNMF_AMD_NMFD_FUSED_TABLES', '1') != '0')
+        self._h_shadow, self._hs, self._hs_valid = None, 0, False
+        if self.fused_tables:
+            self._h_shadow = [torch.empty_like(H), torch.empty_like(H)]
         if self.fused_sums:
-            self.n_hparts = self.lib.nmfmu_fold_hsum_parts(B, Lh)
+            self.n_hparts = (self.lib.nmfmu_fold_hsum_parts_tables(B, Lh) if self.fused_tables else
+                             self.lib.nmfmu_fold_hsum_parts(B, Lh))
             self.hpart = torch.zeros(R * self.n_hparts, dtype=torch.float32, device=dev)
             self.wcol = torch.zeros((cp // 64) * (rpp // 64) * 2, dtype=torch.float32, device=dev)
         self._h_parts_valid = False
@@ -288,6 +298,9 @@ class ConvMU:
                                                        _ptr(self.hut.lo), _stream()), 'nmfmu_conv_tables')
         else:
             self._unfold()
+        if self.fused_tables:
+            self._h_shadow[self._hs].copy_(self.H)
+            self._hs_valid = True
         if sums:
             self._rank_sums(self.H, self.B, self.Lh, self.sum_h)
             self._h_parts_valid = False
@@ -347,6 +360,16 @@ class ConvMU:
         if not self.kl:
             self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc, **tail)
         kl_den = self.sum_w.data_ptr() if self.kl else None
+        if self.fused_tables and self._hs_valid:
+            old, new = self._h_shadow[self._hs], self._h_shadow[self._hs ^ 1]
+            _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_tables(
+                self.H.data_ptr(), old.data_ptr(), new.data_ptr(), self.B, self.R, self.Lh, self.T, self.y.data_ptr(), None,
+                None, self.wcol.data_ptr(), self.c_pad // 64, self.rp_pad, self.hpart.data_ptr(), self.bl_pad, self.l1,
+                self.l2, self.gamma, self.rp_pad, self.h_tail_rows, self.h_tail_split, self.precision, _ptr(self.hu.hi),
+                _ptr(self.hu.lo), _ptr(self.hut.hi), _ptr(self.hut.lo), _stream()), 'nmfmu_conv_fold_parts_apply_h_tables')
+            self._hs ^= 1
+            self._h_parts_valid = True
+            return
         if self.fused_sums:
             _capi.check(self.lib.nmfmu_conv_fold_parts_apply_h_tail(
                 self.H.data_ptr(), self.B, self.R, self.Lh, self.T, self.y.data_ptr(), None, None, self.wcol.data_ptr(),

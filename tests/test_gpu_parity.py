@@ -829,6 +829,46 @@ def test_nmfd_ragged_channels_inside_the_gemm_grid(dev, shape, beta, prec, monke
            rel_H=rel_err(res['1'][1], Hr), rel_W_ragged_rows=rel_err(res['1'][0][cm:], Wr[cm:]))
 
 
+@pytest.mark.parametrize('shape', [(2, 40, 520, 3, 136), (1, 129, 1208, 2, 400), (1, 33, 392, 2, 128), (3, 16, 1096, 1, 136)])
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16', 'f16'])
+def test_nmfd_h_update_rewrites_the_window_tables(dev, shape, prec, monkeypatch):
+    """beta == 1 on implicit operands: the H update's launch also rewrites the window tables of the new H
+    (nmfmu_conv_fold_parts_apply_h_tables) instead of a nmfmu_conv_tables launch per iteration.  Blocks own 242 positions
+    and recompute a 7-wide halo from a read-only shadow of the old H (two shadows alternate).  After every iteration the
+    tables must equal, byte for byte, what nmfmu_conv_tables builds from the new H; the factors must agree with the
+    separate-launch path (only the partition of the rank sums differs).  One to five blocks per
+    (batch, rank) row, batches, an H changed from outside between iterations (refresh_images)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, L, R, T = shape
+    g = torch.Generator().manual_seed(sum(shape) + 2)
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_FUSED_TABLES', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, 1, 0.01, 0.02, precision=prec)
+        assert eng.fused_sums and eng.fused_tables == (mode == '1')
+        for it in range(3):
+            eng.w_step()
+            eng.h_step()
+            if mode == '1':
+                got = [eng.hu.hi.clone(), eng.hut.hi.clone()] + ([eng.hu.lo.clone(), eng.hut.lo.clone()] if prec == 'bf16x3' else [])
+                eng._pack_h(sums=False)          # the standalone kernel on the same H
+                want = [eng.hu.hi, eng.hut.hi] + ([eng.hu.lo, eng.hut.lo] if prec == 'bf16x3' else [])
+                for a_, b_ in zip(got, want):
+                    assert torch.equal(a_, b_), f'table bytes differ after iteration {it}'
+            if it == 1:                          # H changed from outside: the images and the shadow must follow
+                H.mul_(1.25)
+                eng.refresh_images()
+        res[mode] = (W.cpu(), H.cpu(), eng.divergence())
+    tol = 3e-6 if prec == 'bf16x3' else 3e-5
+    assert rel_err(res['0'][0], res['1'][0]) < tol and rel_err(res['0'][1], res['1'][1]) < tol
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-5)
+
+
 @pytest.mark.parametrize('shape', [(1, 40, 520, 3, 136), (2, 33, 335, 2, 130), (1, 129, 600, 2, 400), (3, 70, 300, 5, 128)])
 @pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
 def test_nmfd_rank_sums_ride_in_their_producers(dev, shape, prec, monkeypatch):
