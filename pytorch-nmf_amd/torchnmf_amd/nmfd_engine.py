@@ -395,6 +395,15 @@ class ConvMU:
                         'nmfmu_convnd_fold_apply_h')
         self._pack_h()
 
+    def left_f16_range(self) -> bool:
+        """'f16' only: the range gate of 'auto' / the constructor looks at the initial data.  A factor value
+        that grows beyond fp16's largest finite number during the fit is clamped to 65504 in the operand planes / window
+        tables, and the updates stop following the reference.  fit() asks at its loss checkpoints (one more host sync
+        there, two small reductions) and warns."""
+        if self.precision != _capi.PREC_F16:
+            return False
+        return bool(torch.maximum(self.W.max(), self.H.max()).item() > 65504.0)
+
     def divergence(self) -> float:
         """beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401).  One host sync."""
         self._gemm(self.wm, self.hu, _capi.EPI_LOSS, x=self.x_w, out=self.loss_part, m_valid=self.C,

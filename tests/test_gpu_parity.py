@@ -351,6 +351,32 @@ def test_f16_factor_leaving_the_range_is_reported(dev):
     assert any("fp16's range" in str(w.message) for w in rec), [str(w.message) for w in rec]
 
 
+def test_nmfd_f16_factor_leaving_the_range_is_reported(dev):
+    """The same report for NMFD in 'f16' (its planes and window tables clamp at 65504): fit() warns at a loss checkpoint."""
+    import warnings
+    from torchnmf_amd.nmf import NMFD
+    from torchnmf_amd.nmfd_engine import ConvMU
+    g = torch.Generator().manual_seed(6)
+    B, Cc, L, R, T = 1, 24, 328, 2, 136
+    V = torch.rand(B, Cc, L, generator=g) * 2.0e4
+    W0 = torch.rand(Cc, R, T, generator=g) + 0.5
+    H0 = (torch.rand(B, R, L - T + 1, generator=g) + 0.5) * 1e-3     # W <- W * (V / S (*) H) / sum(H): far beyond 65504
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = ConvMU(V.to(dev), W, H, 1, precision='f16')
+    assert not eng.left_f16_range()
+    eng.w_step()
+    assert float(W.max()) > 65504.0 and eng.left_f16_range()
+    W2, H2 = W0.clone().to(dev), (H0 * 1e3).to(dev)
+    eng2 = ConvMU((V / 2.0e4).to(dev), W2, H2, 1, precision='f16')
+    eng2.w_step(); eng2.h_step()
+    assert not eng2.left_f16_range()
+    m = NMFD(W=W0, H=H0).to(dev)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        m.fit(V.to(dev), 1, NO_STOP, 10, precision='f16')
+    assert any("fp16's range" in str(w.message) for w in rec), [str(w.message) for w in rec]
+
+
 def test_fit_f16_meets_parity_bar(dev):
     """north_star's bar (1e-4 relative on the factors after N iterations) in the single-plane fp16 mode at a size where
     the per-step rounding errors average down: 2048 x 4096, rank 64, 50 iterations."""
