@@ -279,6 +279,8 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  // channel tiles that are padding only: their planes and tile sums were zeroed by the pack-only pass and stay zero
+  if (update && c0 >= C) return;
   // the tile's own loads first (sixteen elements per thread, consecutive threads along k: coalesced fp32 traffic) ...
   const bool klm = kl_den != nullptr || kl_hpart != nullptr;
   float wv[16], nv[16], dv[16];
@@ -423,7 +425,38 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
   const int m_lo = r * T, m_hi = m_lo + T;
   const int diag = jx + b * L - m_lo;        // n - m of every element of this sum
   float neg = 0.f, pos = 0.f, hv = 0.f;
-  if (valid) {
+  const int tm_lo = m_lo / 128, tm_hi = (m_hi - 1) / 128;
+  if (valid && tm_hi - tm_lo < 6 && tm_hi < tail_tm0) {
+    // the usual case (<= 640 taps, no tail-split rows): <= 6 tile rows x 2 tile columns, every load issued before the
+    // first add (the general loop below serialises the L2 latencies: its trip counts are run-time values)
+    float vn[12], vd[12];
+#pragma unroll
+    for (int sr = 0; sr < 6; ++sr) {
+      const int tm = tm_lo + sr;
+      const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;
+      const int rbit = r > (tm * 128) / T ? 2 : 0;
+      const int tn_a = (b * L + jx + ta) / 128, tn_z = (b * L + jx + tb - 1) / 128;
+#pragma unroll
+      for (int sc = 0; sc < 2; ++sc) {
+        const int tn = sc ? tn_z : tn_a;
+        const bool ok = tm <= tm_hi && (sc == 0 || tn_z > tn_a);
+        const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
+        const int dd = diag - 128 * (tn - tm) + 127;
+        const size_t i = ((size_t)(tm * tiles_n + tn) * 4 + seg) * 256 + dd;
+        vn[2 * sr + sc] = ok ? pnum[i] : 0.f;
+        vd[2 * sr + sc] = (ok && !kl) ? pden[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) neg += vn[q], pos += vd[q];
+    if (kl) pos = den;
+    const size_t i = ((size_t)b * R + r) * Lh + jx;
+    hv = mu_update(TAB ? tb.h_old[i] : H[i], neg, pos, kl, l1, l2, gamma);
+    if (owned) {
+      H[i] = hv;
+      if constexpr (TAB) tb.h_next[i] = hv;
+    }
+  } else if (valid) {
     for (int tm = m_lo / 128; tm <= (m_hi - 1) / 128; ++tm) {
       const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
       const int rbit = r > (tm * 128) / T ? 2 : 0;
@@ -800,6 +833,10 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     if (d->m_pad < a.tR * a.tT || (int64_t)d->n_pad < (int64_t)a.tB * (a.tLh + a.tT - 1)) return NMFMU_ERR_ARG;
   } else {
     return NMFMU_ERR_ARG;
+  }
+  if (d->k_extra) {            // rank-1 tail of the contraction (fold epilogue)
+    if (epilogue != NMFMU_EPI_FOLD || d->k_extra < 0 || d->k_extra > 4 || a.k_len + d->k_extra > d->k_pad) return NMFMU_ERR_ARG;
+    a.k_extra = d->k_extra;
   }
   if (d->rag_channels > 0) {   // ragged channels as an extra MFMA block inside this launch's grid
     if (epilogue != NMFMU_EPI_RATIO || (d->ops != NMFMU_OPS_B_HU && d->ops != NMFMU_OPS_A_HU)) return NMFMU_ERR_ARG;

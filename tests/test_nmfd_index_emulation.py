@@ -259,3 +259,51 @@ def test_ragged_channels_as_an_extra_mfma_block(ops):
                     hits[c, frame] += 1
     assert (hits == 1).all()
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('B,R,T,Lh', [(1, 2, 136, 385), (2, 1, 8, 9), (1, 3, 16, 242 - 14), (1, 1, 24, 242 - 13), (2, 2, 128, 700)])
+def test_h_update_blocks_rewrite_the_window_tables(B, R, T, Lh):
+    """Round 3: conv_fold_parts_apply_h_kernel<TAB>.  A block covers 256 positions jx = jb * 242 + tid - 14 of one (b, r)
+    row, owns tid 7 .. 248 and recomputes the rest as halo; positions run over [-7, Lh + 6] (H = 0 outside [0, Lh)).
+    Owned threads write the reversed window {H[j] .. H[j-7]} for 0 <= j <= Lh + 6 and the forward window {H[j] .. H[j+7]}
+    for -7 <= j <= Lh - 1 at entry 1 + (b R + r) JJ + j + (T - 1).  Emulated with the kernel's index arithmetic: every
+    element of H is stored exactly once, and the tables equal what conv_tables_kernel builds (all other entries zero)."""
+    OWN = 242
+    JJ = Lh + 2 * T - 2
+    rng = np.random.default_rng(Lh)
+    Hnew = rng.random((B, R, Lh)) + 0.5
+    n = 1 + B * R * JJ
+    # reference tables (conv_tables_kernel)
+    rev_want, fwd_want = np.zeros((n, 8)), np.zeros((n, 8))
+    for i in range(1, n):
+        k = i - 1
+        br, j = k // JJ, k % JJ - (T - 1)
+        for e in range(8):
+            if 0 <= j - e < Lh:
+                rev_want[i, e] = Hnew.reshape(B * R, Lh)[br, j - e]
+            if 0 <= j + e < Lh:
+                fwd_want[i, e] = Hnew.reshape(B * R, Lh)[br, j + e]
+    rev, fwd = np.zeros((n, 8)), np.zeros((n, 8))       # set-up state: every entry once by the standalone kernel (zeros here)
+    stored = np.zeros((B, R, Lh), dtype=int)
+    jblocks = (Lh + 14 + OWN - 1) // OWN
+    for blk in range(B * R * jblocks):
+        jb, r, b = blk % jblocks, (blk // jblocks) % R, blk // (jblocks * R)
+        hl = np.zeros(256)
+        for tid in range(256):
+            jx = jb * OWN + tid - 14
+            if 0 <= jx < Lh:
+                hl[tid] = Hnew[b, r, jx]                 # (the update itself: any function of the OLD shadow and the parts)
+                if 7 <= tid < 7 + OWN:
+                    stored[b, r, jx] += 1
+        for tid in range(7, 7 + OWN):
+            jx = jb * OWN + tid - 14
+            assert jx >= -7
+            e = 1 + (b * R + r) * JJ + jx + T - 1
+            if jx <= Lh + 6:
+                if jx >= 0:
+                    rev[e] = [hl[tid - q] for q in range(8)]
+                if jx <= Lh - 1:
+                    fwd[e] = [hl[tid + q] for q in range(8)]
+    assert (stored == 1).all()
+    np.testing.assert_array_equal(rev, rev_want)
+    np.testing.assert_array_equal(fwd, fwd_want)
