@@ -36,7 +36,7 @@ extern "C" {
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
                                   NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status;
-                               5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), k_extra, nmfmu_gemm_ragged_supported,
+                               5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported,
                                   nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables */
 
 #define NMFMU_OK 0
@@ -270,10 +270,6 @@ typedef struct nmfmu_gemm_desc {
    * (row / column rag_c0.. of x / gn / gp at pitch n_ld).  Replaces a separate nmfmu_conv_ragged_rows launch (modes
    * 0 / 1) when nmfmu_gemm_ragged_supported().  rag_channels == 0: off. */
   int32_t rag_c0, rag_channels;
-  /* (ABI 5, appended) NMFMU_EPI_FOLD: the k_extra (0..4) contraction elements k_len .. k_len + k_extra - 1 are not run
-   * through the k loop but added as rank-1 updates of the tile in the epilogue (1025 channels = 16 k-tiles of 64 + one
-   * channel: k_len = 1024, k_extra = 1 instead of a seventeenth k-tile).  Same rounded operand values, fp32 products. */
-  int32_t k_extra;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */

@@ -55,10 +55,6 @@ struct GemmArgs {
   // not part of the GEMM's own tiles (one or two rows would cost a whole tile row, i.e. a second scheduling round);
   // every workgroup carries one extra 16 x 16 MFMA block for them (see nt_gemm_kernel).  rag_C <= rag_c0: off.
   int rag_c0, rag_C;
-  // EPI_FOLD: the last k_extra (<= 4) channels of the contraction, k = k_len .. k_len + k_extra - 1, are not run through
-  // the k loop (1025 channels = 16 k-tiles + ONE channel: a seventeenth k-tile for it costs 6 % of the GEMM) but added
-  // as rank-1 updates of the accumulator tile in the epilogue, from the same rounded operand values.
-  int k_extra;
 };
 
 // which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
@@ -138,26 +134,6 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     rag_sub0 = 16 * sub;
     rag_src[0] = reinterpret_cast<const char*>(OPS == kOpsBHu ? a.a_hi : a.b_hi) + (size_t)a.rag_c0 * ldk;
     if constexpr (X3) rag_src[1] = reinterpret_cast<const char*>(OPS == kOpsBHu ? a.a_lo : a.b_lo) + (size_t)a.rag_c0 * ldk;
-  }
-
-  // rank-1 tail of the contraction (EPI_FOLD): thread tid < 128 holds A[row tid][k_len + e], the others B[row tid - 128][..];
-  // fetched now, used in the epilogue.  Only contraction part 0 of a tail-split tile row adds them.
-  float r1v[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (EPI == kEpiFold && SH::THREADS == 256) {
-    if (a.k_extra > 0 && zz == 0) {
-      const bool isa = tid < 128;
-      const size_t ro = (size_t)((isa ? bm * C::BM : bn * C::BN) + (tid & 127)) * a.k_pad + a.k_len;
-      const uint16_t* ph = (isa ? a.a_hi : a.b_hi) + ro;
-      const uint16_t* pl = (isa ? a.a_lo : a.b_lo) + ro;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (e < a.k_extra) {
-          float v = unpack_lo<OPT>((uint32_t)ph[e]);
-          if constexpr (X3) v += bf16_lo((uint32_t)pl[e]);
-          r1v[e] = v;
-        }
-      }
-    }
   }
 
   // DMA source pointers: thread handles chunk c = p*THREADS + tid of a tile: row = c >> 3, LDS slot = c & 7,
@@ -404,25 +380,6 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     constexpr int QM = C::BM / 128, QN = C::BN / 128, QP = THREADS / 256, QBUF = 128 * kFoldLd;
     static_assert((QM * QN) % QP == 0, "whole quadrant groups");
     float* tl_all = reinterpret_cast<float*>(smem);
-    if constexpr (SH::THREADS == 256) {
-      if (a.k_extra > 0 && zz == 0) {   // (block-uniform)
-        float* rl = tl_all + QP * QBUF;  // [4][256]: A rows then B rows of the tile, behind the fold tile
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rl[e * 256 + tid] = r1v[e];
-        __syncthreads();
-        for (int e = 0; e < a.k_extra; ++e) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              const float bv = rl[e * 256 + 128 + wn * NI * 32 + ni * 32 + j];
-#pragma unroll
-              for (int q = 0; q < 16; ++q)
-                acc[mi][ni][q] = fmaf(rl[e * 256 + wm * MI * 32 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * hl], bv, acc[mi][ni][q]);
-            }
-        }
-      }
-    }
     const int L = a.tLh + a.tT - 1;
     const int tiles_n = a.n_pad / 128;
     for (int g = 0; g < QM * QN; g += QP) {
@@ -556,7 +513,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
 template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3, SH>;
-  constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4 + 4 * 256 * 4;   // fold tile + rank-1 operands
+  constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
   constexpr bool kRag = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256;
   constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
   static_assert(kLds <= 160 * 1024, "LDS budget");
@@ -571,7 +528,6 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
     *flag = true;
   }
   if (a.k_split > 1 && EPI != kEpiF32 && !(EPI == kEpiFold && a.tail_rows > 0)) return -3;
-  if (a.k_extra < 0 || a.k_extra > 4 || (a.k_extra > 0 && (EPI != kEpiFold || SH::THREADS != 256))) return -3;
   if (a.rag_C > a.rag_c0) {   // eight workgroups share out a tile's 128 frames: the other dimension needs >= 8 tiles
     if (!kRag || a.rag_C - a.rag_c0 > 16 || (OPS == kOpsBHu ? a.m_pad : a.n_pad) < 8 * 128) return -3;
   }

@@ -834,10 +834,6 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   } else {
     return NMFMU_ERR_ARG;
   }
-  if (d->k_extra) {            // rank-1 tail of the contraction (fold epilogue)
-    if (epilogue != NMFMU_EPI_FOLD || d->k_extra < 0 || d->k_extra > 4 || a.k_len + d->k_extra > d->k_pad) return NMFMU_ERR_ARG;
-    a.k_extra = d->k_extra;
-  }
   if (d->rag_channels > 0) {   // ragged channels as an extra MFMA block inside this launch's grid
     if (epilogue != NMFMU_EPI_RATIO || (d->ops != NMFMU_OPS_B_HU && d->ops != NMFMU_OPS_A_HU)) return NMFMU_ERR_ARG;
     const int own = d->ops == NMFMU_OPS_B_HU ? d->m_pad : d->n_pad;    // channels the GEMM's own tiles cover

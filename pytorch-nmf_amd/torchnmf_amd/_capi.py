@@ -51,7 +51,7 @@ class GemmDesc(C.Structure):
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
-                ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32), ('k_extra', C.c_int32)]
+                ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32)]
 
 
 ABI_VERSION = 5   # include/nmfmu.h: NMFMU_ABI_VERSION

@@ -164,17 +164,13 @@ class ConvMU:
         # when they make N full rounds of the chip plus at most a quarter round that is whole tile rows (configs[3]: 1600
         # tiles on 512 slots = 3 rounds + the last row of 64), those rows are contraction-split so that the last round
         # costs a fraction of a tile time.  The parts add up in the gather (fixed order).
-        # The contraction of that GEMM runs over the channels: with C = 64 k + (1..4) the last few are added as rank-1
-        # updates in its epilogue instead of costing a k-tile of their own (nmfmu_gemm_desc.k_extra).
-        self.h_k_extra = Cc % 64 if (self.fold_parts and Cc >= 64 and 1 <= Cc % 64 <= 4 and
-                                     os.environ.get('TORCHNMF_AMD_NMFD_K_EXTRA', '1') != '0') else 0
         self.h_tail_rows, self.h_tail_split = 0, 1
         want = os.environ.get('TORCHNMF_AMD_NMFD_TAIL_SPLIT', '1')      # '0' off, '1' automatic, 'rows,split' forced (tests)
         if self.fold_parts and want != '0':
             slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
             mt, nt = rpp // 128, blp // 128
             rem = (mt * nt) % slots
-            k_tiles = Cc // 64 if self.h_k_extra else -(-Cc // 64)
+            k_tiles = -(-Cc // 64)
             if ',' in want:
                 self.h_tail_rows, self.h_tail_split = (int(v) for v in want.split(','))
                 assert 0 < self.h_tail_rows <= mt and 2 <= self.h_tail_split <= k_tiles
@@ -229,7 +225,7 @@ class ConvMU:
                                           _ptr(planes.lo) if planes else None, _ptr(flags), _stream()), 'nmfmu_pack2d')
 
     def _gemm(self, a: _Planes, b: _Planes, epi, x=None, gn=None, gp=None, out=None, m_valid=0, n_valid=0, m_rows=None,
-              n_rows=None, k_len=0, k_split=0, tail_rows=0, ragged=False, k_extra=0, tag=None):
+              n_rows=None, k_len=0, k_split=0, tail_rows=0, ragged=False, tag=None):
         """D = A B^T with the given epilogue.  m_rows / n_rows: only the first rows of A / of B (ragged channels); the
         output planes keep their leading dimension.  tag: name of the launch for an attached KernelTimer (bench.py)."""
         assert a.cols_pad == b.cols_pad
@@ -244,7 +240,7 @@ class ConvMU:
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split,
-                           tail_rows, self.c_main if ragged else 0, self.C if ragged else 0, k_extra)
+                           tail_rows, self.c_main if ragged else 0, self.C if ragged else 0)
         timer = getattr(self, 'timer', None) if tag else None
         if timer is not None:
             timer.mark(tag + '<')
@@ -360,9 +356,6 @@ class ConvMU:
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
         kc = -(-self.C // 64) * 64             # the contraction runs over the channels: skip the zero tail of the padding
         tail = dict(k_split=self.h_tail_split, tail_rows=self.h_tail_rows) if self.h_tail_rows else {}
-        if self.h_k_extra:
-            kc = (self.C // 64) * 64
-            tail['k_extra'] = self.h_k_extra
         self._gemm(self.wmt, self.gnt, epi, out=self.y, k_len=kc, tag='num_h', **tail)
         if not self.kl:
             self._gemm(self.wmt, self.gpt, epi, out=self.y_den, k_len=kc, **tail)

@@ -774,39 +774,6 @@ def test_nmfd_h_numerator_tail_round_split(dev, shape, tail, beta, prec, monkeyp
         assert rel_err(res[tail][0], Wr) < TOL and rel_err(res[tail][1], Hr) < TOL
 
 
-@pytest.mark.parametrize('shape', [(1, 129, 600, 2, 400), (2, 66, 336, 3, 136), (1, 196, 520, 2, 128), (1, 1025, 776, 1, 400)])
-@pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (1, 'f16'), (0, 'bf16')])
-def test_nmfd_h_numerator_rank1_tail_of_the_contraction(dev, shape, beta, prec, monkeypatch):
-    """The H-numerator GEMM contracts over the channels.  With C = 64 k + (1..4) the last channels are not a k-tile of their
-    own (1025 channels: the 17th k-tile would hold one) but rank-1 updates of the accumulator tile in the fold epilogue
-    (nmfmu_gemm_desc.k_extra), from the same rounded operand values -- for the numerator and, beta != 1, the denominator
-    GEMM, with and without the tail-round split (only contraction part 0 adds them).  Must agree with the all-k-tiles
-    path to fp32 rounding and with the oracle; one, two and four extra channels."""
-    from oracle import mu_oracle as O
-    from torchnmf_amd.nmfd_engine import ConvMU
-    B, Cc, L, R, T = shape
-    g = torch.Generator().manual_seed(sum(shape) + 3)
-    V = torch.rand(B, Cc, L, generator=g) + 1e-3
-    W0 = torch.randn(Cc, R, T, generator=g).abs()
-    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
-    res = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('TORCHNMF_AMD_NMFD_K_EXTRA', mode)
-        if Cc == 1025:
-            monkeypatch.setenv('TORCHNMF_AMD_NMFD_TAIL_SPLIT', '4,6')
-        W, H = W0.clone().to(dev), H0.clone().to(dev)
-        eng = ConvMU(V.to(dev), W, H, beta, 0.01, 0.02, precision=prec)
-        assert eng.fold_parts and eng.h_k_extra == (Cc % 64 if mode == '1' else 0)
-        for _ in range(2):
-            eng.w_step()
-            eng.h_step()
-        res[mode] = (W.cpu(), H.cpu())
-    assert rel_err(res['1'][0], res['0'][0]) < 2e-6 and rel_err(res['1'][1], res['0'][1]) < 2e-6
-    Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, alpha=0.03, l1_ratio=1.0 / 3.0, kind='nmfd')
-    bar = TOL if prec == 'bf16x3' else 1e-4 if prec == 'f16' else 3e-3
-    assert rel_err(res['1'][0], Wr) < bar and rel_err(res['1'][1], Hr) < bar
-
-
 @pytest.mark.parametrize('shape', [(1, 129, 304, 4, 8), (2, 257, 200, 3, 24), (1, 136, 600, 2, 400), (1, 1025, 520, 3, 136),
                                    (3, 130, 96, 9, 5)])
 @pytest.mark.parametrize('beta,prec', [(1, 'bf16x3'), (2, 'bf16x3'), (0.5, 'bf16x3'), (1, 'bf16')])
