@@ -12,6 +12,9 @@
 //              (r, b) segment of the tile; nmfmu_conv_fold_parts_apply_h gathers them (the col2im sum of the conv1d
 //              backward pass wrt H without the 4 * R*T * B*L bytes write + read of Y)
 //
+// Round 3 added two things around the k loop: the tail-round split of the EPI_FOLD launch (GemmArgs::tail_rows) and the
+// ragged channels of the reconstruction launches as one extra 16 x 16 x 32 MFMA block per workgroup (GemmArgs::rag_*).
+//
 // Both operands are bf16 planes (hi[, lo]) with k contiguous, zero padded to multiples of 128 in every dimension.
 // 128x128 block tile, 4 waves (2x2, 64x64 each = 2x2 MFMA 32x32x16 tiles),
 // BK = 64, LDS double buffered by LDS-DMA.  The 128-byte LDS rows are XOR-swizzled on the DMA *source* side (linear LDS destination) and on the
