@@ -51,6 +51,28 @@ class _Table:
         self.lo = torch.empty(nbytes, dtype=torch.uint8, device=dev) if x3 else None
 
 
+def tail_round_split(mt: int, nt: int, slots: int, k_tiles: int, want: str = '1'):
+    """Tail-round split of an EPI_FOLD GEMM with mt x nt tiles on `slots` workgroup slots (two per CU) and k_tiles k-tiles:
+    (tail_rows, k_split), (0, 1) = none.  Automatic ('1'): when the tiles make at least one full round plus at most a
+    quarter round that is whole tile rows, those rows are contraction-split as far as the free slots, half the k-tiles
+    and 8 allow.  'rows,split' forces a choice (tests).  Either way the split is normalised so that every part holds
+    ceil(k_tiles / split) k-tiles and none is empty (the kernel's parts are [z * per, (z + 1) * per))."""
+    rows, split = 0, 1
+    rem = (mt * nt) % slots
+    if ',' in want:
+        rows, split = (int(v) for v in want.split(','))
+        assert 0 < rows <= mt and 2 <= split <= k_tiles
+    elif mt * nt > slots and 0 < rem <= slots // 4 and rem % nt == 0 and k_tiles >= 8:
+        rows = rem // nt
+        split = max(2, min(slots // rem, k_tiles // 2, 8))
+    if rows:
+        per = -(-k_tiles // split)
+        split = -(-k_tiles // per)
+        if split < 2:
+            rows, split = 0, 1
+    return rows, split
+
+
 class ConvMU:
     """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
 
@@ -168,20 +190,7 @@ class ConvMU:
         want = os.environ.get('TORCHNMF_AMD_NMFD_TAIL_SPLIT', '1')      # '0' off, '1' automatic, 'rows,split' forced (tests)
         if self.fold_parts and want != '0':
             slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
-            mt, nt = rpp // 128, blp // 128
-            rem = (mt * nt) % slots
-            k_tiles = -(-Cc // 64)
-            if ',' in want:
-                self.h_tail_rows, self.h_tail_split = (int(v) for v in want.split(','))
-                assert 0 < self.h_tail_rows <= mt and 2 <= self.h_tail_split <= k_tiles
-            elif mt * nt > slots and 0 < rem <= slots // 4 and rem % nt == 0 and k_tiles >= 8:
-                self.h_tail_rows = rem // nt
-                self.h_tail_split = max(2, min(slots // rem, k_tiles // 2, 8))
-            if self.h_tail_rows:                       # every part non-empty: parts of ceil(k_tiles / split) k-tiles
-                per = -(-k_tiles // self.h_tail_split)
-                self.h_tail_split = -(-k_tiles // per)
-                if self.h_tail_split < 2:
-                    self.h_tail_rows, self.h_tail_split = 0, 1
+            self.h_tail_rows, self.h_tail_split = tail_round_split(rpp // 128, blp // 128, slots, -(-Cc // 64), want)
         ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
         self.y = torch.empty(ny, dtype=torch.float32, device=dev)
         self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)

@@ -440,3 +440,28 @@ def test_fused_kernels_do_not_spill_to_scratch(tmp_path, unit):
                 in_loop = 'Loop' in line
             elif 'scratch_' in line:
                 assert not in_loop, (fn.split(':')[0], line)
+
+
+def test_tail_round_split_selection():
+    """Host rule of the NMFD H-numerator GEMM's tail-round split (nmfd_engine.tail_round_split): chosen only when the tiles
+    make whole rounds of the chip plus at most a quarter round of whole tile rows; every contraction part non-empty."""
+    from torchnmf_amd.nmfd_engine import tail_round_split
+    # configs[3]: R T = 3200 -> 25 tile rows, B L = 8192 -> 64 tile columns, 512 slots, 1025 channels -> 17 k-tiles
+    assert tail_round_split(25, 64, 512, 17) == (1, 6)          # min(512 / 64, 17 // 2, 8) = 8 -> parts of 3 k-tiles -> 6 parts
+    assert tail_round_split(25, 64, 512, 16) == (1, 8)
+    # exactly whole rounds, less than one round, a remainder that is not whole rows or above a quarter round: none
+    assert tail_round_split(24, 64, 512, 17) == (0, 1)
+    assert tail_round_split(7, 64, 512, 17) == (0, 1)
+    assert tail_round_split(25, 60, 512, 17) == (0, 1)          # 1500 % 512 = 476 > 128
+    assert tail_round_split(27, 64, 512, 17) == (0, 1)          # 3 rows = 192 > 128
+    assert tail_round_split(26, 64, 512, 17) == (2, 4)          # 128 tiles left: 512 / 128 = 4 parts of 5, 5, 5, 2
+    assert tail_round_split(25, 64, 512, 7) == (0, 1)           # short contractions are not worth splitting
+    # forced (tests): normalised so that no part is empty -- 17 k-tiles in 8 parts of 3 would leave parts 6, 7 empty
+    assert tail_round_split(25, 64, 512, 17, '4,8') == (4, 6)
+    assert tail_round_split(5, 5, 512, 9, '1,3') == (1, 3)
+    assert tail_round_split(5, 5, 512, 10, '2,2') == (2, 2)
+    for kt in range(2, 40):
+        for want_split in range(2, min(kt, 12) + 1):
+            rows, split = tail_round_split(30, 10, 512, kt, f'3,{want_split}')
+            per = -(-kt // split)
+            assert rows == 3 and 2 <= split <= want_split and (split - 1) * per < kt <= split * per
