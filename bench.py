@@ -66,7 +66,7 @@ def parse():
     ap.add_argument('--no-sweep', action='store_true', help='skip the beta_sweep (configs[2]) and nmfd (configs[3]) sub-objects '
                     'of the default run')
     ap.add_argument('--beta', type=float, default=1.0)
-    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16'],
+    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16', 'f16x'],
                     help="operand type of the headline leg: 'f16' (default: fp16 operands, bf16's MFMA rate, meets the 1e-4 "
                          "parity bar; nmf and nmfd workloads), 'bf16' (the type configs[1] names; factors ~2e-4 after 3 "
                          "iterations; default of the other workloads), 'bf16x3'")
@@ -84,6 +84,9 @@ def parse():
                     help="betamu: the closure returns m() (reconstruction written out, as in the reference's tests) "
                          "instead of the layer itself")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded (all-reduce) path even at world size 1')
+    ap.add_argument('--telemetry-s', type=float, default=0.8, help='seconds of back-to-back iterations (untimed, after the '
+                    'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
+                    'into roofline.clock_mhz / power_w (0 disables)')
     return ap.parse_args()
 
 
@@ -133,6 +136,127 @@ def pick_threads(run_probe, max_cands=None):
             best = c
     torch.set_num_threads(best)
     return best, tried
+
+
+class SmiSampler:
+    """Core clock and socket power while the GPU is under the benchmark's own load, read through amdsmi (the library
+    behind `amd-smi` / `rocm-smi --showpower --showclocks`) by a side thread -- the driver-visible evidence for what the
+    MFMA loops run at (they are power-limited).  Everything is best effort: a box without amdsmi, or
+    a metrics table without a field, yields None for it; nothing here is on the timed path."""
+
+    def __init__(self, index=0):
+        self.ok, self.err, self.h = False, None, None
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[min(index, len(hs) - 1)]
+            self.ok = True
+        except Exception as e:                       # no library / no permission: report why
+            self.err = f'{type(e).__name__}: {e}'[:200]
+
+    @staticmethod
+    def _num(v):
+        return float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else None
+
+    def read(self):
+        """One sample: {'t', 'gfxclk_mhz' (mean over the XCDs that report), 'power_w', 'energy', ...}."""
+        out = {'t': time.perf_counter()}
+        m = {}
+        try:
+            m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        except Exception as e:
+            self.err = f'metrics: {type(e).__name__}: {e}'[:200]
+        clks = m.get('current_gfxclks')
+        clks = [float(c) for c in clks if isinstance(c, (int, float)) and 0 < c < 10000] if isinstance(clks, (list, tuple)) else []
+        if not clks and self._num(m.get('current_gfxclk')):
+            clks = [float(m['current_gfxclk'])]
+        if not clks:
+            try:
+                c = self.smi.amdsmi_get_clock_info(self.h, self.smi.AmdSmiClkType.GFX)
+                if self._num(c.get('clk')):
+                    clks = [float(c['clk'])]
+            except Exception:
+                pass
+        out['gfxclk_mhz'] = sum(clks) / len(clks) if clks else None
+        out['gfxclk_xcd_mhz'] = clks
+        pw = self._num(m.get('current_socket_power'))
+        if pw is None or pw <= 0 or pw >= 65535:
+            pw = self._num(m.get('average_socket_power'))
+        if pw is None or pw <= 0 or pw >= 65535:
+            try:
+                pi = self.smi.amdsmi_get_power_info(self.h)
+                for k in ('current_socket_power', 'socket_power', 'average_socket_power'):
+                    if self._num(pi.get(k)) and 0 < pi[k] < 65535:
+                        pw = float(pi[k])
+                        break
+            except Exception:
+                pass
+        out['power_w'] = pw if pw and 0 < pw < 65535 else None
+        out['energy'] = self._num(m.get('energy_accumulator'))
+        out['mem_activity'] = self._num(m.get('average_umc_activity'))
+        out['temp_hotspot'] = self._num(m.get('temperature_hotspot'))
+        return out
+
+    def power_limit_w(self):
+        try:
+            pi = self.smi.amdsmi_get_power_info(self.h)
+            v = self._num(pi.get('power_limit'))
+            if v and v > 10000:          # some versions report microwatts
+                v /= 1e6
+            return v
+        except Exception:
+            return None
+
+    def under_load(self, step, seconds=1.0, period=0.04):
+        """Run `step` back to back for `seconds` (untimed) while a side thread samples; returns the summary dict."""
+        if not self.ok:
+            return {'source': 'amdsmi', 'available': False, 'error': self.err}
+        import threading
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                samples.append(self.read())
+                stop.wait(period)
+        idle = self.read()
+        th = threading.Thread(target=poll, daemon=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        # let the load run for a quarter of the window before the first sample counts (clock settles, SMI averages catch up)
+        while time.perf_counter() - t0 < 0.25 * seconds:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+        th.start()
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < seconds:
+            for _ in range(20):
+                step()
+            n += 20
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        stop.set()
+        th.join()
+        mean = lambda xs: (round(sum(xs) / len(xs), 1) if xs else None)
+        clk = [s_['gfxclk_mhz'] for s_ in samples if s_['gfxclk_mhz']]
+        pw = [s_['power_w'] for s_ in samples if s_['power_w']]
+        out = {'source': 'amdsmi gpu_metrics, side thread, %d samples over %.2f s of back-to-back iterations (untimed leg)' % (len(samples), dt),
+               'available': True, 'clock_mhz': mean(clk), 'clock_mhz_min_max': [min(clk), max(clk)] if clk else None,
+               'power_w': mean(pw), 'power_w_max': max(pw) if pw else None, 'power_limit_w': self.power_limit_w(),
+               'idle_clock_mhz': idle.get('gfxclk_mhz'), 'idle_power_w': idle.get('power_w'),
+               'iters_per_s_during_sampling': round(n / dt, 1),
+               'hotspot_c': mean([s_['temp_hotspot'] for s_ in samples if s_['temp_hotspot']]),
+               'hbm_activity_pct': mean([s_['mem_activity'] for s_ in samples if s_['mem_activity'] is not None])}
+        e = [s_['energy'] for s_ in samples if s_['energy']]
+        if len(e) >= 2 and e[-1] > e[0]:
+            # energy accumulator: 15.259 uJ per count (amdsmi's documented resolution for this family)
+            out['power_w_from_energy_counter'] = round((e[-1] - e[0]) * 15.259e-6 / (samples[-1]['t'] - samples[0]['t']), 1)
+        if self.err:
+            out['last_error'] = self.err
+        return out
 
 
 def preroll_steps(step, seconds):
@@ -458,7 +582,7 @@ def main_plca(a):
         'cpu_baseline': cpu}))
 
 
-def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, betamu=False, blocks_min=None):
+def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, betamu=False, blocks_min=None, telemetry=False):
     """W warm-up steps, an untimed pre-roll, then blocks of exactly K steps, each bracketed by barrier + synchronize; the
     block time is the MAX over ranks, the reported ms/step the median of the settled blocks.  Returns a dict."""
     from torchnmf_amd.engine import DenseMU, KernelTimer
@@ -535,7 +659,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         all_ms = spans.get('w', []) + spans.get('h', [])
         avg_ms = sum(all_ms) / len(all_ms)
         flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
-        elt = 4 if precision == 'bf16x3' else 2
+        elt = 4 if precision in ('bf16x3', 'f16x') else 2
         bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         pp = eng.step_h.block_rows == 256
@@ -553,6 +677,15 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
                 'hbm': {'achieved': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_bytes_per_launch': int(bytes_per_launch)}}
+        if telemetry and a.telemetry_s > 0 and world == 1:
+            # driver-visible clock / power evidence: what the chip grants under THIS loop
+            tel = SmiSampler(dev.index or 0).under_load(step, a.telemetry_s)
+            roof['clock_mhz'], roof['power_w'] = tel.get('clock_mhz'), tel.get('power_w')
+            if tel.get('clock_mhz'):
+                pk = MFMA_BF16_PEAK_TFLOPS * tel['clock_mhz'] / 2400.0
+                roof['peak_at_measured_clock'] = round(pk, 1)
+                roof['frac_of_peak_at_measured_clock'] = round(ach / pk, 4)
+            roof['telemetry'] = tel
         if 'ar' in spans:
             roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
             roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
@@ -593,8 +726,43 @@ def parity_leg(a, V, W0, H0, Vc, beta, precision, Wr, Hr, k, dev):
     return d
 
 
-DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)'}
+def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms):
+    """What the user calls: NMF.fit(V, beta, tol -> never stops, max_iter = 200) end to end -- engine
+    construction (packing V twice, validation), the initial loss, 200 iterations with the 20 loss evaluations + host syncs of
+    nmf.py:393-407 -- wall clock, next to the engine-step figure of the headline."""
+    from torchnmf_amd.nmf import NMF
+    m = NMF(W=W0, H=H0).to(dev)
+
+    def run(max_iter):
+        m.W.data.copy_(W0)
+        m.H.data.copy_(H0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = m.fit(V, beta=beta, tol=-1e9, max_iter=max_iter, **({} if precision is None else {'precision': precision}))
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0), n
+    run(20)                                        # warm: allocator, kernels' first launches
+    setup = min(run(0)[0] for _ in range(3))       # max_iter = 0: everything fit() does outside its loop
+    walls = []
+    for _ in range(3):
+        w, n = run(200)
+        assert n == 200
+        walls.append(w)
+    wall = sorted(walls)[1]
+    loop = wall - setup
+    return {'call': f"NMF.fit(V, beta={beta:g}, tol=-1e9, max_iter=200" + ("" if precision is None else f", precision='{precision}'") + ")",
+            'iterations': 200,
+            'wall_ms': round(wall, 3), 'wall_ms_runs': [round(x, 3) for x in walls], 'setup_ms': round(setup, 3),
+            'iters_per_s_whole_call': round(200e3 / wall, 1), 'iters_per_s_loop': round(200e3 / loop, 1),
+            'ms_per_iter_loop': round(loop / 200, 4), 'engine_step_ms': round(engine_ms, 4),
+            'loop_over_engine_step': round(loop / 200 / engine_ms, 4),
+            'note': 'loop = 200 MU iterations + 20 loss evaluations with their host syncs (nmf.py:393-407); setup = packing V in '
+                    'both orientations, validation flags, precision admission test, initial loss'}
+
+
+DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)', 'f16x': 'f16 operands, f32 target'}
 DTYPE_LONG = {'f16': 'f16 operands and target / fp32 accumulate (same MFMA rate as bf16; meets the 1e-4 parity bar)',
+              'f16x': 'f16 operands, fp32 target / fp32 accumulate (1x MFMA work, twice the V stream; for targets fp16 does not hold exactly)',
               'bf16': 'bf16 operands and target / fp32 accumulate (the type configs[1] names; factors ~2e-4 after 3 iterations)',
               'bf16x3': 'split bf16 (3 MFMAs per product, fp32 target): fp32-grade'}
 
@@ -674,7 +842,7 @@ def main():
     betamu = a.workload == 'betamu'
     flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R
 
-    head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu)
+    head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu, telemetry=True)
     # secondary, clearly labelled object: the other single-plane operand type, timed in the same run
     other = {'f16': 'bf16', 'bf16': 'f16'}.get(a.precision)
     second = None
@@ -736,6 +904,34 @@ def main():
         nmfd = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
                                      'roofline', 'parity', 'cpu_baseline')}
 
+    # ---- fit(): the call a torchnmf user makes, end to end; real_data_mode: a target fp16 does NOT hold exactly
+    fit_obj, real = None, None
+    if default_run:
+        from torchnmf_amd.engine import DenseMU
+        fit_obj = fit_leg(a, V, W0, H0, beta, a.precision, dev, head['ms_per_step'])
+        gr = torch.Generator(device=dev).manual_seed(4000)
+        Vr = torch.rand(N, C, device=dev, generator=gr)             # plain fp32 U[0,1): fp16 would round it
+        be = head['eng'].be
+        picks = DenseMU.auto_single_plane(Vr, W0, H0, be.pad_rank(R), be) or 'bf16x3'
+        leg = dense_leg(a, Vr, W0, H0, beta, picks, None, 1, dev, True, blocks_min=3)
+        rf = leg['roofline']
+        real = {'target': 'plain fp32 U[0,1) (not exactly representable in fp16)', 'auto_picks': picks, 'dtype': DTYPE_LONG[picks],
+                'iters_per_s': round(1e3 / leg['ms_per_step'], 2), 'ms_per_step': round(leg['ms_per_step'], 4),
+                'value': round(leg['gflops'], 1), 'unit': 'GFLOP/s', 'blocks_ms_per_step': leg['blocks_ms_per_step'],
+                'kernel': rf['kernel'], 'kernel_avg_launch_ms': rf['avg_launch_ms'], 'kernel_frac_mfma': rf['frac'],
+                'hbm': rf['hbm']}
+        del leg
+        if do_cpu:
+            from oracle import aten_port
+            k = 3
+            Vrc = Vr.cpu()
+            Wr, Hr = aten_port.mu_iterations(Vrc, W0.cpu(), H0.cpu(), beta, k)
+            real['parity'] = dict(k=k, **parity_leg(a, Vr, W0, H0, Vrc, beta, picks, Wr, Hr, k, dev))
+            del Vrc
+        fitr = fit_leg(a, Vr, W0, H0, beta, None, dev, 1e3 / real['iters_per_s'])   # precision=None: fit()'s own default ('auto')
+        real['fit'] = fitr
+        del Vr
+
     if rank == 0:
         ms_per_step = head['ms_per_step']
         eng = head['eng']
@@ -759,7 +955,7 @@ def main():
                        'launch': 'eager launches'},
             'roofline': head.get('roofline'), 'cpu_baseline': cpu, 'parity': parity,
             ('bf16_mode' if other == 'bf16' else 'parity_mode'): second,
-            'beta_sweep': beta_sweep, 'nmfd': nmfd,
+            'beta_sweep': beta_sweep, 'nmfd': nmfd, 'fit': fit_obj, 'real_data_mode': real,
         }
         if betamu:
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \

@@ -31,17 +31,19 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 5 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+#define NMFMU_ABI_VERSION 6 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
                                3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
                                   NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status;
                                5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported,
-                                  nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables */
+                                  nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables;
+                               6: NMFMU_PREC_F16X (fp16 operands, fp32 target) */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
 #define NMFMU_ERR_ARG (-3)         /* inconsistent sizes or null pointer */
+#define NMFMU_ERR_ALLOC (-4)       /* a host allocation inside the library failed (communicator / timer handles) */
 
 /* precision of the MFMA operands (accumulation is always fp32, factors are kept in fp32) */
 #define NMFMU_PREC_BF16 0   /* X stored bf16; operands bf16                                   */
@@ -50,6 +52,10 @@ extern "C" {
                                clamped to 65504 when packed, conversions saturate.  The single-plane mode that meets the
                                reference within 1e-4 at the BASELINE shapes.  beta == 1 at padded rank <= 128 runs on the
                                ping-pong kernel (nmfmu_pp.h), everything else on the four-wave kernel (nmfmu_fused.h) */
+#define NMFMU_PREC_F16X 3   /* X stored fp32 (nmfmu_xp_bytes: 4 bytes per element), operands fp16: the target is never rounded
+                               (nmf.py:65 is where X enters; it stays in fp32 VALU arithmetic, for beta == 2 it is an fp16
+                               hi + lo operand pair), so the mode is parity-grade on targets fp16 does not hold exactly, at 1x
+                               MFMA work and twice the X stream.  Four-wave kernel, every beta, padded rank <= 256 */
 
 /* beta branches of nmf.py:61-74 / metrics.py:78-96 */
 #define NMFMU_BETA_KL 0  /* beta == 1 */
@@ -332,7 +338,10 @@ int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* 
                        const float* kl_den, int rp_pad, float l1, float l2, float gamma, void* stream);
 
 /* nmfmu_conv_apply_w (when update != 0) fused with the re-packing of W into both GEMM operand layouts:
- * Wm [c_pad][rp_pad] and WmT [rp_pad][c_pad] bf16 planes (hi[, lo]; padding zero).  update == 0 only packs. */
+ * Wm [c_pad][rp_pad] and WmT [rp_pad][c_pad] bf16 planes (hi[, lo]; padding zero).  update == 0 only packs.
+ * PRECONDITION of update != 0: the same plane buffers (and tile-sum buffer, in the _sums form) have been through ONE
+ * update == 0 call before -- channel tiles that are padding only are skipped by the update pass and rely on the zeros
+ * the pack-only pass wrote there. */
 int nmfmu_conv_apply_pack_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                             const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
                             void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);

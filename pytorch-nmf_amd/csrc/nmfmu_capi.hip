@@ -21,6 +21,8 @@ using namespace nmfmu;
 namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool is_f16(int precision) { return precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_F16X; }   // fp16 operand images
+inline bool x_is_f32(int precision) { return precision == NMFMU_PREC_BF16X3 || precision == NMFMU_PREC_F16X; }
 
 // Diagnostic builds only (make EXTRA=-DNMFMU_DEBUG_HOOKS): NMFMU_FORCE_NSPLIT overrides the contraction split and
 // nmfmu_debug_set_buffer registers the clock-stamp buffer of the ping-pong kernel (tools/pp_timeline.py).  The product
@@ -137,6 +139,7 @@ int nmfmu_supported(int r_pad, int precision) {
   if (precision == NMFMU_PREC_BF16) return 1;
   if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
   if (precision == NMFMU_PREC_F16) return 1;                // ping-pong kernel (beta == 1, r_pad <= 128), else four-wave
+  if (precision == NMFMU_PREC_F16X) return 1;               // four-wave kernel: fp16 operands, fp32 target
   return 0;
 }
 
@@ -170,7 +173,7 @@ int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int
 }
 
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision) {
-  return (size_t)owner_rows_pad * (size_t)panel_rows_pad * (precision == NMFMU_PREC_BF16X3 ? 4 : 2);
+  return (size_t)owner_rows_pad * (size_t)panel_rows_pad * (x_is_f32(precision) ? 4 : 2);
 }
 size_t nmfmu_image_bytes(int rows_pad, int r_pad) { return (size_t)rows_pad * (size_t)r_pad * 2; }
 size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit) {
@@ -183,7 +186,7 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
   if (!v || !xp || rows <= 0 || cols <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int m = transpose ? cols : rows, k = transpose ? rows : cols;
   if (owner_rows_pad != pad_rows(m) || panel_rows_pad != pad_rows(k)) return NMFMU_ERR_ARG;
-  const int fmt = precision == NMFMU_PREC_BF16X3 ? 1 : (precision == NMFMU_PREC_F16 ? 2 : 0);
+  const int fmt = x_is_f32(precision) ? 1 : (precision == NMFMU_PREC_F16 ? 2 : 0);
   return launch_pack_x(v, ld, rows, cols, transpose != 0, fmt, xp, owner_rows_pad, panel_rows_pad, flags,
                        block_rows / 128, S(stream));
 }
@@ -201,7 +204,7 @@ static int pack_factor_common(const nmfmu_factor* fac, int rank, int r_pad, int 
   a.rows = fac->rows, a.rank = rank, a.rows_pad = fac->rows_pad;
   a.gamma = 1.f;
   a.scale = scale;
-  a.f16 = precision == NMFMU_PREC_F16;
+  a.f16 = is_f16(precision);
   return launch_apply(r_pad, a, x3, /*pack_only=*/true, S(stream));
 }
 
@@ -292,7 +295,7 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.rows = st->owner.rows, a.rank = st->rank, a.rows_pad = st->owner.rows_pad;
   a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   a.trainer = trainer, a.ortho = ortho, a.grad = grad;
-  a.f16 = st->precision == NMFMU_PREC_F16;
+  a.f16 = is_f16(st->precision);
   a.status = st->status;
   if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));

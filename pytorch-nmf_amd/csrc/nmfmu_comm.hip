@@ -93,7 +93,10 @@ int nmfmu_comm_init_rank(nmfmu_comm** comm, int nranks, const void* id128, int r
   const int e = rccl().CommInitRank(&c, nranks, id, rank);   // binds to the calling thread's current device
   if (e) return rc(e);
   nmfmu_comm* out = new (std::nothrow) nmfmu_comm{c, nranks};
-  if (!out) return NMFMU_ERR_ARG;
+  if (!out) {                       // do not leak the communicator RCCL has just built
+    rccl().CommDestroy(c);
+    return NMFMU_ERR_ALLOC;
+  }
   *comm = out;
   return NMFMU_OK;
 }
@@ -105,11 +108,22 @@ int nmfmu_comm_init_all(nmfmu_comm** comms, int ndev, const int* devices) {
   const int e = rccl().CommInitAll(cs, ndev, devices);
   if (e) return rc(e);
   for (int i = 0; i < ndev; ++i) comms[i] = new (std::nothrow) nmfmu_comm{cs[i], ndev};
+  for (int i = 0; i < ndev; ++i) {
+    if (comms[i]) continue;
+    // an allocation failed: hand back nothing -- destroy every communicator (wrapped or not) and clear the output array
+    for (int k = 0; k < ndev; ++k) {
+      rccl().CommDestroy(cs[k]);
+      delete comms[k];
+      comms[k] = nullptr;
+    }
+    return NMFMU_ERR_ALLOC;
+  }
   return NMFMU_OK;
 }
 
 int nmfmu_comm_nranks(const nmfmu_comm* comm) {
   if (!comm) return NMFMU_ERR_ARG;
+  if (!rccl().ok) return NMFMU_ERR_UNSUPPORTED;
   int n = 0;
   const int e = rccl().CommCount(comm->comm, &n);
   return e ? -rc(e) : n;
@@ -117,6 +131,7 @@ int nmfmu_comm_nranks(const nmfmu_comm* comm) {
 
 int nmfmu_comm_allreduce_sum_f32(nmfmu_comm* comm, float* buf, size_t count, void* stream) {
   if (!comm || !buf) return NMFMU_ERR_ARG;
+  if (!rccl().ok) return NMFMU_ERR_UNSUPPORTED;
   if (count == 0) return NMFMU_OK;
   return rc(rccl().AllReduce(buf, buf, count, kNcclFloat, kNcclSum, comm->comm, reinterpret_cast<hipStream_t>(stream)));
 }

@@ -31,6 +31,11 @@
 //            saturate at 65504.  For beta < 1 the elementwise terms are negative powers of S and can sit at the
 //            bottom of fp16's range, so Gn and Gp are multiplied by a power of two derived from the factors' column
 //            sums (identical in every workgroup) before the conversion; the epilogue scales the accumulators back.
+//   f16x   : fp16 operands as above, but X stays fp32 in HBM (round 4) -- the target is never rounded, so the mode is
+//            parity-grade on data fp16 does not hold exactly (STFT magnitudes, plain floats) at 1x MFMA work; the X
+//            stream doubles (HBM-bound: 1.07 GB per half-step at configs[1]).  The ratio is formed in fp32 from the
+//            unrounded x; for beta = 2 the target IS the second GEMM's operand and goes in as an fp16 hi + lo pair
+//            (two MFMAs for that product only).
 //
 // Tried and measured slower (round 3, profiles/r03_clock.md): a cross-tile software pipeline for the two-accumulator
 // instances (elementwise of tile t interleaved with GEMM2 of tile t-1 through sched_group_barrier, three LDS stages):
@@ -64,7 +69,7 @@ enum BetaKind : int { kKL = 0, kEuc = 1, kIS = 2, kGen = 3, kSqrt = 4, kSqrt3 = 
 // kModeDen: the positive term alone, den = Gp(S) @ panel with no target at all (sparse targets with a generic beta:
 // the reference's dense pass of nmf.py:628-636).  The loss mode also runs without a target (xp == nullptr: X = 0).
 enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2 };
-enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2 };   // = NMFMU_PREC_* of include/nmfmu.h
+enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2, kPrecF16X = 3 };   // = NMFMU_PREC_* of include/nmfmu.h
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -119,8 +124,9 @@ struct FusedArgs {
 
 template <int R_PAD, int BETA, int PREC, int MODE>
 struct FusedCfg {
-  static constexpr bool X3 = PREC == kPrecX3;
-  static constexpr bool F16 = PREC == kPrecF16;
+  static constexpr bool X3 = PREC == kPrecX3;                           // two operand planes (hi / lo)
+  static constexpr bool F16 = PREC == kPrecF16 || PREC == kPrecF16X;   // fp16 operand type
+  static constexpr bool XF32 = X3 || PREC == kPrecF16X;                // X stored fp32 (fragment order, 8 chunks per lane)
   static constexpr int BM = 128, WAVES = 4, THREADS = 256;
   static constexpr int KS = R_PAD / 16;      // k-steps of GEMM1 (contraction over rank)
   static constexpr int RT = R_PAD / 32;      // 32-wide rank tiles of GEMM2's output
@@ -135,8 +141,11 @@ struct FusedCfg {
   static constexpr int P2HI = NPL * IMG;
   static constexpr int P2LO = NPL * IMG + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  static constexpr int NQ = X3 ? 8 : 4;      // 16-byte X chunks per lane per tile
+  static constexpr int NQ = XF32 ? 8 : 4;    // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
+  // fp32 target as an fp16 MFMA operand (f16x, beta = 2: Gn = X): hi + lo pair, two MFMAs for the numerator product
+  static constexpr bool XSPLIT = PREC == kPrecF16X && BETA == kEuc && !LOSS && !DEN;
+  static constexpr bool GNLO = X3 || XSPLIT;                           // Gn has a low plane
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
   // fp16 operands: Gn / Gp of the branches with negative powers of S carry a power-of-two scale
   static constexpr bool SCALE = F16 && !LOSS && (BETA == kIS || BETA == kGen || BETA == kSqrt);
@@ -434,7 +443,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
 
   // The 16-bit A operands of GEMM2 (Gn, Gp; hi / lo planes), one set per tile
   struct GOps {
-    uint32_t gnh[2][8], gnl[X3 ? 2 : 1][8], gph[C::TWO_ACC ? 2 : 1][8], gpl[(C::TWO_ACC && X3) ? 2 : 1][8];
+    uint32_t gnh[2][8], gnl[C::GNLO ? 2 : 1][8], gph[C::TWO_ACC ? 2 : 1][8], gpl[(C::TWO_ACC && X3) ? 2 : 1][8];
   };
 
   // ---------------- GEMM1: S^T tiles (panel rows x owner rows), contraction over rank.
@@ -511,7 +520,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   // elem_pair: the two elements (columns 2d, 2d+1 of S^T tile tt) of this lane.
   auto elem_pair = [&](int t, const f32x16& stt, const u32x4(&x)[NQ], int tt, int d, GOps& g) {
     float x0, x1;
-    if constexpr (X3) {
+    if constexpr (C::XF32) {
       // NB: extract to scalars first -- __builtin_bit_cast on an ext-vector ELEMENT lvalue reads element 0
       // (hipcc 7.2), which silently turned every 16-byte chunk into a splat of its first float.
       const uint32_t u0 = x[4 * tt + (d >> 1)][2 * (d & 1)];
@@ -534,7 +543,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       float n0, n1, p0, p1;
       // fp16 target: the factor of Gn that does not depend on x first, then ONE v_fma_mix_f32 per element multiplies it
       // by the fp16 half of the stored word (no separate conversion of x)
-      constexpr bool MIX = C::F16 && BETA != kEuc;
+      constexpr bool MIX = C::F16 && !C::XF32 && BETA != kEuc;
       const float xa = MIX ? 1.f : x0, xb = MIX ? 1.f : x1;
       if constexpr (C::SCALE) {
         mu_elem_scaled<BETA>(s0, xa, a.beta, ki, n0, p0);
@@ -552,9 +561,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       }
       if constexpr (C::DEN) n0 = p0, n1 = p1;   // denominator-only pass: the one operand set carries Gp
       // (beta == 2 with one operand plane: Gn IS the stored target word -- no unpack / re-pack)
-      const uint32_t nh = (BETA == kEuc && !X3 && !C::DEN) ? x[2 * tt + (d >> 2)][d & 3] : pack_op<OPT>(n0, n1);
+      const uint32_t nh = (BETA == kEuc && !C::XF32 && !C::DEN) ? x[2 * tt + (d >> 2)][d & 3] : pack_op<OPT>(n0, n1);
       g.gnh[tt][d] = nh;
-      if constexpr (X3) g.gnl[tt][d] = pack_bf16(n0 - bf16_lo(nh), n1 - bf16_hi(nh));
+      if constexpr (C::GNLO) g.gnl[tt][d] = pack_op<OPT>(n0 - unpack_lo<OPT>(nh), n1 - unpack_hi<OPT>(nh));
       if constexpr (C::TWO_ACC) {
         const uint32_t ph = pack_op<OPT>(p0, p1);
         g.gph[tt][d] = ph;
@@ -601,6 +610,9 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         const u32x4 nl = {g.gnl[tt][4 * m2], g.gnl[tt][4 * m2 + 1], g.gnl[tt][4 * m2 + 2], g.gnl[tt][4 * m2 + 3]};
         on[rt] = mfma_bf16(nl, bh, on[rt]);
         on[rt] = mfma_bf16(nh, bl, on[rt]);
+      } else if constexpr (C::XSPLIT) {
+        const u32x4 nl = {g.gnl[tt][4 * m2], g.gnl[tt][4 * m2 + 1], g.gnl[tt][4 * m2 + 2], g.gnl[tt][4 * m2 + 3]};
+        on[rt] = mfma_op<OPT>(nl, bh, on[rt]);
       }
       on[rt] = mfma_op<OPT>(nh, bh, on[rt]);
       if constexpr (C::TWO_ACC) {
@@ -616,7 +628,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
-      __builtin_amdgcn_sched_group_barrier(0x008, (X3 ? 3 : 1) * (C::TWO_ACC ? 2 : 1), 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, X3 ? (C::TWO_ACC ? 6 : 3) : ((C::TWO_ACC ? 2 : 1) + (C::XSPLIT ? 1 : 0)), 1);
       if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
     }
   };
@@ -860,6 +872,8 @@ int launch_fused_dispatch(int beta_kind, int prec, int mode, const FusedArgs& a,
   NMFMU_CASE_LOSS(kPrecBf16)
   NMFMU_CASE_MU(kPrecF16)
   NMFMU_CASE_LOSS(kPrecF16)
+  NMFMU_CASE_MU(kPrecF16X)
+  NMFMU_CASE_LOSS(kPrecF16X)
   NMFMU_CASE(kGen, kPrecBf16, kModeDen)
   if constexpr (ALLOW_X3) {
     NMFMU_CASE(kGen, kPrecX3, kModeDen)

@@ -433,9 +433,9 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
 #pragma unroll
     for (int sr = 0; sr < 6; ++sr) {
       const int tm = tm_lo + sr;
-      const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;
+      const int tap_a = max(m_lo, tm * 128) - m_lo, tap_b = min(m_hi, tm * 128 + 128) - m_lo;   // (not `tb`: the tables)
       const int rbit = r > (tm * 128) / T ? 2 : 0;
-      const int tn_a = (b * L + jx + ta) / 128, tn_z = (b * L + jx + tb - 1) / 128;
+      const int tn_a = (b * L + jx + tap_a) / 128, tn_z = (b * L + jx + tap_b - 1) / 128;
 #pragma unroll
       for (int sc = 0; sc < 2; ++sc) {
         const int tn = sc ? tn_z : tn_a;
@@ -458,9 +458,9 @@ __global__ void __launch_bounds__(256) conv_fold_parts_apply_h_kernel(float* __r
     }
   } else if (valid) {
     for (int tm = m_lo / 128; tm <= (m_hi - 1) / 128; ++tm) {
-      const int ta = max(m_lo, tm * 128) - m_lo, tb = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
+      const int tap_a = max(m_lo, tm * 128) - m_lo, tap_b = min(m_hi, tm * 128 + 128) - m_lo;   // taps inside this tile row
       const int rbit = r > (tm * 128) / T ? 2 : 0;
-      const int na = b * L + jx + ta, nz = b * L + jx + tb - 1;
+      const int na = b * L + jx + tap_a, nz = b * L + jx + tap_b - 1;
       for (int tn = na / 128; tn <= nz / 128; ++tn) {
         const int seg = rbit + (b > (tn * 128) / L ? 1 : 0);
         const int dd = diag - 128 * (tn - tm) + 127;

@@ -311,6 +311,23 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         return;
       }
 #endif
+#ifdef NMFMU_PP_ABLATE_GRAY
+      // timing-only ablation (wrong results), VERDICT r3 item 1a / profiles/r04_clock.md: the operand-port pattern of a
+      // wave that owns 64 rows and walks (owner half, tt) resp. (owner half, rt) in Gray-code order -- exactly ONE
+      // matrix-pipe input changes per MFMA (shipped loop: 1.5 in G1, 1.25 in G2).  The instruction stream is untouched:
+      // every odd stream entry reads the LDS address of its even partner (identical data on the port), its MFMA takes
+      // the other input from a neighbouring register (q[kk+1] in G1, the other ratio quad in G2).  =1: G1 only (the
+      // experiment the verdict names; no clock change), =2: G1 and G2 (its G2 part corrupts the numerators; the factors
+      // degenerate within tens of iterations and the clock follows the DATA -- not a valid bound, see r04_clock.md).
+      if constexpr (g1 && e0 < NSTEP1) {
+        rd(dst, sa[0] ^ ((e0 >> 1) * 32), std::integral_constant<int, 0>{});
+      } else {
+        constexpr int ee = e0 - (g1 ? NSTEP1 : 0);
+        constexpr int e = NMFMU_PP_ABLATE_GRAY >= 2 ? (ee & ~1) : ee;
+        constexpr int rt = e % RT, c = e / RT;
+        rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
+      }
+#else
       if constexpr (g1 && e0 < NSTEP1) {
         rd(dst, sa[e0 & 1] ^ ((e0 >> 1) * 32), std::integral_constant<int, 0>{});
       } else {
@@ -318,6 +335,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         constexpr int rt = e % RT, c = e / RT;
         rd(dst, sb[c >> 1][c & 1], std::integral_constant<int, rt * 4096>{});
       }
+#endif
     };
     auto prefetch = [&](auto g1c) {   // first PF operands of the next M segment; issued in the preceding E segment
       static_for<PF>([&](auto pc) { opnd(ring[decltype(pc)::value], pc, g1c); });
@@ -337,17 +355,28 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         u32x4& op = ring[e % PF];
         if constexpr (e < N1) {
           constexpr int tt = e & 1, kk = e >> 1;
+#ifdef NMFMU_PP_ABLATE_GRAY
+          constexpr int kq = (kk + tt) % KS;   // B port: q[kk], q[kk+1] | q[kk+1], q[kk+2] | ... (changes on odd entries only)
+#else
+          constexpr int kq = kk;
+#endif
           if constexpr (kk == 0) {   // accumulator seed: the inline constant 1.0 (bf16, scaled) or the eps tile
             if constexpr (SCALED)
-              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=&v"(S[tt]) : "v"(op), "v"(q[0]));
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0" : "=&v"(S[tt]) : "v"(op), "v"(q[kq]));
             else
-              asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[0]), "v"(epsv));
+              asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(S[tt]) : "v"(op), "v"(q[kq]), "v"(epsv));
           } else {
-            mma(S[tt], op, q[kk]);
+            mma(S[tt], op, q[kq]);
           }
         } else {
           constexpr int s2 = e - N1;
+#if defined(NMFMU_PP_ABLATE_GRAY) && NMFMU_PP_ABLATE_GRAY >= 2
+          // Gray order over (ratio quad, rank tile): the B port (operand read, duplicated in pairs above) changes on even
+          // entries, the A port (ratio quad) on odd ones (and once more at the half-way point)
+          constexpr int rt = s2 % RT, c = (2 * (s2 >> 3)) ^ (((s2 + 1) >> 1) & 1), tt = c >> 1, m2 = c & 1;
+#else
           constexpr int rt = s2 % RT, c = s2 / RT, tt = c >> 1, m2 = c & 1;
+#endif
           const u32x4 nh = {gn[tt][4 * m2], gn[tt][4 * m2 + 1], gn[tt][4 * m2 + 2], gn[tt][4 * m2 + 3]};
           mma(acc[rt], nh, op);
         }

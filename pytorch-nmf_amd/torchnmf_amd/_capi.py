@@ -17,11 +17,12 @@ LIB_PATH = os.environ.get('NMFMU_LIB') or os.path.join(os.path.dirname(os.path.a
 OK = 0
 ERR_UNSUPPORTED = -2
 ERR_ARG = -3
-PREC_BF16, PREC_BF16X3, PREC_F16 = 0, 1, 2
+ERR_ALLOC = -4
+PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16X = 0, 1, 2, 3
 STAGE_REG, STAGE_DMA = 0, 1
 BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
 
-PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16}
+PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16, 'f16x': PREC_F16X}
 
 
 class NmfmuError(RuntimeError):
@@ -54,7 +55,7 @@ class GemmDesc(C.Structure):
                 ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32)]
 
 
-ABI_VERSION = 5   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 6   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
 
@@ -211,4 +212,6 @@ def check(code: int, what: str) -> None:
         raise NotImplementedError(f'{what}: combination not supported by libnmfmu (rank > 256, or bf16x3 with rank > 128)')
     if code == ERR_ARG:
         raise ValueError(f'{what}: libnmfmu rejected the arguments')
+    if code == ERR_ALLOC:
+        raise MemoryError(f'{what}: a host allocation inside libnmfmu failed')
     raise NmfmuError(f'{what}: HIP error {code}')

@@ -264,9 +264,10 @@ class DenseMU:
     F16_MIN_MEAN = 2.0 ** -10
 
     @classmethod
-    def f16_in_range(cls, V, W, H) -> bool:
-        """Range and exact-representability test of the fp16 mode: two passes over V (row chunks, so that the
-        temporaries stay small next to V), one over W and H, one host sync."""
+    def f16_stats(cls, V, W, H):
+        """(in_range, exact): the data sit inside fp16's range with room for the ratios / V is exactly representable in
+        fp16.  Two passes over V (row chunks, so that the temporaries stay small next to V), one over W and H, one
+        host sync."""
         bad = torch.zeros((), dtype=torch.bool, device=V.device)
         vmax = torch.zeros((), dtype=torch.float32, device=V.device)
         vsum = torch.zeros((), dtype=torch.float64, device=V.device)
@@ -278,10 +279,44 @@ class DenseMU:
             vsum += v.sum(dtype=torch.float64)
         stats = torch.stack([bad.float(), vmax, (vsum / V.numel()).float(), W.max(), H.max(), W.mean(), H.mean()]).tolist()
         inexact, vmax, vmean, wmax, hmax, wmean, hmean = stats
-        return (not inexact) and max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
+        in_range = max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
+        return in_range, not inexact
+
+    @classmethod
+    def f16_in_range(cls, V, W, H) -> bool:
+        """Admission test of the 'f16' mode (fp16 operands AND target): in range and V exact in fp16."""
+        in_range, exact = cls.f16_stats(V, W, H)
+        return in_range and exact
+
+    @classmethod
+    def auto_single_plane(cls, V, W, H, r_pad, be, group=None) -> Optional[str]:
+        """What precision='auto' may take at 1x MFMA work, or None: 'f16' (fp16 operands and target) when V is exact in
+        fp16, 'f16x' (fp16 operands, fp32 target) when it is not -- both only where the contraction lengths average the
+        operand rounding down (both dimensions >= F16_MIN_DIM) and the data sit inside fp16's range.  On a sharded fit
+        EVERY rank enters the same all-reduce, whatever its own shard looks like (shards of 4096, 4096, 4095
+        columns must not disagree about entering a collective), and all take the weakest rank's answer."""
+        if (os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') == '0' or not hasattr(_capi, 'PREC_F16')
+                or not be.supported(r_pad, _capi.PREC_F16)):
+            return None                                   # rank-invariant: same library, same environment on every rank
+        dims_ok = min(V.shape) >= cls.F16_MIN_DIM
+        if group is None and not dims_ok:
+            return None
+        in_range, exact = cls.f16_stats(V, W, H) if dims_ok else (False, False)
+        level = 2 if (in_range and exact) else (1 if in_range else 0)      # 2: f16, 1: f16x, 0: neither
+        if level == 1 and not (hasattr(_capi, 'PREC_F16X') and be.supported(r_pad, _capi.PREC_F16X)
+                               and os.environ.get('TORCHNMF_AMD_AUTO_F16X', '1') != '0'):
+            level = 0
+        if group is not None:
+            import torch.distributed as dist
+            flag = torch.tensor([level], dtype=torch.int32, device=V.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            level = int(flag.item())
+            if level == 1 and not (hasattr(_capi, 'PREC_F16X') and be.supported(r_pad, _capi.PREC_F16X)):
+                level = 0
+        return {2: 'f16', 1: 'f16x', 0: None}[level]
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
-                 update_W=True, update_H=True, block_rows=None, allow_f16=False):
+                 update_W=True, update_H=True, block_rows=None, allow_f16=False, ar_overlap=None):
         self.be = backend if backend is not None else DEFAULT_BACKEND_FACTORY()
         self.group = group
         self.beta = float(beta)
@@ -298,26 +333,14 @@ class DenseMU:
             # fp16 operands (1x MFMA work) where the contraction lengths average the rounding errors down and the data
             # fit fp16's range (sharded: every rank must decide alike, so the range test is all-reduced), else split
             # bf16 (3x MFMA work, fp32-grade, padded rank <= 128), else an error.
-            precision = None
-            f16_ok = (allow_f16 and min(N, Cc) >= self.F16_MIN_DIM and hasattr(_capi, 'PREC_F16')
-                      and self.be.supported(self.r_pad, _capi.PREC_F16)
-                      and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0')
-            if f16_ok:
-                ok = self.f16_in_range(V, W, H)
-                if group is not None:
-                    import torch.distributed as dist
-                    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=V.device)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-                    ok = int(flag.item()) == 0
-                if ok:
-                    precision = 'f16'
+            precision = self.auto_single_plane(V, W, H, self.r_pad, self.be, group) if allow_f16 else None
             if precision is None:
                 if not self.be.supported(self.r_pad, _capi.PREC_BF16X3):
                     raise NotImplementedError(
                         f"precision='auto' found no mode for rank {R} that meets the 1e-4 parity bar on the fused kernels "
-                        f"(fp16 operands need both dimensions >= {self.F16_MIN_DIM} and a target that fp16 represents exactly "
-                        f"and that sits within its range; split bf16 stops at rank 128); pass precision='bf16' (factors "
-                        f"~1e-3) or 'f16' (exact up to the rounding of V to fp16) explicitly")
+                        f"(fp16 operands -- 'f16', or 'f16x' with an fp32 target -- need both dimensions >= {self.F16_MIN_DIM} "
+                        f"and data within fp16's range; split bf16 stops at rank 128); pass precision='bf16' (factors "
+                        f"~1e-3), 'f16' or 'f16x' explicitly")
                 precision = 'bf16x3'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
@@ -367,7 +390,8 @@ class DenseMU:
             tail = self.r_pad if self.kl else self.step_h.plane
             self.xbuf = torch.empty(self.step_h.plane + tail, dtype=torch.float32, device=dev)
             # overlap: the H half-step as two row halves -- the first half's numerators are on the wire while the second
-            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0: one launch, one blocking all-reduce).  The split point
+            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0 or fit(..., allreduce='single'): one launch, ONE all-reduce of
+            # the packed buffer per iteration -- the form north_star names).  The split point
             # defaults to the middle row block; TORCHNMF_AMD_AR_SPLIT=<fraction of the rows in the first part> moves it
             # (to be swept on a multi-GPU node: the first part's all-reduce should just fit behind the second part's kernel)
             st = self.step_h
@@ -375,7 +399,9 @@ class DenseMU:
             frac = float(os.environ.get('TORCHNMF_AMD_AR_SPLIT', '0.5'))
             r0 = min(max(int(frac * nblk + 1e-9), 1), max(nblk - 1, 1)) * 256
             self._h_rows = None
-            if (os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0' and nblk >= 2 and st.owner.rows > r0
+            if ar_overlap is None:
+                ar_overlap = os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0'
+            if (ar_overlap and nblk >= 2 and st.owner.rows > r0
                     and hasattr(self.be, 'xp_rows')):
                 k_pad = st.panel.rows_pad
                 parts = [(0, r0), (r0, st.owner.rows_pad - r0)]
@@ -513,7 +539,7 @@ class DenseMU:
     def left_f16_range(self) -> bool:
         """fp16 mode: has any update so far clamped a factor value at 65504 for its image?  (One small device read; fit()
         asks at its loss checkpoints, where it synchronises anyway.)"""
-        return self.precision == _capi.PREC_F16 and bool(int(self.status.item()) & 1)
+        return self.precision in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)) and bool(int(self.status.item()) & 1)
 
     def divergence(self) -> float:
         """beta_div(H W^T, V) (nmf.py:360-361 / 400-401), summed over shards.  One host sync."""

@@ -111,7 +111,8 @@ class BaseComponent(nn.Module):
 
     @torch.no_grad()
     def fit(self, V: Tensor, beta: float = 1, tol: float = 1e-4, max_iter: int = 200, verbose: bool = False,
-            alpha: float = 0, l1_ratio: float = 0, *, precision: Optional[str] = None, process_group=None) -> int:
+            alpha: float = 0, l1_ratio: float = 0, *, precision: Optional[str] = None, process_group=None,
+            allreduce: Optional[str] = None) -> int:
         """Minimise the beta-divergence between ``V`` and the model by multiplicative updates.
 
         Same contract as the reference (nmf.py:297-409): W half-step, then H
@@ -120,16 +121,21 @@ class BaseComponent(nn.Module):
         ``(previous - loss) / loss_init < tol``.  Returns the number of iterations.
 
         Extra keyword-only arguments (not in the reference):
-          precision      None / 'auto' (default): the fastest mode that meets the reference's 1e-4 bar -- 'f16'
-                         (fp16 operands and target, bf16's MFMA rate) when both dimensions are >= 4096, rank <= 256,
-                         V is exactly representable in fp16 and the data sit inside fp16's range, otherwise 'bf16x3'
-                         (split-bf16 MFMA, matches the fp32 reference to ~1e-5; above rank 128 on the GEMM engine).
-                         Never plain bf16.  Explicit: 'f16' (a V that fp16 does not hold exactly is rounded to 11
-                         significant bits: a few 1e-5 per iteration, ~3e-4 after 200), 'bf16x3', 'bf16' (V and
-                         operands rounded to bf16: objective within 1e-4, factors ~1e-3).
+          precision      None / 'auto' (default): the fastest mode that meets the reference's 1e-4 bar.  With both
+                         dimensions >= 4096, rank <= 256 and the data inside fp16's range that is a single-plane fp16
+                         mode at bf16's MFMA rate: 'f16' (fp16 operands AND target) when V is exactly representable in
+                         fp16, else 'f16x' (fp16 operands, V stays fp32 in HBM: nothing is rounded that the reference
+                         does not round, twice the V stream).  Otherwise 'bf16x3' (split-bf16 MFMA, 3x the MFMA work,
+                         matches the fp32 reference to ~1e-5; above rank 128 on the GEMM engine).  Never plain bf16.
+                         Explicit: 'f16' (a V that fp16 does not hold exactly is rounded to 11 significant bits: a few
+                         1e-5 per iteration, ~3e-4 after 200), 'f16x', 'bf16x3', 'bf16' (V and operands rounded to
+                         bf16: objective within 1e-4, factors ~1e-3).
                          The environment variable TORCHNMF_AMD_PRECISION overrides the default.
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
+          allreduce      sharded fits only: 'single' = ONE all-reduce of the packed [numerator | denominator] buffer per
+                         iteration; 'overlap' = the H half-step in two row halves, the first half's all-reduce travelling
+                         behind the second half's kernel (two collectives); None = TORCHNMF_AMD_AR_OVERLAP (default overlap).
         """
         sparse = V.is_sparse
         if sparse and not isinstance(self, NMF):
@@ -156,6 +162,9 @@ class BaseComponent(nn.Module):
             from .sparse_engine import SparseMU
             eng = SparseMU(V, W.data, H.data, beta, l1, l2, update_W=W.requires_grad, update_H=H.requires_grad)
         else:
+            if allreduce not in (None, 'single', 'overlap'):
+                raise ValueError(f"allreduce must be None, 'single' or 'overlap', got {allreduce!r}")
+            self._ar_overlap = None if allreduce is None else allreduce == 'overlap'
             eng = self._make_engine(V, beta, l1, l2, precision, process_group)
 
         has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
@@ -192,6 +201,12 @@ class BaseComponent(nn.Module):
                     if (previous - loss) / loss_init < tol:
                         break
                     previous = loss
+            # fits shorter than ten iterations never reach a checkpoint: ask once more at the end
+            if not warned and getattr(eng, 'left_f16_range', None) is not None and eng.left_f16_range():
+                import warnings
+                warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during the fit; its fp16 operand "
+                              "image was clamped and the updates no longer follow the reference.  Re-run with "
+                              "precision='bf16x3' (or rescale V).")
         finally:
             if pbar is not None:
                 pbar.close()
@@ -241,17 +256,20 @@ class NMF(BaseComponent):
         auto = precision in (None, 'auto')
         wide = R > 256 or (R > 128 and precision == 'bf16x3')
         if R > 128 and R <= 256 and auto:
-            from .engine import DenseMU as _D
-            f16_ok = (min(V.shape) >= _D.F16_MIN_DIM and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0')
-            if group is None:
-                wide = not (f16_ok and _D.f16_in_range(V, self.W.data, self.H.data))
-                if not wide:
-                    precision = 'f16'
-            elif not f16_ok:
+            # one admission test for both engines (DenseMU.auto_single_plane; sharded: its answer is all-reduced, so every
+            # rank takes the same branch -- including the raise below)
+            from .engine import DenseMU as _D, DEFAULT_BACKEND_FACTORY
+            be = DEFAULT_BACKEND_FACTORY()
+            single = _D.auto_single_plane(V, self.W.data, self.H.data, be.pad_rank(R), be, group)
+            if single is not None:
+                precision = single
+            elif group is None:
+                wide = True
+            else:
                 raise NotImplementedError(
-                    "precision='auto' on a column-sharded fit at rank 129..256 needs the fp16 mode (both dimensions >= "
-                    f"{_D.F16_MIN_DIM}, a target fp16 holds exactly and within its range); pass precision='bf16' (factors "
-                    f"~1e-3) or 'f16' explicitly")
+                    "precision='auto' on a column-sharded fit at rank 129..256 needs a single-plane fp16 mode (both "
+                    f"dimensions >= {_D.F16_MIN_DIM} on every rank, data within fp16's range); pass precision='bf16' "
+                    f"(factors ~1e-3), 'f16' or 'f16x' explicitly")
         if wide and group is not None:
             raise NotImplementedError('column sharding is implemented for the fused kernels (rank <= 256; bf16x3 up to '
                                       'rank 128)')
@@ -260,7 +278,8 @@ class NMF(BaseComponent):
             return WideRankMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision,
                               update_W=self.W.requires_grad, update_H=self.H.requires_grad)
         return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
-                       update_W=self.W.requires_grad, update_H=self.H.requires_grad, allow_f16=True)
+                       update_W=self.W.requires_grad, update_H=self.H.requires_grad, allow_f16=True,
+                       ar_overlap=getattr(self, '_ar_overlap', None))
 
 
 class NMFD(BaseComponent):

@@ -183,7 +183,13 @@ class BetaMu(Optimizer):
                             q.data = q.data.contiguous()
                     if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
                         p.grad = torch.empty_like(p.data)
-                    if len(Ws) == 1:
+                    # One layer runs on the fused kernels -- unless 'auto' has no parity-grade mode there: rank 129..256
+                    # (split bf16 stops at rank 128, the fp16 modes are not admitted here) and anything wider than the
+                    # kernels' 256 take the exact chain path below, which has no rank limit (the reference's
+                    # BetaMu has none either, trainer.py:72-112).
+                    rank1 = Ws[0].shape[1] if len(Ws) == 1 else 0
+                    fused_ok = len(Ws) == 1 and (rank1 <= 128 or (rank1 <= 256 and self._precision not in (None, 'auto', 'bf16x3')))
+                    if fused_ok:
                         H, W = X0, Ws[0]
                         assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0]), \
                             f'target must be {(H.shape[0], W.shape[0])}, got {tuple(V.shape)}'

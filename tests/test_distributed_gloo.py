@@ -102,15 +102,27 @@ def _worker_rows(rank, world, port, beta, overlap, out_dir, split=None):
         V, W0, H0 = _tall_problem(beta)
         s, e = O.shard_bounds(V.shape[1], world)[rank]
         m = NMF(W=W0[s:e].clone(), H=H0.clone())
-        seen = {}
+        seen = {'sum_per_h_step': set()}
         orig = engine.DenseMU.h_step
+        orig_ar = dist.all_reduce
+        count = {'n': 0}
+
+        def counting_all_reduce(tensor, op=dist.ReduceOp.SUM, *a_, **k_):
+            if op == dist.ReduceOp.SUM:
+                count['n'] += 1
+            return orig_ar(tensor, op, *a_, **k_)
+        dist.all_reduce = counting_all_reduce
 
         def spy(self):
             seen['rows'] = None if self._h_rows is None else [(v.r0, v.owner.rows, v.owner.rows_pad) for v in self._h_rows]
-            return orig(self)
+            before = count['n']
+            out = orig(self)
+            seen['sum_per_h_step'].add(count['n'] - before)     # SUM collectives of this half-step
+            return out
         engine.DenseMU.h_step = spy
         n = m.fit(V[:, s:e].contiguous(), beta, 1e-4, 25, alpha=0.05, l1_ratio=0.5, process_group=dist.group.WORLD)
-        torch.save({'W': m.W.data, 'H': m.H.data, 'n': n, 'rows': seen.get('rows')}, os.path.join(out_dir, f'r{rank}.pt'))
+        torch.save({'W': m.W.data, 'H': m.H.data, 'n': n, 'rows': seen.get('rows'), 'sums': sorted(seen['sum_per_h_step'])},
+                   os.path.join(out_dir, f'r{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -136,6 +148,9 @@ def test_sharded_h_step_in_row_halves_world2(tmp_path, beta, overlap):
     Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 25, 0.05, 0.5)
     for p in parts:
         assert p['rows'] == ([(0, 256, 256), (256, 444, 512)] if overlap == '1' else None)
+        # north_star's form (TORCHNMF_AMD_AR_OVERLAP=0 / fit(..., allreduce='single')): exactly ONE SUM all-reduce of the packed
+        # [numerator | denominator] buffer per iteration; the overlapped form sends the two row halves separately
+        assert p['sums'] == ([2] if overlap == '1' else [1])
         assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
     assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5
     assert torch.equal(parts[0]['H'], parts[1]['H'])
@@ -158,3 +173,45 @@ def test_sharded_fit_world4_uneven_shards_and_moved_split(tmp_path, beta):
         assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
         assert torch.equal(p['H'], parts[0]['H'])
     assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5
+
+
+def _worker_gate(rank, world, port, cols, inexact_rank, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'pytorch-nmf_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cpu_backend import OracleBackend
+        from oracle import mu_oracle as O
+        from torchnmf_amd import engine
+        engine.DEFAULT_BACKEND_FACTORY = OracleBackend
+        engine.DenseMU.F16_MIN_DIM = 64
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(5)
+        N, R = 64, 4
+        V = torch.rand(N, cols, generator=g).half().float()
+        W0, H0 = torch.rand(cols, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1
+        s, e = O.shard_bounds(cols, world)[rank]
+        Vs = V[:, s:e].contiguous()
+        if rank == inexact_rank:
+            Vs[0, 0] += 2.0 ** -15                    # one value fp16 does not hold, on one rank only
+        eng = engine.DenseMU(Vs, W0[s:e].clone(), H0.clone(), 1.0, precision='auto', group=dist.group.WORLD, allow_f16=True)
+        eng.w_step()
+        eng.h_step()                                   # would hang / mis-pair if the ranks disagreed about the gate's collective
+        torch.save((eng.precision_name, e - s), os.path.join(out_dir, f'g{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cols,inexact_rank,want', [(128, -1, 'f16'), (128, 1, 'f16x'), (127, -1, 'bf16x3'), (127, 0, 'bf16x3')])
+def test_auto_precision_gate_is_rank_invariant(tmp_path, cols, inexact_rank, want):
+    """the admission test of the fp16 modes looks at the LOCAL shard (size, exactness), so with uneven shards
+    straddling F16_MIN_DIM (64 | 63 columns here) or one rank holding an fp16-inexact value the ranks used to disagree about
+    entering the flag all-reduce.  Now every rank enters it and all take the weakest rank's answer."""
+    world = 2
+    mp.spawn(_worker_gate, args=(world, _free_port(), cols, inexact_rank, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f'g{r}.pt') for r in range(world)]
+    assert [g_[0] for g_ in got] == [want] * world, got
+    assert sorted(g_[1] for g_ in got) == ([64, 64] if cols == 128 else [63, 64])

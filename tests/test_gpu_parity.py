@@ -74,7 +74,7 @@ def test_probe_lds_dma_is_lane_linear(dev):
 # ----------------------------------------------------------------------------------------------------------
 # packing layouts
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('prec', ['bf16', 'bf16x3', 'f16'])
+@pytest.mark.parametrize('prec', ['bf16', 'bf16x3', 'f16', 'f16x'])
 @pytest.mark.parametrize('transpose', [False, True])
 @pytest.mark.parametrize('block_rows', [128, 256])
 def test_pack_x_layout_and_flags(dev, prec, transpose, block_rows):
@@ -90,7 +90,7 @@ def test_pack_x_layout_and_flags(dev, prec, transpose, block_rows):
     flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
     xp = be.pack_x(V.to(dev), transpose, _capi.PRECISIONS[prec], block_rows, m_pad, k_pad, flags)
     torch.cuda.synchronize()
-    fp32 = prec == 'bf16x3'
+    fp32 = prec in ('bf16x3', 'f16x')
     got = (xp.view(torch.float32) if fp32 else xp.view(torch.float16 if prec == 'f16' else torch.bfloat16).float()).cpu().numpy()
     X = (V.t() if transpose else V).numpy()
     want = np.zeros(m_pad * k_pad, dtype=np.float32)
@@ -289,6 +289,49 @@ def test_f16_scaled_terms_small_and_large_reconstructions(dev, beta, scale):
     assert ew < 2e-4 and eh < 2e-4, (ew, eh)
 
 
+@pytest.mark.parametrize('beta', [1, 2, 0, 0.5, 1.5, 3, -1])
+@pytest.mark.parametrize('shape', [(384, 1100, 64), (520, 2300, 128), (200, 330, 24), (300, 700, 200)])
+def test_half_steps_f16x_every_beta(dev, beta, shape):
+    """precision='f16x' (round 4: fp16 operands, the target stays fp32 -- four-wave kernel for every beta, padded rank up
+    to 256): one regularised iteration against the fp32 oracle on a target fp16 does NOT hold exactly (plain floats).
+    For beta = 2 the target is the second GEMM's operand and goes in as an fp16 hi + lo pair."""
+    from oracle import mu_oracle as O
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + R + int(10 * beta) + 7)
+    V = torch.rand(N, C, generator=g) + (2.0 ** -7 if beta <= 0 else 0)
+    assert not torch.equal(V.half().float(), V)
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, beta, 'f16x', 1, alpha=0.1, l1r=0.5)
+    gam = O.gamma_of(beta)
+    Wr = O.nmf_w_step(V, W0, H0, beta, gam, 0.05, 0.05)
+    Hr = O.nmf_h_step(V, Wr, H0, beta, gam, 0.05, 0.05)
+    ew, eh = rel_err(W1, Wr), rel_err(H1, Hr)
+    record('half_steps_f16x_every_beta', beta=beta, shape=shape, relW=ew, relH=eh)
+    assert ew < TOL and eh < TOL, (ew, eh)
+    assert l0 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(H0, W0), V, beta)), rel=2e-4)
+    assert l1 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, beta)), rel=2e-4)
+
+
+def test_f16x_keeps_the_target_unrounded(dev):
+    """The point of 'f16x': a target made of values that fp16 rounds badly (x = 1 + 2^-13 multiples) -- the 'f16' mode
+    sees V rounded to 11 bits, 'f16x' must not: one beta = 2 half-step, whose numerator V^T H is linear in V, is compared
+    with the oracle on V and on fp16(V)."""
+    from oracle import mu_oracle as O
+    g = torch.Generator().manual_seed(77)
+    N, C, R = 384, 1100, 64
+    V = 1.0 + torch.randint(0, 8, (N, C), generator=g).float() * 2.0 ** -13     # fp16 spacing at 1.0 is 2^-10
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs().half().float()                  # operands exact in fp16: isolates the target
+    W0 = W0.half().float()
+    W1, _, _, _ = _one_iter(dev, V, W0, H0, 2, 'f16x', 1)
+    Wr = O.nmf_w_step(V, W0, H0, 2, 1.0)
+    Wq = O.nmf_w_step(V.half().float(), W0, H0, 2, 1.0)
+    e_true, e_rounded = rel_err(W1, Wr), rel_err(W1, Wq)
+    record('f16x_unrounded_target', e_true=e_true, e_vs_rounded_target=e_rounded)
+    assert e_true < 2e-5 and e_rounded > 3 * e_true, (e_true, e_rounded)
+
+
 def test_register_staging_is_gone(dev):
     """NMFMU_STAGE_REG (ABI < 4) is no longer built: the library says so instead of silently taking the DMA path."""
     from torchnmf_amd.engine import DenseMU
@@ -418,6 +461,29 @@ def test_auto_f16_at_its_threshold_200_iterations(dev):
     Wr, Hr = aten_port.mu_iterations(V, W0, H0, 1, 200)
     ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
     record('auto_f16_threshold_200', shape=(N, C, R), relW=ew, relH=eh)
+    assert n == 200 and ew < TOL and eh < TOL, (ew, eh)
+
+
+def test_auto_f16x_real_data_200_iterations(dev):
+    """what precision='auto' promises on data fp16 does not hold exactly (plain U[0,1) floats): the
+    smallest shape it admits, the default max_iter = 200, through fit() -- 'f16x' (fp16 operands, fp32 target), factors
+    within 1e-4 of the reference's fp32 iteration.  (The 'f16' mode drifts to 3.4e-4 on such a target.)"""
+    from oracle import aten_port
+    from torchnmf_amd import engine
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(34)
+    N, C, R = engine.DenseMU.F16_MIN_DIM, engine.DenseMU.F16_MIN_DIM, 64
+    V = torch.rand(N, C, generator=g)
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    Vd = V.to(dev)
+    assert engine.DenseMU(Vd, m.W.data.clone(), m.H.data.clone(), 1.0, precision='auto', allow_f16=True).precision_name == 'f16x'
+    n = m.fit(Vd, 1, NO_STOP, 200)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    Wr, Hr = aten_port.mu_iterations(V, W0, H0, 1, 200)
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    record('auto_f16x_real_data_200', shape=(N, C, R), relW=ew, relH=eh)
     assert n == 200 and ew < TOL and eh < TOL, (ew, eh)
 
 
@@ -1270,6 +1336,32 @@ def test_betamu_grad_is_beta_div_gradient(dev, beta, attr):
     assert bool(torch.all(getattr(m, attr).data >= 0))
 
 
+@pytest.mark.parametrize('rank', [200, 300])
+@pytest.mark.parametrize('beta', [1, 0.5])
+def test_betamu_default_precision_above_rank_128(dev, rank, beta):
+    """BetaMu's default precision ('auto') has no fused mode above rank 128 (split bf16 stops there and the
+    fp16 modes are not admitted for the trainer); such a layer -- and one wider than the kernels' 256 -- must take the
+    exact chain path, not raise: the reference's BetaMu has no rank limit (trainer.py:72-112)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
+    g = torch.Generator().manual_seed(rank)
+    V = torch.rand(260, 340, generator=g) + 1e-3
+    W0 = torch.randn(340, rank, generator=g).abs()
+    H0 = torch.randn(260, rank, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    trainer = BetaMu(m.parameters(), beta)
+    Vd = V.to(dev)
+
+    def closure():
+        trainer.zero_grad()
+        return Vd, m()
+    trainer.step(closure)
+    Wn, Hn, _ = O.betamu_step(V, W0, H0, beta)
+    ew, eh = rel_err(m.W.data.cpu(), Wn), rel_err(m.H.data.cpu(), Hn)
+    assert ew < TOL and eh < TOL, (ew, eh)
+
+
 def test_betamu_rejects_general_graphs_and_cpu_tensors(dev):
     from torchnmf_amd import _capi
     from torchnmf_amd.nmf import NMF
@@ -1583,7 +1675,7 @@ def test_cfg1_full_size_one_iteration(dev, prec, tol):
     assert ew < tol and eh < tol, (ew, eh)
 
 
-@pytest.mark.parametrize('beta', [2, 0.5])
+@pytest.mark.parametrize('beta', [2, 0.5, 0])
 def test_cfg2_full_size_one_iteration_f16(dev, beta):
     """BASELINE configs[2] (the beta sweep at the configs[1] shape) in the parity-grade single-plane mode: one full-size
     iteration against the reference's op sequence."""
@@ -1591,6 +1683,8 @@ def test_cfg2_full_size_one_iteration_f16(dev, beta):
     g = torch.Generator().manual_seed(2)
     N, C, R = 4096, 65536, 128
     V = torch.rand(N, C, generator=g).bfloat16().float()
+    if beta <= 0:
+        V.clamp_(min=2.0 ** -7)                          # strictly positive for beta <= 0 (nmf.py:332-336)
     W0 = torch.randn(C, R, generator=g).abs()
     H0 = torch.randn(N, R, generator=g).abs()
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -1602,10 +1696,11 @@ def test_cfg2_full_size_one_iteration_f16(dev, beta):
 
 
 def test_cfg1_full_size_20_iterations_f16_unrounded_target(dev):
-    """20 iterations at configs[1]'s full size in the f16 mode with a target that fp16 does NOT hold
-    exactly (plain U[0,1) floats), against the reference's op sequence.  The rounding of V is the dominant error of
-    this mode on such data and grows with the iteration count -- which is why 'auto' demands an
-    fp16-exact target; at 20 iterations it is still inside the bar."""
+    """20 iterations at configs[1]'s full size with a target that fp16 does NOT hold exactly
+    (plain U[0,1) floats), against the reference's op sequence -- in the f16 mode (the rounding of V is its dominant
+    error on such data and grows with the iteration count, DESIGN.md section 4, which is why 'auto' demands an fp16-exact
+    target for it; at 20 iterations it is still inside the bar) and in 'f16x', which keeps V in fp32 and is what 'auto'
+    takes here."""
     from oracle import aten_port
     from torchnmf_amd.engine import DenseMU
     g = torch.Generator().manual_seed(3)
@@ -1615,18 +1710,21 @@ def test_cfg1_full_size_20_iterations_f16_unrounded_target(dev):
     H0 = torch.randn(N, R, generator=g).abs()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     Wr, Hr = aten_port.mu_iterations(V, W0, H0, 1, 20)
-    W, H = W0.clone().to(dev), H0.clone().to(dev)
     Vd = V.to(dev)
-    assert DenseMU(Vd[:4096, :4096].contiguous(), W[:4096].clone(), H.clone(), 1.0, precision='auto',
-                   allow_f16=True).precision_name == 'bf16x3'      # not fp16-exact: 'auto' stays fp32-grade
-    eng = DenseMU(Vd, W, H, 1.0, precision='f16')
-    for _ in range(20):
-        eng.w_step()
-        eng.h_step()
-    torch.cuda.synchronize()
-    ew, eh = rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr)
-    record('cfg1_full_size_20_iterations_f16_unrounded', relW=ew, relH=eh)
-    assert ew < TOL and eh < TOL, (ew, eh)
+    # not fp16-exact: 'auto' keeps the target in fp32 (round 4: at fp16 operands -- 'f16x'; before, split bf16)
+    assert DenseMU(Vd[:4096, :4096].contiguous(), W0[:4096].clone().to(dev), H0.clone().to(dev), 1.0, precision='auto',
+                   allow_f16=True).precision_name == 'f16x'
+    for prec in ('f16', 'f16x'):
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = DenseMU(Vd, W, H, 1.0, precision=prec)
+        for _ in range(20):
+            eng.w_step()
+            eng.h_step()
+        torch.cuda.synchronize()
+        ew, eh = rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr)
+        record('cfg1_full_size_20_iterations_unrounded', prec=prec, relW=ew, relH=eh)
+        assert ew < TOL and eh < TOL, (prec, ew, eh)
+        del eng
 
 
 @pytest.mark.parametrize('prec,tol', [('bf16', 5e-3), ('f16', TOL)])
@@ -1664,7 +1762,11 @@ def test_auto_precision_policy(dev, monkeypatch):
     assert pick(4096, 4352, 64) == 'f16'
     assert pick(4096, 4352, 64, beta=2.0) == 'f16' and pick(4096, 4352, 64, beta=0.5) == 'f16'
     assert pick(4096, 4352, 200) == 'f16'                      # padded rank 256: the four-wave fp16 kernel
-    assert pick(4096, 4352, 64, exact=False) == 'bf16x3'       # fp16 would round the target
+    assert pick(4096, 4352, 64, exact=False) == 'f16x'         # fp16 would round the target: it stays fp32 (round 4)
+    assert pick(4096, 4352, 200, exact=False, beta=2.0) == 'f16x'
+    monkeypatch.setenv('TORCHNMF_AMD_AUTO_F16X', '0')
+    assert pick(4096, 4352, 64, exact=False) == 'bf16x3'
+    monkeypatch.delenv('TORCHNMF_AMD_AUTO_F16X')
     assert pick(4096, 4352, 64, allow=False) == 'bf16x3'       # trainer / PLCA engines keep the fp32-grade default
     assert pick(2048, 8192, 64) == 'bf16x3'                    # short contraction: rounding errors do not average down
     assert pick(4096, 4352, 64, scale=2.0 ** 20) == 'bf16x3'   # outside fp16's range

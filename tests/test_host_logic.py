@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_static_queries():
     lib = _capi.load()
-    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 5
+    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 6
     assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
     assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
     assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED
@@ -129,6 +129,9 @@ def test_static_queries():
     assert lib.nmfmu_block_rows(128, _capi.PREC_F16, 1.0) == 256 and lib.nmfmu_block_rows(128, _capi.PREC_BF16, 1.0) == 256
     assert lib.nmfmu_block_rows(128, _capi.PREC_F16, 2.0) == 128 and lib.nmfmu_block_rows(256, _capi.PREC_F16, 1.0) == 128
     assert lib.nmfmu_block_rows(128, _capi.PREC_BF16X3, 1.0) == 128
+    # fp16 operands with an fp32 target (round 4): four-wave kernel at every rank pad, X stored at 4 bytes per element
+    assert lib.nmfmu_supported(256, _capi.PREC_F16X) == 1 and lib.nmfmu_block_rows(128, _capi.PREC_F16X, 1.0) == 128
+    assert lib.nmfmu_xp_bytes(256, 512, _capi.PREC_F16X) == 4 * 256 * 512 == 2 * lib.nmfmu_xp_bytes(256, 512, _capi.PREC_F16)
     assert lib.nmfmu_debug_set_buffer(None) == _capi.ERR_UNSUPPORTED   # diagnostic hook: NMFMU_DEBUG_HOOKS builds only
     assert lib.nmfmu_choose_nsplit(4096, 65536, 128, 256) == 16      # 32 owner blocks x 16 chunks = 512 workgroups
     assert lib.nmfmu_choose_nsplit(65536, 4096, 128, 256) == 1
@@ -339,7 +342,7 @@ def test_f16_admission_test_of_auto_precision():
     assert not DenseMU.f16_in_range(Vb, W, H)
 
 
-def test_auto_precision_policy_on_the_standin_backend(cpu_engine):
+def test_auto_precision_policy_on_the_standin_backend(cpu_engine, monkeypatch):
     """The decision tree of 'auto' without a GPU (the stand-in backend supports every single-plane rank and split bf16 up
     to rank 128, like the library): fp16 needs both dimensions >= F16_MIN_DIM and an admissible target; otherwise split
     bf16; above rank 128 an error from the fused engine -- never plain bf16."""
@@ -355,17 +358,22 @@ def test_auto_precision_policy_on_the_standin_backend(cpu_engine):
             return DenseMU(V, torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1, 1.0,
                            precision='auto', allow_f16=allow).precision_name
         assert pick(64, 80, 8) == 'f16'
-        assert pick(64, 80, 8, exact=False) == 'bf16x3'
+        assert pick(64, 80, 8, exact=False) == 'f16x'       # round 4: an inexact target stays fp32 under fp16 operands
         assert pick(64, 80, 8, allow=False) == 'bf16x3'
         assert pick(63, 80, 8) == 'bf16x3'
         assert pick(64, 80, 200) == 'f16'
+        assert pick(64, 80, 200, exact=False) == 'f16x'
         with pytest.raises(NotImplementedError):
             pick(63, 80, 200)
+        monkeypatch.setenv('TORCHNMF_AMD_AUTO_F16X', '0')
+        assert pick(64, 80, 8, exact=False) == 'bf16x3'
         with pytest.raises(NotImplementedError):
             pick(64, 80, 200, exact=False)
+        monkeypatch.setenv('TORCHNMF_AMD_AUTO_F16', '0')
+        assert pick(64, 80, 8) == 'bf16x3'
     finally:
         DenseMU.F16_MIN_DIM = old
-    assert _capi.PRECISIONS['f16'] == _capi.PREC_F16 == 2
+    assert _capi.PRECISIONS['f16'] == _capi.PREC_F16 == 2 and _capi.PRECISIONS['f16x'] == _capi.PREC_F16X == 3
 
 
 def test_bench_block_timing_rules(monkeypatch):

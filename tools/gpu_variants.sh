@@ -10,7 +10,7 @@ for i in 1 2; do
 import json
 try:
     d=json.load(open("$OUT/v_${v}_$i.json")); r=d["roofline"]
-    print("[%-4s] it/s=%.1f ms/step=%.4f fused_ms=%.4f (w %.4f h %.4f) TF=%.0f" % ("$v" or "base", d["iters_per_s"], d["ms_per_step"], r["avg_launch_ms"], r["avg_launch_ms_w_step"], r["avg_launch_ms_h_step"], r["achieved"]))
+    print("[%-4s] it/s=%.1f ms/step=%.4f fused_ms=%.4f (w %.4f h %.4f) TF=%.0f clock=%s MHz power=%s W" % ("$v" or "base", d["iters_per_s"], d["ms_per_step"], r["avg_launch_ms"], r["avg_launch_ms_w_step"], r["avg_launch_ms_h_step"], r["achieved"], r.get("clock_mhz"), r.get("power_w")))
 except Exception as e: print("[$v] FAILED", e)
 PY
   done
