@@ -245,7 +245,51 @@ def mu_gamma(beta: float) -> float:
     return 1.0
 
 
-class DenseMU:
+class AsyncLossMixin:
+    """Loss checkpoints of ``fit`` without a host sync (reference loop: nmf.py:393-407).
+
+    ``checkpoint_begin`` enqueues the loss kernel, an asynchronous copy of its result (and of the fp16-range flag) into
+    pinned host memory, a device-side snapshot of the two factors, and an event -- then returns; the host keeps launching
+    iterations.  ``checkpoint_result`` is asked one checkpoint later (the event completed ten iterations ago: no bubble);
+    if the stop rule fired for the checkpoint, ``rollback`` restores the snapshot, so the caller gets exactly the factors
+    the synchronous loop would have returned.  An engine provides ``_loss_device()`` (enqueue; float64[1] device tensor),
+    ``_range_flag_device()`` (float64[1] device tensor or None), ``_ckpt_tensors()`` and ``refresh_images()``."""
+
+    _ck = None
+
+    def checkpoint_begin(self):
+        tens = self._ckpt_tensors()
+        if self._ck is None:
+            on_gpu = tens[0].is_cuda       # (the CPU test-suite drives this logic through the stand-in backend)
+            host = torch.zeros(2, dtype=torch.float64)
+            self._ck = {'snap': [torch.empty_like(t) for t in tens],
+                        'host': host.pin_memory() if on_gpu else host,
+                        'stage': torch.zeros(2, dtype=torch.float64, device=tens[0].device),
+                        'ev': torch.cuda.Event() if on_gpu else None}
+        ck = self._ck
+        ck['stage'][0:1].copy_(self._loss_device())
+        flag = self._range_flag_device()
+        if flag is not None:
+            ck['stage'][1:2].copy_(flag)
+        ck['host'].copy_(ck['stage'], non_blocking=True)
+        for s_, t_ in zip(ck['snap'], tens):
+            s_.copy_(t_)
+        if ck['ev'] is not None:
+            ck['ev'].record()
+
+    def checkpoint_result(self):
+        """(divergence, left_f16_range) of the last ``checkpoint_begin``."""
+        if self._ck['ev'] is not None:
+            self._ck['ev'].synchronize()
+        return float(self._ck['host'][0]), bool(self._ck['host'][1] != 0)
+
+    def rollback(self):
+        for s_, t_ in zip(self._ck['snap'], self._ckpt_tensors()):
+            t_.copy_(s_)
+        self.refresh_images()
+
+
+class DenseMU(AsyncLossMixin):
     """Engine for ``NMF.fit``: V (N, C) ~ H (N, R) @ W (C, R)^T on the current device.
 
     ``W`` / ``H`` are the parameters' ``.data`` tensors and are updated in place
@@ -540,6 +584,19 @@ class DenseMU:
         """fp16 mode: has any update so far clamped a factor value at 65504 for its image?  (One small device read; fit()
         asks at its loss checkpoints, where it synchronises anyway.)"""
         return self.precision in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)) and bool(int(self.status.item()) & 1)
+
+    # -- AsyncLossMixin (unsharded fits)
+    def _loss_device(self):
+        self.be.loss(self.step_h, self.loss_part, self.loss_out)
+        return self.loss_out
+
+    def _range_flag_device(self):
+        if self.precision not in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)):
+            return None
+        return (self.status & 1).double()
+
+    def _ckpt_tensors(self):
+        return [self.fW.f, self.fH.f]
 
     def divergence(self) -> float:
         """beta_div(H W^T, V) (nmf.py:360-361 / 400-401), summed over shards.  One host sync."""

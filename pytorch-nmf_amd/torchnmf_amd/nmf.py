@@ -181,6 +181,41 @@ class BaseComponent(nn.Module):
             pbar = tqdm(total=max_iter)
         n_iter = -1
         warned = False
+        # Loss checkpoints without a host sync (engines with AsyncLossMixin; unsharded, no progress bar): the loss of
+        # checkpoint k is enqueued -- with a snapshot of W and H -- and judged at checkpoint k + 10, when its value has long
+        # arrived; if the stop rule of nmf.py:405 had fired at k, the snapshot is restored and k + 1 returned: the same
+        # factors and the same count as the synchronous loop, without draining the launch queue every ten iterations.
+        use_async = (process_group is None and not verbose and hasattr(eng, 'checkpoint_begin')
+                     and os.environ.get('TORCHNMF_AMD_ASYNC_LOSS', '1') != '0')
+        pending = None           # iteration index of the checkpoint whose loss is still in flight
+
+        def range_warning():
+            nonlocal warned
+            import warnings
+            warned = True
+            warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during the fit; its fp16 "
+                          "operand image is clamped from here on and the updates no longer follow the "
+                          "reference.  Re-run with precision='bf16x3' (or rescale V).")
+
+        def judge(loss, left):
+            """nmf.py:402-407 for one checkpoint; True = stop there."""
+            nonlocal previous
+            if left and not warned:
+                range_warning()
+            if (previous - loss) / loss_init < tol:
+                return True
+            previous = loss
+            return False
+
+        def settle():
+            """Judge the pending checkpoint; on stop restore its factors and return its iteration index, else None."""
+            nonlocal pending
+            k, pending = pending, None
+            div, left = eng.checkpoint_result()
+            if judge(_sqrt2(div), left):
+                eng.rollback()
+                return k
+            return None
         try:
             for n_iter in range(max_iter):
                 if W.requires_grad:
@@ -188,25 +223,30 @@ class BaseComponent(nn.Module):
                 if H.requires_grad:
                     eng.h_step()
                 if n_iter % 10 == 9:
+                    if use_async:
+                        if pending is not None:
+                            stopped_at = settle()
+                            if stopped_at is not None:
+                                n_iter = stopped_at
+                                break
+                        if n_iter + 1 < max_iter:     # (the last iteration's loss decides nothing: n_iter + 1 is returned either way)
+                            eng.checkpoint_begin()
+                            pending = n_iter
+                        continue
                     loss = _sqrt2(eng.divergence())
-                    if not warned and getattr(eng, 'left_f16_range', None) is not None and eng.left_f16_range():
-                        import warnings
-                        warned = True
-                        warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during the fit; its fp16 "
-                                      "operand image is clamped from here on and the updates no longer follow the "
-                                      "reference.  Re-run with precision='bf16x3' (or rescale V).")
+                    left = getattr(eng, 'left_f16_range', None) is not None and not warned and eng.left_f16_range()
                     if pbar is not None:
                         pbar.set_postfix(loss=loss)
                         pbar.update(10)
-                    if (previous - loss) / loss_init < tol:
+                    if judge(loss, left):
                         break
-                    previous = loss
+            if pending is not None:                   # max_iter reached with one checkpoint still unjudged
+                stopped_at = settle()
+                if stopped_at is not None:
+                    n_iter = stopped_at
             # fits shorter than ten iterations never reach a checkpoint: ask once more at the end
             if not warned and getattr(eng, 'left_f16_range', None) is not None and eng.left_f16_range():
-                import warnings
-                warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during the fit; its fp16 operand "
-                              "image was clamped and the updates no longer follow the reference.  Re-run with "
-                              "precision='bf16x3' (or rescale V).")
+                range_warning()
         finally:
             if pbar is not None:
                 pbar.close()

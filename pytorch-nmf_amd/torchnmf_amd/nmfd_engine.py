@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _capi
-from .engine import _ptr, mu_gamma
+from .engine import AsyncLossMixin, _ptr, mu_gamma
 
 
 def _pad128(n: int) -> int:
@@ -73,7 +73,7 @@ def tail_round_split(mt: int, nt: int, slots: int, k_tiles: int, want: str = '1'
     return rows, split
 
 
-class ConvMU:
+class ConvMU(AsyncLossMixin):
     """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
 
     F16_MIN_DIM = 1024       # 'auto' -> 'f16' from this size on (every contraction at least this long)
@@ -413,13 +413,25 @@ class ConvMU:
             return False
         return bool(torch.maximum(self.W.max(), self.H.max()).item() > 65504.0)
 
-    def divergence(self) -> float:
-        """beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401).  One host sync."""
+    def _loss_device(self):
+        """Enqueue beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401); the value as a float64[1] device tensor."""
         self._gemm(self.wm, self.hu, _capi.EPI_LOSS, x=self.x_w, out=self.loss_part, m_valid=self.C,
                    n_valid=self.B * self.L, m_rows=self.c_main if self.ragged else None)
         if self.ragged:
             self._ragged(2, self.x_w)
-        return float(self.loss_part.double().sum().item())
+        return self.loss_part.double().sum().reshape(1)
+
+    def _range_flag_device(self):
+        if self.precision != _capi.PREC_F16:
+            return None
+        return (torch.maximum(self.W.max(), self.H.max()) > 65504.0).double().reshape(1)
+
+    def _ckpt_tensors(self):
+        return [self.W, self.H]
+
+    def divergence(self) -> float:
+        """One host sync."""
+        return float(self._loss_device().item())
 
 
 class WideRankMU:

@@ -192,6 +192,37 @@ def test_fit_loop_early_stop_matches_reference(cpu_engine, beta):
     assert rel_err(m.W.data, g[f'b{beta}_W']) < 5e-6 and rel_err(m.H.data, g[f'b{beta}_H']) < 5e-6
 
 
+@pytest.mark.parametrize('beta', [1, 2])     # (G3's beta = 0.5 run never stops within its 200 iterations)
+def test_fit_loop_async_checkpoints_equal_the_synchronous_loop(cpu_engine, beta, monkeypatch):
+    """Round 4: the loss checkpoints of fit() are judged one checkpoint late (no host sync in the loop) and a stop is
+    rolled back to the snapshot of its checkpoint.  Count and factors must equal the synchronous loop's bit for bit --
+    when the stop rule fires (golden G3), when max_iter ends the loop with a checkpoint still unjudged (max_iter just past
+    the stopping checkpoint: the pending one must still stop the fit there), and when it never fires."""
+    from torchnmf_amd import engine
+    g = load_golden('g3_early_stop')
+    n_stop = int(g[f'b{beta}_n_iter'])
+    assert n_stop % 10 == 0 and n_stop >= 20
+    calls = {'begin': 0, 'rollback': 0}
+    for name in ('checkpoint_begin', 'rollback'):
+        orig = getattr(engine.AsyncLossMixin, name)
+        monkeypatch.setattr(engine.AsyncLossMixin, name,
+                            (lambda o, k: lambda self: (calls.__setitem__(k, calls[k] + 1), o(self))[1])(orig, name.split('_')[-1]))
+    for max_iter, tol in [(200, 1e-4), (n_stop + 3, 1e-4), (n_stop + 10, 1e-4), (n_stop - 5, 1e-4), (40, -1e9)]:
+        out = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('TORCHNMF_AMD_ASYNC_LOSS', mode)
+            calls.update(begin=0, rollback=0)
+            m = NMF(W=t(g['W0']), H=t(g['H0']))
+            n = m.fit(t(g['V']), beta, tol, max_iter)
+            out[mode] = (n, m.W.data.clone(), m.H.data.clone(), dict(calls))
+        (na, Wa, Ha, ca), (ns, Ws, Hs, cs) = out['1'], out['0']
+        assert na == ns == (min(n_stop, max_iter) if tol > 0 else max_iter), (max_iter, na, ns)
+        assert torch.equal(Wa, Ws) and torch.equal(Ha, Hs), max_iter
+        assert cs == {'begin': 0, 'rollback': 0}
+        assert ca['rollback'] == (1 if (tol > 0 and max_iter >= n_stop + 1) else 0), (max_iter, ca)
+        assert ca['begin'] >= 1
+
+
 @pytest.mark.parametrize('name,tW,tH', [('frozenW', False, True), ('frozenH', True, False)])
 def test_fit_loop_respects_frozen_factors(cpu_engine, name, tW, tH):
     g = load_golden('g4_frozen')
