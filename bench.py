@@ -51,9 +51,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', default=None, choices=['cfg1', 'cfg5'],
+    ap.add_argument('--config', default=None, choices=['cfg1', 'cfg5', 'cfg5full'],
                     help="dense-NMF preset: cfg1 = BASELINE configs[1] (4096x65536 r128; default at 1 GPU), cfg5 = configs[4]'s "
-                         "per-GPU shard (8192x262144 r256; default when --gpus > 1)")
+                         "per-GPU shard (8192x262144 r256; default when --gpus > 1), cfg5full = ALL of configs[4] "
+                         "(8192x2097152 r256, 64 GiB of packed V) on ONE GPU: the strong-scaling denominator of the 8-GPU run")
     ap.add_argument('--rows', type=int, default=None)
     ap.add_argument('--cols', type=int, default=None, help='columns PER GPU')
     ap.add_argument('--rank', type=int, default=None)
@@ -84,6 +85,8 @@ def parse():
                     help="betamu: the closure returns m() (reconstruction written out, as in the reference's tests) "
                          "instead of the layer itself")
     ap.add_argument('--force-dist', action='store_true', help='run the sharded (all-reduce) path even at world size 1')
+    ap.add_argument('--gram', action='store_true', help="--beta 2 only: time fit()'s path without reconstruction (X @ panel + Gram "
+                    'matrix) instead of the 12*N*C*R kernel')
     ap.add_argument('--telemetry-s', type=float, default=0.8, help='seconds of back-to-back iterations (untimed, after the '
                     'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
                     'into roofline.clock_mhz / power_w (0 disables)')
@@ -378,6 +381,10 @@ def nmfd_line(a, sub=False):
     spans = eng.timer.spans()
     eng.timer.close()
     eng.timer = None
+    tel = SmiSampler(0).under_load(step, a.telemetry_s) if a.telemetry_s > 0 else None
+    fit_obj = None
+    if a.workload == 'nmfd' and beta == 1:      # what the user calls: NMFD.fit end to end (200 iterations, 20 loss checkpoints)
+        fit_obj = fit_leg(a, V, Wc, Hc, beta, a.precision, dev, ms, cls_name='NMFD')
     gflop = 2.0 * Cc * L * R * T
     per_gemm = {k: {'avg_launch_ms': round(sum(v) / len(v), 5),
                     'frac': round(gflop / (sum(v) / len(v) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in spans.items()}
@@ -429,9 +436,11 @@ def nmfd_line(a, sub=False):
                      'kernel': 'nmfmu::nt_gemm_kernel (mean over the GEMM launches of an iteration: reconstruction + ratio of both '
                                'half-steps, W numerator, H numerator with the fold epilogue)',
                      'avg_launch_ms': round(gemm_ms, 5), 'per_gemm': per_gemm,
+                     'clock_mhz': tel.get('clock_mhz') if tel else None, 'power_w': tel.get('power_w') if tel else None,
+                     'telemetry': tel,
                      'note': 'bf16x3 issues 3 MFMAs per algorithmic product: hardware MFMA rate is 3x achieved'
                      if a.precision == 'bf16x3' else ''},
-        'cpu_baseline': cpu, 'parity': parity, 'parity_mode': pm}
+        'cpu_baseline': cpu, 'parity': parity, 'parity_mode': pm, 'fit': fit_obj}
 
 
 def main_nmfd(a):
@@ -582,13 +591,16 @@ def main_plca(a):
         'cpu_baseline': cpu}))
 
 
-def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, betamu=False, blocks_min=None, telemetry=False):
+def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, betamu=False, blocks_min=None, telemetry=False,
+              gram=False):
     """W warm-up steps, an untimed pre-roll, then blocks of exactly K steps, each bracketed by barrier + synchronize; the
     block time is the MAX over ranks, the reported ms/step the median of the settled blocks.  Returns a dict."""
     from torchnmf_amd.engine import DenseMU, KernelTimer
     N, C = V.shape
     R = W0.shape[1]
     flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R     # SURVEY.md 8d: 4 (6) contractions of 2NCR
+    if gram and beta == 2:
+        flops_per_iter_gpu = 4.0 * N * C * R                         # executed: two X @ panel GEMMs (never priced as 12 N C R)
     W, H = W0.clone(), H0.clone()
     if betamu:
         # SURVEY.md 8(f1): trainer.BetaMu.step(closure) on one NMF layer; one step = W update + H update
@@ -607,7 +619,8 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         step()
         eng = next(iter(trainer._engines.values()))[0]
     else:
-        eng = DenseMU(V, W, H, beta, precision=precision, group=group, block_rows=a.block_rows)
+        eng = DenseMU(V, W, H, beta, precision=precision, group=group, block_rows=a.block_rows, allow_gram=gram)
+        assert eng.gram_path == (gram and beta == 2 and not (precision == 'f16x' and R > 128))
 
         def step():
             eng.w_step()
@@ -694,12 +707,12 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
     return out
 
 
-def parity_leg(a, V, W0, H0, Vc, beta, precision, Wr, Hr, k, dev):
+def parity_leg(a, V, W0, H0, Vc, beta, precision, Wr, Hr, k, dev, gram=False):
     """k MU iterations from the same (V, W0, H0) as the CPU reference leg, compared factor by factor."""
     from torchnmf_amd.engine import DenseMU
     N, C = V.shape
     W, H = W0.clone(), H0.clone()
-    eng = DenseMU(V, W, H, beta, precision=precision)
+    eng = DenseMU(V, W, H, beta, precision=precision, allow_gram=gram)
     for _ in range(k):
         eng.w_step()
         eng.h_step()
@@ -726,12 +739,12 @@ def parity_leg(a, V, W0, H0, Vc, beta, precision, Wr, Hr, k, dev):
     return d
 
 
-def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms):
+def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms, cls_name='NMF'):
     """What the user calls: NMF.fit(V, beta, tol -> never stops, max_iter = 200) end to end -- engine
     construction (packing V twice, validation), the initial loss, 200 iterations with the 20 loss evaluations + host syncs of
     nmf.py:393-407 -- wall clock, next to the engine-step figure of the headline."""
-    from torchnmf_amd.nmf import NMF
-    m = NMF(W=W0, H=H0).to(dev)
+    from torchnmf_amd import nmf as _nmf
+    m = getattr(_nmf, cls_name)(W=W0, H=H0).to(dev)
 
     def run(max_iter):
         m.W.data.copy_(W0)
@@ -750,7 +763,7 @@ def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms):
         walls.append(w)
     wall = sorted(walls)[1]
     loop = wall - setup
-    return {'call': f"NMF.fit(V, beta={beta:g}, tol=-1e9, max_iter=200" + ("" if precision is None else f", precision='{precision}'") + ")",
+    return {'call': f"{cls_name}.fit(V, beta={beta:g}, tol=-1e9, max_iter=200" + ("" if precision is None else f", precision='{precision}'") + ")",
             'iterations': 200,
             'wall_ms': round(wall, 3), 'wall_ms_runs': [round(x, 3) for x in walls], 'setup_ms': round(setup, 3),
             'iters_per_s_whole_call': round(200e3 / wall, 1), 'iters_per_s_loop': round(200e3 / loop, 1),
@@ -825,13 +838,19 @@ def main():
     # target is quoted on -- every rank owns an 8192 x 262144 column shard at rank 256 (weak scaling).  Explicit
     # --rows / --cols / --rank override the preset.
     preset = a.config or ('cfg5' if world > 1 else 'cfg1')
-    pr = {'cfg1': (4096, 65536, 128), 'cfg5': (8192, 262144, 256)}[preset]
+    pr = {'cfg1': (4096, 65536, 128), 'cfg5': (8192, 262144, 256), 'cfg5full': (8192, 2097152, 256)}[preset]
     N = a.rows if a.rows is not None else pr[0]
     C = a.cols if a.cols is not None else pr[1]
     R = a.rank if a.rank is not None else pr[2]
     beta = a.beta
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()   # bf16-representable U[0,1): exact in fp16 too
+    if N * C > (1 << 32):
+        # (cfg5full: 64 GiB of fp32 -- drawn in column chunks so that the temporaries stay small; same law)
+        V = torch.empty(N, C, device=dev)
+        for c0 in range(0, C, 65536):
+            V[:, c0:c0 + 65536] = torch.rand(N, min(65536, C - c0), device=dev, generator=g).bfloat16().float()
+    else:
+        V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()   # bf16-representable U[0,1): exact in fp16 too
     if beta <= 0:
         V.clamp_(min=2.0 ** -7)                                        # strictly positive for beta <= 0 (nmf.py:332-336)
     gw = torch.Generator(device=dev).manual_seed(2000 + rank)
@@ -842,7 +861,8 @@ def main():
     betamu = a.workload == 'betamu'
     flops_per_iter_gpu = (8.0 if beta == 1 else 12.0) * N * C * R
 
-    head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu, telemetry=True)
+    head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu, telemetry=True,
+                     gram=a.gram and beta == 2 and world == 1)
     # secondary, clearly labelled object: the other single-plane operand type, timed in the same run
     other = {'f16': 'bf16', 'bf16': 'f16'}.get(a.precision)
     second = None
@@ -881,17 +901,40 @@ def main():
                       'flops_per_iteration': '12*N*C*R (6 contractions, as the reference computes them)', 'betas': {}}
         for b in (2.0, 0.5, 0.0):
             Vb = V.clamp(min=2.0 ** -7) if b <= 0 else V
-            leg = dense_leg(a, Vb, W0, H0, b, a.precision, None, 1, dev, True, blocks_min=3)
+            leg = dense_leg(a, Vb, W0, H0, b, a.precision, None, 1, dev, True, blocks_min=3, telemetry=True)
             ent = {'iters_per_s': round(1e3 / leg['ms_per_step'], 2), 'ms_per_step': round(leg['ms_per_step'], 4),
                    'value': round(leg['gflops'], 1), 'unit': 'GFLOP/s', 'blocks_ms_per_step': leg['blocks_ms_per_step'],
                    'kernel': leg['roofline']['kernel'], 'kernel_frac': leg['roofline']['frac'],
-                   'kernel_avg_launch_ms': leg['roofline']['avg_launch_ms'], 'kernel_tflops': leg['roofline']['achieved']}
+                   'kernel_avg_launch_ms': leg['roofline']['avg_launch_ms'], 'kernel_tflops': leg['roofline']['achieved'],
+                   'clock_mhz': leg['roofline'].get('clock_mhz'), 'power_w': leg['roofline'].get('power_w')}
             del leg
+            gleg = None
+            if b == 2.0:
+                # what fit() runs for beta == 2 (round 4): no reconstruction -- numerator X @ panel (one streaming MFMA GEMM),
+                # denominator owner @ (panel^T panel).  4 N C R flops executed per iteration; HBM-bound on the X stream, so it
+                # is priced against the HBM roofline -- the 12 N C R kernel above stays the MFMA-roofline line of configs[2].
+                gleg = dense_leg(a, Vb, W0, H0, b, a.precision, None, 1, dev, True, blocks_min=3, gram=True, telemetry=True)
+                rf = gleg['roofline']
+                ent['gram_path'] = {
+                    'what': 'NMF.fit(beta=2): num = X @ panel (kModeXB, one pass over X), den = owner @ (panel^T panel) via the MFMA '
+                            'Gram kernel; no N x C reconstruction (nmf.py:61-63 puts no eps inside its grad_outputs)',
+                    'iters_per_s': round(1e3 / gleg['ms_per_step'], 2), 'ms_per_step': round(gleg['ms_per_step'], 4),
+                    'blocks_ms_per_step': gleg['blocks_ms_per_step'],
+                    'flops_executed_per_iteration': '4*N*C*R (two X @ panel GEMMs) + 4*(N+C)*R*R (Gram matrices and owner @ G)',
+                    'kernel': 'nmfmu::fused_kernel<.., kEuc, .., kModeXB>', 'kernel_avg_launch_ms': rf['avg_launch_ms'],
+                    'kernel_avg_launch_ms_w_step': rf['avg_launch_ms_w_step'], 'kernel_avg_launch_ms_h_step': rf['avg_launch_ms_h_step'],
+                    'roofline': {'bound': 'hbm', 'achieved': rf['hbm']['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': rf['hbm']['frac'], 'algorithmic_bytes_per_launch': rf['hbm']['algorithmic_bytes_per_launch']},
+                    'speedup_over_12NCR_kernel': round(ent['ms_per_step'] / gleg['ms_per_step'], 3),
+                    'clock_mhz': rf.get('clock_mhz'), 'power_w': rf.get('power_w')}
+                del gleg
             if do_cpu:
                 k = 3
                 Vbc = Vc.clamp(min=2.0 ** -7) if b <= 0 else Vc
                 Wr, Hr = aten_port.mu_iterations(Vbc, W0.cpu(), H0.cpu(), b, k)
                 ent['parity'] = dict(k=k, **parity_leg(a, Vb, W0, H0, Vbc, b, a.precision, Wr, Hr, k, dev))
+                if b == 2.0:
+                    ent['gram_path']['parity'] = dict(k=k, **parity_leg(a, Vb, W0, H0, Vbc, b, a.precision, Wr, Hr, k, dev, gram=True))
                 del Vbc
             del Vb
             beta_sweep['betas'][f'{b:g}'] = ent
@@ -902,7 +945,7 @@ def main():
             na.cpu_iters = 0
         line = nmfd_line(na, sub=True)
         nmfd = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
-                                     'roofline', 'parity', 'cpu_baseline')}
+                                     'roofline', 'parity', 'cpu_baseline', 'fit')}
 
     # ---- fit(): the call a torchnmf user makes, end to end; real_data_mode: a target fp16 does NOT hold exactly
     fit_obj, real = None, None

@@ -38,7 +38,8 @@ extern "C" {
                                   NMFMU_STAGE_REG and the 256 x 256 GEMM tile no longer built; nmfmu_step.status;
                                5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported,
                                   nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables;
-                               6: NMFMU_PREC_F16X (fp16 operands, fp32 target) */
+                               6: NMFMU_PREC_F16X (fp16 operands, fp32 target); nmfmu_gram_panel / nmfmu_xb_* (beta == 2 without
+                                  the reconstruction); NMFMU_ERR_ALLOC */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -153,6 +154,27 @@ int nmfmu_den_partial(const nmfmu_step* st, void* stream);
  * kl_den: column sums of the panel (beta == 1), else ignored.  phase: 0 = everything, 1 = only the fused kernel,
  * 2 = only what follows it (lets a caller bracket the dominant kernel with events). */
 int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream);
+
+/* beta == 2 WITHOUT the reconstruction (round 4).  The reference's beta == 2 branch (nmf.py:61-63) puts no eps inside the
+ * two grad_outputs, so the update's numerator is X @ panel exactly and its denominator owner @ (panel^T panel): one
+ * streaming MFMA GEMM over X (4 N C R flops per iteration instead of 12 N C R, HBM-bound) plus a rank x rank Gram matrix.
+ *   nmfmu_gram_panel : G = panel^T panel from the panel's transposed 16-bit image (MFMA, fp32 accumulate, deterministic
+ *                      two-stage sum).  Outputs: gram [r_pad][r_pad] fp32 (zero in the padding); g_hi / g_lo 16-bit
+ *                      images of row r scaled by 2^-e[r] (inside fp16's range), g_scale[r] = 2^e[r].  ws: nmfmu_gram_ws_bytes.
+ *   nmfmu_xb_partial : numerator slabs only (st->slab_num; st->slab_den is not touched) -- for callers that reduce across
+ *                      devices before the apply.
+ *   nmfmu_xb_step    : the complete half-step; phase as in nmfmu_mu_step.  The denominator is one more small MFMA product
+ *                      (owner fragments x Gram image rows) inside the same kernel.  Unsplit contraction and padded rank
+ *                      <= 128: everything in one kernel (nmf.py:78-92 in its epilogue); otherwise st->nsplit numerator slabs
+ *                      + ONE denominator slab in st->slab_den (owner_rows_pad x r_pad floats suffice) + the apply kernel.
+ * Single-plane precisions only (NMFMU_PREC_BF16 / F16 / F16X; with F16X the fp32 target enters the GEMM as an fp16
+ * hi + lo pair). */
+int nmfmu_xb_supported(int r_pad, int precision, float beta);
+size_t nmfmu_gram_ws_bytes(int r_pad);
+int nmfmu_gram_panel(const nmfmu_factor* panel, int r_pad, int precision, void* ws, float* gram, void* g_hi, void* g_lo,
+                     float* g_scale, void* stream);
+int nmfmu_xb_partial(const nmfmu_step* st, void* stream);
+int nmfmu_xb_step(const nmfmu_step* st, const void* g_hi, const void* g_lo, const float* g_scale, int phase, void* stream);
 
 /* Column-sum bookkeeping (nmf.py:122-131's H.sum / W.sum, deterministic two-stage sums): the number of partial sums
  * [nparts][r_pad] a half-step (nmfmu_colsum_nparts) or nmfmu_pack_factor (nmfmu_pack_nparts) leaves in colsum_part, and
@@ -467,6 +489,11 @@ int nmfmu_comm_allreduce_sum_f32(nmfmu_comm* comm, float* buf, size_t count, voi
 int nmfmu_comm_allreduce_sum_f32_multi(nmfmu_comm* const* comms, float* const* bufs, size_t count, void* const* streams,
                                        int ndev);
 int nmfmu_comm_destroy(nmfmu_comm* comm);
+/* The column-sharded H half-step in one host call: nmfmu_mu_partial -> nmfmu_slab_reduce into xbuf =
+ * [numerator owner_rows_pad x r_pad | beta == 1: the panel shard's column sums, r_pad floats; else the denominator,
+ * owner_rows_pad x r_pad] -> ONE all-reduce of the whole buffer -> nmfmu_mu_apply(nslab = 1) -- enqueued back to back on
+ * `stream`; relu / eps / regularisers are applied after the sum, as nmf.py:78-92 does on the unsharded matrix. */
+int nmfmu_mu_step_allreduce(const nmfmu_step* st, nmfmu_comm* comm, float* xbuf, void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------------------------
  * hipEvent-based timers on the caller's stream (bench.py uses them to time the dominant kernel live). */

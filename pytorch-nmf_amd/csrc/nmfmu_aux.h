@@ -27,6 +27,8 @@ struct ApplyArgs {
   float* grad;          // [rows][rank] or nullptr
   int f16;              // images in fp16 (clamped to 65504) instead of bf16; no lo planes
   uint32_t* status;     // or nullptr: bit 0 is set when an fp16 image value had to be clamped
+  int den_nslab;        // slabs of `den` when it differs from nslab (kModeXB leaves ONE denominator slab); 0 = nslab
+  int skip_colsum;      // do not launch the column-sum finalize (beta == 2: nothing reads the column sums)
 };
 
 int apply_stripe_rows(int rows_pad);   // rows per apply workgroup (= rows per column-sum partial): 16 or 64

@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
           pos[0] = d4.x, pos[1] = d4.y, pos[2] = d4.z, pos[3] = d4.w;
         } else {
           float4 d4 = *reinterpret_cast<const float4*>(a.den + e);
-          for (int s = 1; s < a.nslab; ++s) {
+          const int dslab = a.den_nslab > 0 ? a.den_nslab : a.nslab;
+          for (int s = 1; s < dslab; ++s) {
             const float4 v = *reinterpret_cast<const float4*>(a.den + s * plane + e);
             d4.x += v.x, d4.y += v.y, d4.z += v.z, d4.w += v.w;
           }
@@ -285,7 +286,7 @@ int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) 
   else L(false, false)
 #undef L
   int e = (int)hipGetLastError();
-  if (e) return e;
+  if (e || a.skip_colsum) return e;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(R_PAD / 32), dim3(256), 0, s, a.colsum_part, grid, R_PAD, a.colsum);
   return (int)hipGetLastError();
 }

@@ -46,10 +46,17 @@ static int kernel_beta_kind(float beta) {
   return nmfmu_beta_kind(beta);
 }
 
+struct GramRef {   // Gram matrix of the panel (nmfmu_gram_panel): fp32 matrix + 16-bit images with per-row scales
+  const float* gram;
+  const void* hi;
+  const void* lo;
+  const float* scale;
+};
+
 int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int K, hipStream_t s,
-                   const float* fuse_kl_den = nullptr, bool fuse_apply = false) {
+                   const float* fuse_kl_den = nullptr, bool fuse_apply = false, const GramRef* gm = nullptr) {
   if (!st || !st->owner.p1_hi || !st->panel.p1_hi) return NMFMU_ERR_ARG;
-  if (!st->xp && mode == kModeMU) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
+  if (!st->xp && (mode == kModeMU || mode == kModeXB)) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
   if (st->stage != NMFMU_STAGE_DMA) return NMFMU_ERR_UNSUPPORTED;   // the register-staged variant is no longer built
@@ -88,7 +95,18 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     a.colsum_part = st->owner.colsum_part;
     a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   }
-  if (mode == kModeMU || mode == kModeDen) {
+  if (mode == kModeXB) {   // beta == 2 without reconstruction: numerator slabs only (or the fused apply with the Gram images)
+    if (kind != kEuc || x3 || st->block_rows != 128) return NMFMU_ERR_UNSUPPORTED;
+    if (!a.p2_hi || (!fuse_apply && !a.slab_num)) return NMFMU_ERR_ARG;
+    if (fuse_apply && (!gm || st->r_pad > 128)) return NMFMU_ERR_ARG;
+    if (gm) {   // denominator in the kernel: fused apply, or ONE denominator slab written by the ks == 0 workgroups
+      if (!gm->hi || !gm->lo || !gm->scale || (!fuse_apply && !a.slab_den)) return NMFMU_ERR_ARG;
+      a.gram_hi = static_cast<const uint16_t*>(gm->hi), a.gram_lo = static_cast<const uint16_t*>(gm->lo);
+      a.gram_scale = gm->scale;
+    } else {
+      a.slab_den = nullptr;   // numerator slabs only (nmfmu_xb_partial)
+    }
+  } else if (mode == kModeMU || mode == kModeDen) {
     if (!a.slab_num || !a.p2_hi || (x3 && !a.p2_lo)) return NMFMU_ERR_ARG;
     if (mode == kModeMU && kind != kKL && !a.slab_den) return NMFMU_ERR_ARG;
     if (mode == kModeDen && (kind != kGen || st->block_rows != 128)) return NMFMU_ERR_UNSUPPORTED;
@@ -279,7 +297,7 @@ int nmfmu_slab_reduce(const nmfmu_step* st, float* num_out, float* den_out, void
 }
 
 static int apply_common(const nmfmu_step* st, const float* num, const float* den, int nslab, const float* kl_den,
-                        int trainer, float ortho, float* grad, void* stream) {
+                        int trainer, float ortho, float* grad, void* stream, int den_nslab = 0, int skip_colsum = 0) {
   if (!st || !st->owner.f) return NMFMU_ERR_ARG;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   ApplyArgs a{};
@@ -289,6 +307,8 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.nslab = num ? nslab : st->nsplit;
   a.kl_den = kl ? kl_den : nullptr;
   if (!a.num || a.nslab < 1) return NMFMU_ERR_ARG;
+  a.den_nslab = den_nslab;
+  a.skip_colsum = skip_colsum;
   if (kl ? !a.kl_den : !a.den) return NMFMU_ERR_ARG;
   a.p1_hi = st->owner.p1_hi, a.p1_lo = st->owner.p1_lo, a.p2_hi = st->owner.p2_hi, a.p2_lo = st->owner.p2_lo;
   a.colsum_part = st->owner.colsum_part, a.colsum = st->owner.colsum;
@@ -310,6 +330,64 @@ int nmfmu_trainer_apply(const nmfmu_step* st, const float* num, const float* den
                         float ortho, float* grad, void* stream) {
   if (!(ortho >= 0.f)) return NMFMU_ERR_ARG;
   return apply_common(st, num, den, nslab, kl_den, 1, ortho, grad, stream);
+}
+
+int nmfmu_xb_supported(int r_pad, int precision, float beta) {
+  if (nmfmu_beta_kind(beta) != NMFMU_BETA_EUC) return 0;
+  if (r_pad != 32 && r_pad != 64 && r_pad != 128 && r_pad != 256) return 0;
+  if (precision == NMFMU_PREC_F16X) return r_pad <= 128;   // (three fp32 X buffers + rank-256 accumulators: no registers)
+  return precision == NMFMU_PREC_BF16 || precision == NMFMU_PREC_F16;
+}
+
+int nmfmu_xb_partial(const nmfmu_step* st, void* stream) {
+  if (!st) return NMFMU_ERR_ARG;
+  if (!nmfmu_xb_supported(st->r_pad, st->precision, st->beta)) return NMFMU_ERR_UNSUPPORTED;
+  return fused_dispatch(st, kModeXB, nullptr, st->owner.rows, st->panel.rows, S(stream));
+}
+
+int nmfmu_xb_step(const nmfmu_step* st, const void* g_hi, const void* g_lo, const float* g_scale, int phase, void* stream) {
+  if (!st || !g_hi || !g_lo || !g_scale || phase < 0 || phase > 2) return NMFMU_ERR_ARG;
+  if (!nmfmu_xb_supported(st->r_pad, st->precision, st->beta)) return NMFMU_ERR_UNSUPPORTED;
+  // the workgroup owns whole rows (unsplit contraction): numerator, denominator (owner fragments x Gram image) and
+  // nmf.py:78-92 in the kernel's epilogue; otherwise nsplit numerator slabs + ONE denominator slab (written by the first
+  // workgroup of every row block, the same MFMA product) + the apply kernel
+  const bool fuse = st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum && st->owner.colsum_part &&
+                    st->r_pad <= 128;
+  if (!fuse && !st->slab_den) return NMFMU_ERR_ARG;
+  const GramRef gm{nullptr, g_hi, g_lo, g_scale};
+  int e = 0;
+  if (phase != 2) {
+    e = fused_dispatch(st, kModeXB, nullptr, st->owner.rows, st->panel.rows, S(stream), nullptr, fuse, &gm);
+    if (e) return e;
+  }
+  // (no column-sum finalize on this path: beta == 2 reads neither the closed-form denominators nor the fp16 scale)
+  if (phase != 1 && !fuse)
+    e = apply_common(st, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, stream, /*den_nslab=*/1, /*skip_colsum=*/1);
+  return e;
+}
+
+int nmfmu_mu_step_allreduce(const nmfmu_step* st, nmfmu_comm* comm, float* xbuf, void* stream) {
+  // The column-sharded H half-step of SURVEY 8(e) as ONE host call: partial sums -> slab reduction into the packed buffer
+  // [numerator M_pad x R_PAD | panel column sums R_PAD (beta == 1) or denominator M_pad x R_PAD] -> ONE RCCL all-reduce
+  // -> apply -- all enqueued back to back on the caller's stream, so the host never returns to its interpreter between
+  // the kernel and the collective (the torch.distributed route costs a Python / c10d round trip and two stream hops there).
+  if (!st || !comm || !xbuf) return NMFMU_ERR_ARG;
+  const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
+  const size_t plane = (size_t)st->owner.rows_pad * st->r_pad;
+  const size_t tail = kl ? (size_t)st->r_pad : plane;
+  if (kl && !st->panel.colsum) return NMFMU_ERR_ARG;
+  int e = nmfmu_mu_partial(st, stream);
+  if (e) return e;
+  e = nmfmu_slab_reduce(st, xbuf, kl ? nullptr : xbuf + plane, stream);
+  if (e) return e;
+  if (kl) {
+    hipError_t he = hipMemcpyAsync(xbuf + plane, st->panel.colsum, st->r_pad * sizeof(float), hipMemcpyDeviceToDevice, S(stream));
+    if (he != hipSuccess) return (int)he;
+  }
+  e = nmfmu_comm_allreduce_sum_f32(comm, xbuf, plane + tail, stream);
+  if (e) return e;
+  return kl ? nmfmu_mu_apply(st, xbuf, nullptr, 1, xbuf + plane, stream)
+            : nmfmu_mu_apply(st, xbuf, xbuf + plane, 1, nullptr, stream);
 }
 
 int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit) {

@@ -60,6 +60,7 @@
 #define NMFMU_FUSED_G1_ASM 1
 #endif
 
+
 namespace nmfmu {
 
 constexpr float kEps = 1.1920928955078125e-07f;  // constants.py:3 of the reference
@@ -68,7 +69,12 @@ constexpr float kEps = 1.1920928955078125e-07f;  // constants.py:3 of the refere
 enum BetaKind : int { kKL = 0, kEuc = 1, kIS = 2, kGen = 3, kSqrt = 4, kSqrt3 = 5 };
 // kModeDen: the positive term alone, den = Gp(S) @ panel with no target at all (sparse targets with a generic beta:
 // the reference's dense pass of nmf.py:628-636).  The loss mode also runs without a target (xp == nullptr: X = 0).
-enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2 };
+// kModeXB (round 4): beta == 2 without the reconstruction.  nmf.py:61-63 puts no eps inside the two grad_outputs, so the
+// numerator is X @ panel exactly -- ONE streaming MFMA GEMM over X, no S tiles, no elementwise stage -- and the denominator
+// owner @ (panel^T panel) needs only the rank x rank Gram matrix (nmfmu_gram_panel): in the fused-apply epilogue it is one
+// more small MFMA product per workgroup (owner fragments x Gram image), otherwise the apply kernel forms it from the fp32
+// master.  4*N*C*R flops per iteration instead of 12*N*C*R; HBM-bound on the X stream.
+enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2, kModeXB = 3 };
 enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2, kPrecF16X = 3 };   // = NMFMU_PREC_* of include/nmfmu.h
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -118,6 +124,11 @@ struct FusedArgs {
   // fp16 operands, beta < 1: column sums of owner and panel ([R_PAD] each) -> typical S -> power-of-two scale of Gn / Gp
   const float* cs_owner;
   const float* cs_panel;
+  // kModeXB, fused apply: Gram matrix of the panel as 16-bit images [R_PAD][R_PAD] (row r = column r of the symmetric
+  // matrix, scaled by 2^-gram_exp[r] so that it sits inside fp16's range; lo plane = the rounding remainder of hi)
+  const uint16_t* gram_hi;
+  const uint16_t* gram_lo;
+  const float* gram_scale;   // [R_PAD]: 2^gram_exp[r], multiplied back onto the denominator column r
   uint32_t* status;       // or nullptr: bit 0 is set when the fused apply had to clamp an fp16 image value at 65504
   void* debug;            // NMFMU_DEBUG_HOOKS builds: clock stamps of the ping-pong kernel (tools/pp_timeline.py)
 };
@@ -135,25 +146,35 @@ struct FusedCfg {
   static constexpr int NPL = X3 ? 2 : 1;     // planes (hi / lo)
   static constexpr bool LOSS = MODE == kModeLoss;
   static constexpr bool DEN = MODE == kModeDen;
-  static constexpr int NIMG = (LOSS ? 1 : 2) * NPL;
+  static constexpr bool XB = MODE == kModeXB;   // numerator = X @ panel only (beta == 2); only the P2 image is staged
+  static constexpr int NIMG = ((LOSS || XB) ? 1 : 2) * NPL;
   static constexpr int P1HI = 0;
   static constexpr int P1LO = IMG;           // valid when X3
-  static constexpr int P2HI = NPL * IMG;
-  static constexpr int P2LO = NPL * IMG + IMG;
+  static constexpr int P2HI = XB ? 0 : NPL * IMG;
+  static constexpr int P2LO = P2HI + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
   static constexpr int NQ = XF32 ? 8 : 4;    // 16-byte X chunks per lane per tile
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
   // fp32 target as an fp16 MFMA operand (f16x, beta = 2: Gn = X): hi + lo pair, two MFMAs for the numerator product
-  static constexpr bool XSPLIT = PREC == kPrecF16X && BETA == kEuc && !LOSS && !DEN;
+  static constexpr bool XSPLIT = PREC == kPrecF16X && BETA == kEuc && !LOSS && !DEN;   // (kModeXB included)
   static constexpr bool GNLO = X3 || XSPLIT;                           // Gn has a low plane
   static constexpr int PASSES = IMG / 4096;  // 256 threads x 16 B per pass
   // fp16 operands: Gn / Gp of the branches with negative powers of S carry a power-of-two scale
   static constexpr bool SCALE = F16 && !LOSS && (BETA == kIS || BETA == kGen || BETA == kSqrt);
-  static constexpr int MINW = (X3 || TWO_ACC || R_PAD > 128) ? 1 : 2;
+  // DEEP: the HBM-bound kModeXB instances stream through a ring of NSTAGE LDS stages / register buffers with counted
+  // waits (NSTAGE - 1 tiles in flight behind the one being multiplied).  (The fp32-target mode 'f16x' was tried on the
+  // same loop with one workgroup per CU and three fp32 X buffers -- r4d: 1 975 vs 2 270-2 370 it/s on the generic loop with
+  // two workgroups per CU at beta = 1, 1 640 vs 1 690 at beta = 0.5; not kept.)
+  static constexpr bool DEEP = XB;
+  // workgroups per CU the register budget is sized for: the streaming kModeXB kernel wants two (bytes in flight)
+  static constexpr int MINW = XB ? (R_PAD <= 128 ? 2 : 1) : ((X3 || TWO_ACC || R_PAD > 128) ? 1 : 2);
   // GEMM1 as asm with VGPR constraints (see gemm1()): the single-plane instances that run one wave per SIMD
   static constexpr bool G1_ASM = NMFMU_FUSED_G1_ASM && !X3 && MINW == 1;
-  static constexpr int NSTAGE = 2;
-  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  // kModeXB streams: four (fp32 target: three) ring stages, tiles t+1 .. t+3 in flight behind tile t (counted waits); at padded rank 128 the
+  // ring is exactly as large as its epilogue's staging tile (4 waves x 32 rows x R_PAD floats)
+  static constexpr int NSTAGE = DEEP ? (XF32 ? 3 : 4) : 2;   // (fp32 X buffers are 32 registers each: three of them)
+  static constexpr int EPI_BYTES = XB ? WAVES * 32 * R_PAD * 4 : 0;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -305,6 +326,39 @@ __device__ __forceinline__ float loss_elem(float s, float x, float beta) {
   }
 }
 
+// ---- helpers of the kModeXB stream (free functions: every register-array index must be a compile-time constant -- an
+// un-unrolled `#pragma unroll` loop over an asm-loaded array demotes it to scratch memory, seen at padded rank 256)
+template <int NQ, int Q = 0>
+__device__ __forceinline__ void xb_load_x(const char* p, u32x4 (&x)[NQ]) {   // this lane's NQ 16-byte chunks of a tile, by asm
+  if constexpr (Q < NQ) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(x[Q]) : "v"(p + Q * 1024) : "memory");
+    xb_load_x<NQ, Q + 1>(p, x);
+  }
+}
+template <int NQ, int Q = 0>
+__device__ __forceinline__ void xb_tie(u32x4 (&x)[NQ]) {   // "these registers are written by the loads above"
+  if constexpr (Q < NQ) {
+    asm volatile("" : "+v"(x[Q]));
+    xb_tie<NQ, Q + 1>(x);
+  }
+}
+// the target IS the second GEMM's A operand: the stored 16-bit words as they are, or (fp32 target) an fp16 hi + lo pair
+template <bool XF32, bool GNLO, int OPT, int NQ, class G>
+__device__ __forceinline__ void xb_to_ops(const u32x4 (&x)[NQ], G& g) {
+  static_for<16>([&](auto ic) {
+    constexpr int tt = decltype(ic)::value >> 3, d = decltype(ic)::value & 7;
+    if constexpr (XF32) {
+      const uint32_t u0 = x[4 * tt + (d >> 1)][2 * (d & 1)], u1 = x[4 * tt + (d >> 1)][2 * (d & 1) + 1];
+      const float x0 = __builtin_bit_cast(float, u0), x1 = __builtin_bit_cast(float, u1);
+      const uint32_t nh = pack_op<OPT>(x0, x1);
+      g.gnh[tt][d] = nh;
+      if constexpr (GNLO) g.gnl[tt][d] = pack_op<OPT>(x0 - unpack_lo<OPT>(nh), x1 - unpack_hi<OPT>(nh));
+    } else {
+      g.gnh[tt][d] = x[2 * tt + (d >> 2)][d & 3];
+    }
+  });
+}
+
 template <int R_PAD, int BETA, int PREC, int MODE>
 __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)) fused_kernel(const FusedArgs a) {
   using C = FusedCfg<R_PAD, BETA, PREC, MODE>;
@@ -406,11 +460,16 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
 
   // ---- panel staging: every image tile is one contiguous, pre-swizzled block in HBM
   const char* img_src[C::NIMG];
-  img_src[0] = reinterpret_cast<const char*>(a.p1_hi);
-  if constexpr (X3) img_src[1] = reinterpret_cast<const char*>(a.p1_lo);
-  if constexpr (!C::LOSS) {
-    img_src[C::NPL] = reinterpret_cast<const char*>(a.p2_hi);
-    if constexpr (X3) img_src[C::NPL + 1] = reinterpret_cast<const char*>(a.p2_lo);
+  if constexpr (C::XB) {
+    img_src[0] = reinterpret_cast<const char*>(a.p2_hi);
+    if constexpr (X3) img_src[1] = reinterpret_cast<const char*>(a.p2_lo);
+  } else {
+    img_src[0] = reinterpret_cast<const char*>(a.p1_hi);
+    if constexpr (X3) img_src[1] = reinterpret_cast<const char*>(a.p1_lo);
+    if constexpr (!C::LOSS) {
+      img_src[C::NPL] = reinterpret_cast<const char*>(a.p2_hi);
+      if constexpr (X3) img_src[C::NPL + 1] = reinterpret_cast<const char*>(a.p2_lo);
+    }
   }
   const unsigned lds_base =
       __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
@@ -424,7 +483,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       const char* src = img_src[im] + (size_t)t * IMG + tid * 16;
 #pragma unroll
       for (int p = 0; p < C::PASSES; ++p) {
-        const unsigned lds_addr = lds_base + (unsigned)(stage_off + im * IMG + p * 4096) + wave_lds;
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage_off + im * IMG + p * 4096) + wave_lds);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                      :
                      : "v"(src + p * 4096), "s"(lds_addr)
@@ -615,7 +674,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         on[rt] = mfma_op<OPT>(nl, bh, on[rt]);
       }
       on[rt] = mfma_op<OPT>(nh, bh, on[rt]);
-      if constexpr (C::TWO_ACC) {
+      if constexpr (C::TWO_ACC && !C::XB) {
         const u32x4 ph = {g.gph[tt][4 * m2], g.gph[tt][4 * m2 + 1], g.gph[tt][4 * m2 + 2], g.gph[tt][4 * m2 + 3]};
         if constexpr (X3) {
           const u32x4 pl = {g.gpl[tt][4 * m2], g.gpl[tt][4 * m2 + 1], g.gpl[tt][4 * m2 + 2], g.gpl[tt][4 * m2 + 3]};
@@ -628,7 +687,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
-      __builtin_amdgcn_sched_group_barrier(0x008, X3 ? (C::TWO_ACC ? 6 : 3) : ((C::TWO_ACC ? 2 : 1) + (C::XSPLIT ? 1 : 0)), 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, X3 ? ((C::TWO_ACC && !C::XB) ? 6 : 3) : (((C::TWO_ACC && !C::XB) ? 2 : 1) + (C::XSPLIT ? 1 : 0)), 1);
       if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
     }
   };
@@ -637,7 +696,54 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0)
     __syncthreads();
   };
-  if (t0 < t1) {
+  if constexpr (C::DEEP) {
+    // ---------------- kModeXB: nothing but X @ panel (16 MFMAs per tile and wave).  HBM-bound and latency-sensitive, so
+    // the streams run deep: the panel's P2 tiles through an NSTAGE-slot LDS ring and X through NSTAGE register buffers,
+    // both NSTAGE - 1 tiles ahead, every load issued from inline asm with ONE counted wait per tile (tile t has landed when
+    // at most the loads of tiles t+1 .. t+NSTAGE-2 are outstanding; tile t+NSTAGE-1 is issued right behind that wait's
+    // barrier, into the stage / registers tile t-1 has just vacated).
+    if (t0 < t1) {
+      const int nt = t1 - t0;
+      constexpr int NST = C::NSTAGE;
+      constexpr int OPS = C::NIMG * C::PASSES + NQ;   // vm operations per tile and thread (LDS-DMA pieces + X chunks)
+      static_assert((NST - 2) * OPS <= 63, "vmcnt range");
+      u32x4 xr[NST][NQ];
+      auto load_x_asm = [&](int t, u32x4(&x)[NQ]) { xb_load_x<NQ>(xbase + (size_t)t * (4 * NQ * 1024), x); };
+      auto landed = [&](int later, u32x4(&x)[NQ]) {   // `later` tiles issued after this one may still be in flight
+        if (later >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPS) : "memory");
+        else if (later == 1 && NST > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xb_tie<NQ>(x);
+        __syncthreads();
+      };
+      auto to_ops = [&](const u32x4(&x)[NQ], GOps& g) { xb_to_ops<C::XF32, C::GNLO, OPT, NQ>(x, g); };
+      auto tile_step = [&](int i, auto bc) {   // tile i lives in ring slot / register buffer b = i % NST
+        constexpr int b = decltype(bc)::value, bn = (b + NST - 1) % NST;
+        landed(min(nt - 1 - i, NST - 2), xr[b]);
+        if (i + NST - 1 < nt) {
+          stage_issue(t0 + i + NST - 1, bn * C::STAGE_BYTES);
+          load_x_asm(t0 + i + NST - 1, xr[bn]);
+        }
+        GOps g;
+        to_ops(xr[b], g);
+        gemm2(smem + b * C::STAGE_BYTES, g);
+      };
+      static_for<NST - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if (d < nt) {
+          stage_issue(t0 + d, d * C::STAGE_BYTES);
+          load_x_asm(t0 + d, xr[d]);
+        }
+      });
+      int i = 0;
+      for (; i + NST <= nt; i += NST)
+        static_for<NST>([&](auto bc) { tile_step(i + decltype(bc)::value, bc); });
+      static_for<NST - 1>([&](auto bc) {
+        if (i + decltype(bc)::value < nt) tile_step(i + decltype(bc)::value, bc);
+      });
+      __syncthreads();   // the epilogue re-uses the ring as its staging tile
+    }
+  } else if (t0 < t1) {
     // ---------------- main loop: LDS double buffer for the panel, X in ONE register buffer that is refilled with the
     // next tile right after its last use; one drain + barrier per tile.
     u32x4 xc[NQ];
@@ -674,6 +780,29 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   } else {
     // accumulator register e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column 32*rt + j
     bool fused_done = false;
+    if constexpr (C::XB && !X3) {
+      // fused apply (unsplit contraction), or -- split contraction -- the ks == 0 workgroup of every row block leaves the
+      // denominator as ONE slab next to the nsplit numerator slabs (a.slab_den; the apply kernel then has nothing to form)
+      const bool den_here = (a.fuse_apply && R_PAD <= 128) || (!a.fuse_apply && ks == 0 && a.slab_den && a.gram_hi);
+      if (den_here) {
+        // denominator of kModeXB: den[m][r] = sum_q owner[m][q] G[q][r] as MFMA(owner fragments, Gram image rows r): the
+        // same (row from the register index, column from the lane) layout as the numerator accumulators.  The image row r
+        // carries 2^-exp[r]; hi + lo planes make the matrix itself exact to 2^-22, what is left is the owner's own rounding.
+        static_for<RT>([&](auto rtc) {   // (compile-time indices: op / qh must stay in registers)
+          constexpr int rt = decltype(rtc)::value;
+          const char* grow = reinterpret_cast<const char*>(a.gram_hi) + (size_t)(rt * 32 + j) * ROWB + hl * 16;
+          const char* grow_lo = reinterpret_cast<const char*>(a.gram_lo) + (size_t)(rt * 32 + j) * ROWB + hl * 16;
+          static_for<KS>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            op[rt] = mfma_op<OPT>(qh[kk], ld16(grow + kk * 32), op[rt]);
+            op[rt] = mfma_op<OPT>(qh[kk], ld16(grow_lo + kk * 32), op[rt]);
+          });
+          const float gs = a.gram_scale[rt * 32 + j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) op[rt][e] *= gs;
+        });
+      }
+    }
     if constexpr (BETA == kKL || (C::TWO_ACC && !X3 && R_PAD <= 128)) {   // (rank pad 256 x two sets: no registers left)
       if (a.fuse_apply) {
         // ---- nmf.py:78-92 in the epilogue (the workgroup owns complete rows: nsplit == 1).  The new factor values
@@ -818,7 +947,10 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
           const int row = (e & 3) + 8 * (e >> 2) + 4 * hl;
           const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
           a.slab_num[idx] = C::SCALE ? on[rt][e] * unsc : on[rt][e];
-          if constexpr (C::TWO_ACC) a.slab_den[idx] = C::SCALE ? op[rt][e] * unsc : op[rt][e];
+          if constexpr (C::TWO_ACC && !C::XB) a.slab_den[idx] = C::SCALE ? op[rt][e] * unsc : op[rt][e];
+          if constexpr (C::XB) {
+            if (ks == 0 && a.slab_den && a.gram_hi) a.slab_den[idx] = op[rt][e];   // (idx: slab 0 when ks == 0)
+          }
         }
       });
     }
@@ -875,6 +1007,10 @@ int launch_fused_dispatch(int beta_kind, int prec, int mode, const FusedArgs& a,
   NMFMU_CASE_MU(kPrecF16X)
   NMFMU_CASE_LOSS(kPrecF16X)
   NMFMU_CASE(kGen, kPrecBf16, kModeDen)
+  NMFMU_CASE(kEuc, kPrecBf16, kModeXB) NMFMU_CASE(kEuc, kPrecF16, kModeXB)
+  if constexpr (R_PAD <= 128) {   // (fp32 X buffers + rank-256 accumulators do not fit the 256 architectural VGPRs)
+    NMFMU_CASE(kEuc, kPrecF16X, kModeXB)
+  }
   if constexpr (ALLOW_X3) {
     NMFMU_CASE(kGen, kPrecX3, kModeDen)
     NMFMU_CASE_MU(kPrecX3)

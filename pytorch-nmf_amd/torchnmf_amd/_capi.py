@@ -79,6 +79,12 @@ SIGNATURES = {
     'nmfmu_mu_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_den_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
     'nmfmu_mu_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_xb_supported': (C.c_int, [C.c_int, C.c_int, C.c_float]),
+    'nmfmu_gram_ws_bytes': (C.c_size_t, [C.c_int]),
+    'nmfmu_gram_panel': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    'nmfmu_xb_partial': (C.c_int, [C.POINTER(Step), C.c_void_p]),
+    'nmfmu_xb_step': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_colsum_nparts': (C.c_int, [C.POINTER(Step)]),
     'nmfmu_pack_nparts': (C.c_int, [C.c_int]),
     'nmfmu_colsum_finalize': (C.c_int, [C.POINTER(Factor), C.c_int, C.c_int, C.c_void_p]),
@@ -175,6 +181,7 @@ SIGNATURES = {
     'nmfmu_comm_allreduce_sum_f32_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
                                                      C.POINTER(C.c_void_p), C.c_int]),
     'nmfmu_comm_destroy': (C.c_int, [C.c_void_p]),
+    'nmfmu_mu_step_allreduce': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_timer_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'nmfmu_timer_record': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_timer_elapsed_ms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -95,6 +95,51 @@ class HipBackend:
         if phase != 1:
             st.owner.nparts = self.lib.nmfmu_colsum_nparts(C.byref(st.struct))
 
+    # -- beta == 2 without the reconstruction (nmfmu_gram_panel / nmfmu_xb_step)
+    def xb_supported(self, r_pad: int, precision: int, beta: float) -> bool:
+        return bool(self.lib.nmfmu_xb_supported(r_pad, precision, beta))
+
+    def gram_alloc(self, r_pad: int, device):
+        """(workspace, fp32 matrix, hi image, lo image, per-row scales) of one Gram matrix."""
+        return (self.alloc(self.lib.nmfmu_gram_ws_bytes(r_pad), device),
+                torch.zeros(r_pad * r_pad, dtype=torch.float32, device=device),
+                self.alloc(r_pad * r_pad * 2, device), self.alloc(r_pad * r_pad * 2, device),
+                torch.zeros(r_pad, dtype=torch.float32, device=device))
+
+    def gram_panel(self, fac: 'FactorBuf', r_pad, precision, gm):
+        ws, gram, hi, lo, scale = gm
+        _capi.check(self.lib.nmfmu_gram_panel(C.byref(fac.struct), r_pad, precision, ws.data_ptr(), gram.data_ptr(),
+                                              hi.data_ptr(), lo.data_ptr(), scale.data_ptr(), self.stream()),
+                    'nmfmu_gram_panel')
+
+    def xb_step(self, st: 'StepBuf', gm, phase=0):
+        _, gram, hi, lo, scale = gm
+        _capi.check(self.lib.nmfmu_xb_step(C.byref(st.struct), hi.data_ptr(), lo.data_ptr(), scale.data_ptr(), phase,
+                                           self.stream()), 'nmfmu_xb_step')
+        if phase != 1:
+            st.owner.nparts = self.lib.nmfmu_colsum_nparts(C.byref(st.struct))
+
+    # -- the library's own RCCL communicator (nmfmu_comm_*), bootstrapped over a torch.distributed group
+    def comm_init(self, group, device):
+        import torch.distributed as dist
+        if not self.lib.nmfmu_comm_available():
+            raise _capi.NmfmuError('librccl could not be loaded by libnmfmu (nmfmu_comm_available() == 0)')
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank(group) == 0:
+            _capi.check(self.lib.nmfmu_comm_unique_id(uid.data_ptr()), 'nmfmu_comm_unique_id')
+        uid_d = uid.to(device)
+        dist.broadcast(uid_d, src=dist.get_global_rank(group, 0) if hasattr(dist, 'get_global_rank') else 0, group=group)
+        uid = uid_d.cpu()
+        comm = C.c_void_p()
+        _capi.check(self.lib.nmfmu_comm_init_rank(C.byref(comm), dist.get_world_size(group), uid.data_ptr(),
+                                                  dist.get_rank(group)), 'nmfmu_comm_init_rank')
+        return _Comm(self.lib, comm)
+
+    def mu_step_allreduce(self, st: 'StepBuf', comm: '_Comm', xbuf):
+        _capi.check(self.lib.nmfmu_mu_step_allreduce(C.byref(st.struct), comm.h, xbuf.data_ptr(), self.stream()),
+                    'nmfmu_mu_step_allreduce')
+        st.owner.nparts = self.lib.nmfmu_pack_nparts(st.owner.rows_pad)
+
     def colsum_finalize(self, fac: 'FactorBuf', r_pad):
         _capi.check(self.lib.nmfmu_colsum_finalize(C.byref(fac.struct), fac.nparts, r_pad, self.stream()),
                     'nmfmu_colsum_finalize')
@@ -115,6 +160,21 @@ class HipBackend:
 
     def loss(self, st, loss_part, out):
         _capi.check(self.lib.nmfmu_loss(C.byref(st.struct), _ptr(loss_part), _ptr(out), self.stream()), 'nmfmu_loss')
+
+
+class _Comm:
+    """Owner of an nmfmu_comm handle (destroyed with the engine)."""
+
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.nmfmu_comm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class KernelTimer:
@@ -180,13 +240,15 @@ class StepBuf:
     """One half-step: X in fragment order, owner/panel factors, partial-sum slabs."""
 
     def __init__(self, xp, owner: FactorBuf, panel: FactorBuf, rank, r_pad, nsplit, precision, stage, block_rows, beta,
-                 gamma, l1, l2, need_den: bool, status=None):
+                 gamma, l1, l2, need_den, status=None):
         self.xp, self.owner, self.panel = xp, owner, panel
         self.nsplit, self.r_pad, self.block_rows = nsplit, r_pad, block_rows
         dev = owner.f.device
         self.plane = owner.rows_pad * r_pad
         self.slab_num = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev)
-        self.slab_den = torch.empty(nsplit * self.plane, dtype=torch.float32, device=dev) if need_den else None
+        # (need_den == 'one': the path without reconstruction leaves ONE denominator slab, whatever the numerator's split)
+        nden = 0 if not need_den else (1 if need_den == 'one' else nsplit)
+        self.slab_den = torch.empty(nden * self.plane, dtype=torch.float32, device=dev) if nden else None
         self.struct = _capi.Step(_ptr(xp), owner.struct, panel.struct, _ptr(self.slab_num), _ptr(self.slab_den), rank,
                                  r_pad, nsplit, precision, stage, block_rows, beta, gamma, l1, l2, _ptr(status))
 
@@ -360,7 +422,8 @@ class DenseMU(AsyncLossMixin):
         return {2: 'f16', 1: 'f16x', 0: None}[level]
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
-                 update_W=True, update_H=True, block_rows=None, allow_f16=False, ar_overlap=None):
+                 update_W=True, update_H=True, block_rows=None, allow_f16=False, ar_overlap=None, allow_gram=False,
+                 ar_direct=None):
         self.be = backend if backend is not None else DEFAULT_BACKEND_FACTORY()
         self.group = group
         self.beta = float(beta)
@@ -394,6 +457,12 @@ class DenseMU(AsyncLossMixin):
             raise NotImplementedError(f'precision {precision!r} is not available for rank {R} (padded {self.r_pad})')
         if stage is None:
             stage = _capi.STAGE_DMA
+        # beta == 2 without the reconstruction (nmf.py:61-63 has no eps inside its grad_outputs): numerator = one streaming
+        # GEMM over X, denominator through the panel's rank x rank Gram matrix -- a third of the MFMA work, HBM-bound.
+        # fit()'s engines only (allow_gram): BetaMu reads numerator AND denominator slabs (p.grad = pos - neg).
+        self.gram_path = (allow_gram and self.beta == 2.0 and group is None and block_rows in (None, 128)
+                          and hasattr(self.be, 'xb_supported') and self.be.xb_supported(self.r_pad, self.precision, self.beta)
+                          and os.environ.get('TORCHNMF_AMD_BETA2_GRAM', '1') != '0')
         gamma = mu_gamma(self.beta)
         dev = V.device
 
@@ -416,15 +485,17 @@ class DenseMU(AsyncLossMixin):
         # H half-step and loss: owner axis N, contraction over C
         xp_h = self.be.pack_x(V, False, self.precision, br, n_pad, c_pad, self.flags)
         ns_h = self.be.choose_nsplit(n_pad, c_pad, br, dev)
+        need_den = False if self.kl else ('one' if self.gram_path else True)   # no slab | one slab | nsplit slabs
         self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, br, self.beta, gamma,
-                              l1, l2, need_den=not self.kl, status=self.status)
+                              l1, l2, need_den=need_den, status=self.status)
         self.step_w = None
         if update_W:
             brw = tile_rows(c_pad, n_pad)
             xp_w = self.be.pack_x(V, True, self.precision, brw, c_pad, n_pad, None)
             ns_w = self.be.choose_nsplit(c_pad, n_pad, brw, dev)
             self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, brw, self.beta,
-                                  gamma, l1, l2, need_den=not self.kl, status=self.status)
+                                  gamma, l1, l2, need_den=need_den, status=self.status)
+        self.gm = self.be.gram_alloc(self.r_pad, dev) if self.gram_path else None
         self.timer: Optional[KernelTimer] = None   # bench.py: times the fused launches live
         self.refresh_images()
         self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
@@ -438,6 +509,15 @@ class DenseMU(AsyncLossMixin):
             # the packed buffer per iteration -- the form north_star names).  The split point
             # defaults to the middle row block; TORCHNMF_AMD_AR_SPLIT=<fraction of the rows in the first part> moves it
             # (to be swept on a multi-GPU node: the first part's all-reduce should just fit behind the second part's kernel)
+            # 'direct' (fit(..., allreduce='direct') / TORCHNMF_AMD_COMM=c): the whole sharded H half-step is ONE C call --
+            # partial sums, slab reduction, a single RCCL all-reduce on the compute stream (the library's own communicator,
+            # bootstrapped over the torch group) and the apply; no return to Python between kernel and collective
+            if ar_direct is None:
+                ar_direct = os.environ.get('TORCHNMF_AMD_COMM', 'torch') == 'c'
+            self._comm = None
+            if ar_direct and hasattr(self.be, 'comm_init'):
+                self._comm = self.be.comm_init(group, dev)
+                ar_overlap = False
             st = self.step_h
             nblk = st.owner.rows_pad // 256
             frac = float(os.environ.get('TORCHNMF_AMD_AR_SPLIT', '0.5'))
@@ -517,17 +597,40 @@ class DenseMU(AsyncLossMixin):
             self.be.mu_partial(st)
             self.timer.mark(tag + '>')
 
+    def _gram_step(self, st, tag):
+        """beta == 2 half-step without the reconstruction: Gram matrix of the panel, then X @ panel with the update in the
+        kernel's epilogue (unsplit contraction) or in the apply kernel."""
+        self.be.gram_panel(st.panel, self.r_pad, self.precision, self.gm)
+        if self.timer is None:
+            self.be.xb_step(st, self.gm, 0)
+        else:
+            self.timer.mark(tag + '<')
+            self.be.xb_step(st, self.gm, 1)
+            self.timer.mark(tag + '>')
+            self.be.xb_step(st, self.gm, 2)
+
     def w_step(self):
         """nmf.py:367-378.  Local even when sharded: W rows belong to this rank's columns."""
+        if self.gram_path:
+            return self._gram_step(self.step_w, 'w')
         self._local_step(self.step_w, self.fH.colsum if self.kl else None, 'w')
 
     def h_step(self):
         """nmf.py:380-391, with the freshly updated W."""
         st = self.step_h
+        if self.gram_path:
+            return self._gram_step(st, 'h')
         if self.group is None:
             self._local_step(st, self.fW.colsum if self.kl else None, 'h')
             return
         import torch.distributed as dist
+        if getattr(self, '_comm', None) is not None:
+            if self.timer is not None:
+                self.timer.mark('h<')
+            self.be.mu_step_allreduce(st, self._comm, self.xbuf)
+            if self.timer is not None:
+                self.timer.mark('h>')
+            return
         num = self.xbuf[:st.plane]
         tail = self.xbuf[st.plane:]
         if self._h_rows is not None:
@@ -574,6 +677,7 @@ class DenseMU(AsyncLossMixin):
         fused kernel's numerator / denominator slabs; ``grad`` (same shape as the factor) receives ``p.grad``."""
         if self.group is not None:
             raise NotImplementedError('BetaMu on a column-sharded layer is not implemented')
+        assert not self.gram_path, 'trainer_step needs the denominator slabs (construct the engine without allow_gram)'
         st = self.step_w if which == 'W' else self.step_h
         assert st is not None
         other = self.fH if which == 'W' else self.fW

@@ -135,7 +135,10 @@ class BaseComponent(nn.Module):
                          (V[:, Cg], W[Cg]); H is replicated.
           allreduce      sharded fits only: 'single' = ONE all-reduce of the packed [numerator | denominator] buffer per
                          iteration; 'overlap' = the H half-step in two row halves, the first half's all-reduce travelling
-                         behind the second half's kernel (two collectives); None = TORCHNMF_AMD_AR_OVERLAP (default overlap).
+                         behind the second half's kernel (two collectives); 'direct' = 'single' with the whole half-step
+                         (kernel, slab reduction, RCCL all-reduce, apply) enqueued by ONE C call on the compute stream
+                         through the library's own communicator (nmfmu_mu_step_allreduce) instead of torch.distributed;
+                         None = TORCHNMF_AMD_AR_OVERLAP / TORCHNMF_AMD_COMM (default: overlap over torch.distributed).
         """
         sparse = V.is_sparse
         if sparse and not isinstance(self, NMF):
@@ -162,9 +165,10 @@ class BaseComponent(nn.Module):
             from .sparse_engine import SparseMU
             eng = SparseMU(V, W.data, H.data, beta, l1, l2, update_W=W.requires_grad, update_H=H.requires_grad)
         else:
-            if allreduce not in (None, 'single', 'overlap'):
-                raise ValueError(f"allreduce must be None, 'single' or 'overlap', got {allreduce!r}")
+            if allreduce not in (None, 'single', 'overlap', 'direct'):
+                raise ValueError(f"allreduce must be None, 'single', 'overlap' or 'direct', got {allreduce!r}")
             self._ar_overlap = None if allreduce is None else allreduce == 'overlap'
+            self._ar_direct = None if allreduce is None else allreduce == 'direct'
             eng = self._make_engine(V, beta, l1, l2, precision, process_group)
 
         has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
@@ -319,7 +323,8 @@ class NMF(BaseComponent):
                               update_W=self.W.requires_grad, update_H=self.H.requires_grad)
         return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
                        update_W=self.W.requires_grad, update_H=self.H.requires_grad, allow_f16=True,
-                       ar_overlap=getattr(self, '_ar_overlap', None))
+                       ar_overlap=getattr(self, '_ar_overlap', None), allow_gram=True,
+                       ar_direct=getattr(self, '_ar_direct', None))
 
 
 class NMFD(BaseComponent):

@@ -145,12 +145,14 @@ def test_pack_factor_images(dev, rank):
 # ----------------------------------------------------------------------------------------------------------
 # single half-steps against the oracle (every beta branch, both precisions, both staging modes)
 # ----------------------------------------------------------------------------------------------------------
-def _one_iter(dev, V, W0, H0, beta, prec, stage, alpha=0.0, l1r=0.0, block_rows=None):
+def _one_iter(dev, V, W0, H0, beta, prec, stage, alpha=0.0, l1r=0.0, block_rows=None, allow_gram=False):
     from torchnmf_amd.engine import DenseMU
     W = W0.clone().to(dev).contiguous()
     H = H0.clone().to(dev).contiguous()
     eng = DenseMU(V.to(dev), W, H, beta, alpha * l1r, alpha * (1 - l1r), precision=prec, stage=stage,
-                  block_rows=block_rows)
+                  block_rows=block_rows, allow_gram=allow_gram)
+    # (the path without reconstruction exists for every single-plane mode except 'f16x' at padded rank 256)
+    assert eng.gram_path == (allow_gram and beta == 2 and not (prec == 'f16x' and W0.shape[1] > 128))
     loss0 = eng.divergence()
     eng.w_step()
     torch.cuda.synchronize()
@@ -330,6 +332,63 @@ def test_f16x_keeps_the_target_unrounded(dev):
     e_true, e_rounded = rel_err(W1, Wr), rel_err(W1, Wq)
     record('f16x_unrounded_target', e_true=e_true, e_vs_rounded_target=e_rounded)
     assert e_true < 2e-5 and e_rounded > 3 * e_true, (e_true, e_rounded)
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16', 5e-3), ('f16', TOL), ('f16x', TOL)])
+@pytest.mark.parametrize('shape', [(384, 1100, 64), (520, 2300, 128), (200, 330, 24), (300, 700, 200), (3000, 260, 100)])
+@pytest.mark.parametrize('regs', [(0.0, 0.0), (0.05, 0.05)])
+def test_half_steps_beta2_without_reconstruction(dev, prec, tol, shape, regs):
+    """Round 4, the beta == 2 path of fit(): numerator = X @ panel (one streaming MFMA GEMM, kModeXB), denominator =
+    owner @ (panel^T panel) through the MFMA Gram kernel -- in the kernel's epilogue when the contraction is not split
+    (rank pad <= 128), in the apply kernel otherwise (split contraction, rank pad 256).  One iteration against the fp32
+    oracle, which follows the reference's own formulation (reconstruction + two backward products, nmf.py:61-63, 77-83)."""
+    from oracle import mu_oracle as O
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + R + 2)
+    V = torch.rand(N, C, generator=g)
+    if prec != 'f16x':
+        V = V.bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, 2, prec, 1, alpha=sum(regs), l1r=0.5, allow_gram=True)
+    Wr = O.nmf_w_step(V, W0, H0, 2, 1.0, *regs)
+    Hr = O.nmf_h_step(V, Wr, H0, 2, 1.0, *regs)
+    ew, eh = rel_err(W1, Wr), rel_err(H1, Hr)
+    record('half_steps_beta2_gram', prec=prec, shape=shape, regs=regs, relW=ew, relH=eh)
+    assert ew < tol and eh < tol, (ew, eh)
+    assert l1 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, 2)), rel=20 * tol)
+
+
+def test_gram_panel_matches_fp32(dev):
+    """nmfmu_gram_panel: G = F^T F from the 16-bit transposed image (MFMA, deterministic two-stage sum): the fp32 matrix
+    against torch on the image's own (rounded) values, the hi + lo images times their row scales against the fp32 matrix."""
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import FactorBuf, HipBackend
+    be = HipBackend()
+    g = torch.Generator().manual_seed(4)
+    for rows, rank, prec in [(5000, 100, 'f16'), (700, 128, 'bf16'), (70000, 40, 'f16'), (300, 200, 'f16')]:
+        F = (torch.randn(rows, rank, generator=g).abs() * 3).to(dev)
+        r_pad, P = be.pad_rank(rank), _capi.PRECISIONS[prec]
+        fb = FactorBuf(F, r_pad, P, be)
+        be.pack_factor(fb, rank, r_pad, P)
+        gm = be.gram_alloc(r_pad, dev)
+        be.gram_panel(fb, r_pad, P, gm)
+        be.gram_panel(fb, r_pad, P, gm)                  # deterministic: a second run must reproduce the bits
+        torch.cuda.synchronize()
+        _, gram, hi, lo, scale = gm
+        Fq = (F.half() if prec == 'f16' else F.bfloat16()).double()
+        want = torch.zeros(r_pad, r_pad, dtype=torch.float64, device=dev)
+        want[:rank, :rank] = Fq.t() @ Fq
+        G = gram.view(r_pad, r_pad)
+        assert float((G.double() - want).norm() / want.norm()) < 2e-6
+        assert torch.equal(G, G.t().contiguous()) or float((G - G.t()).abs().max() / G.abs().max()) < 1e-6
+        dt = torch.float16 if prec == 'f16' else torch.bfloat16
+        img = (hi.view(dt).float() + lo.view(dt).float()).view(r_pad, r_pad) * scale.view(r_pad, 1)
+        assert float((img - G).norm() / G.norm()) < (2e-6 if prec == 'f16' else 3e-5)
+        g2 = gram.clone()
+        be.gram_panel(fb, r_pad, P, gm)
+        torch.cuda.synchronize()
+        assert torch.equal(g2, gram)
 
 
 def test_register_staging_is_gone(dev):
@@ -1138,11 +1197,13 @@ def test_sharded_path_world1_rccl(dev):
         Vb = torch.rand(700, 2100, generator=gg).bfloat16().float().to(dev)
         Wb, Hb = torch.randn(2100, 100, generator=gg).abs(), torch.randn(700, 100, generator=gg).abs()
         res = []
-        for grp, overlap in ((None, '1'), (dist.group.WORLD, '1'), (dist.group.WORLD, '0')):
-            os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
+        for grp, overlap in ((None, '1'), (dist.group.WORLD, '1'), (dist.group.WORLD, '0'), (dist.group.WORLD, 'direct')):
+            os.environ['TORCHNMF_AMD_AR_OVERLAP'] = '0' if overlap == 'direct' else overlap
             W, H = Wb.clone().to(dev), Hb.clone().to(dev)
-            eng = DenseMU(Vb, W, H, 1.0, precision='bf16', group=grp)
+            # 'direct' (round 4): the whole sharded H half-step as one C call with the library's own RCCL communicator
+            eng = DenseMU(Vb, W, H, 1.0, precision='bf16', group=grp, ar_direct=(overlap == 'direct') if grp is not None else None)
             if grp is not None:     # 700 rows pad to 768: the overlapped form runs rows [0, 256) and [256, 768) separately
+                assert (eng._comm is not None) == (overlap == 'direct')
                 assert (eng._h_rows is not None) == (overlap == '1')
                 if overlap == '1':
                     assert [(v.r0, v.owner.rows, v.owner.rows_pad) for v in eng._h_rows] == [(0, 256, 256), (256, 444, 512)]
@@ -1168,6 +1229,11 @@ def test_sharded_path_world1_rccl(dev):
             Wr = O.nmf_w_step(Vc, Wr, Hr, 2, 1.0, 0.05, 0.05)
             Hr = O.nmf_h_step(Vc, Wr, Hr, 2, 1.0, 0.05, 0.05)
         assert rel_err(W.cpu(), Wr) < TOL and rel_err(H.cpu(), Hr) < TOL
+        # ... and through fit(allreduce='direct'): numerator and denominator in ONE all-reduce from the C entry
+        m = NMF(W=Wc, H=Hc).to(dev)
+        assert m.fit(Vc.to(dev).contiguous(), 2, NO_STOP, 3, alpha=0.1, l1_ratio=0.5, precision='bf16x3',
+                     process_group=dist.group.WORLD, allreduce='direct') == 3
+        assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
         # ---- configs[4]'s kernel family on the sharded path: rank 256, fp16 operands (the parity-grade
         # single-plane mode), an 8192 x 8192 slice of the per-GPU shard, two iterations through NMF.fit with
         # precision='auto' -- which must pick 'f16' here (fp16-exact target, both dimensions >= 4096) -- and the two
@@ -1673,6 +1739,43 @@ def test_cfg1_full_size_one_iteration(dev, prec, tol):
     ew, eh = rel_err(W1, Wr), rel_err(H1, Hr)
     record('cfg1_full_size_one_iteration', prec=prec, relW=ew, relH=eh)
     assert ew < tol and eh < tol, (ew, eh)
+
+
+@pytest.mark.parametrize('prec', ['f16', 'f16x'])
+def test_cfg2_full_size_beta2_without_reconstruction(dev, prec):
+    """BASELINE configs[2], beta = 2, through NMF.fit() -- which takes the path without reconstruction (X @ panel + Gram
+    matrix) -- three iterations at full size against the reference's op sequence; 'f16x' on a target fp16 does not hold."""
+    from oracle import aten_port
+    from torchnmf_amd import engine
+    from torchnmf_amd.nmf import NMF
+    g = torch.Generator().manual_seed(2)
+    N, C, R = 4096, 65536, 128
+    V = torch.rand(N, C, generator=g)
+    if prec == 'f16':
+        V = V.bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    key = ('cfg2_gram', prec)
+    if key not in _ORACLE_CACHE:
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        _ORACLE_CACHE[key] = aten_port.mu_iterations(V, W0, H0, 2, 3)
+    Wr, Hr = _ORACLE_CACHE[key]
+    seen = []
+    orig = engine.DenseMU.__init__
+
+    def init(self, *a, **k):
+        orig(self, *a, **k)
+        seen.append((self.precision_name, self.gram_path))
+    engine.DenseMU.__init__ = init
+    try:
+        m = NMF(W=W0, H=H0).to(dev)
+        n = m.fit(V.to(dev), 2, NO_STOP, 3)
+    finally:
+        engine.DenseMU.__init__ = orig
+    assert n == 3 and seen == [(prec, True)], seen
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    record('cfg2_full_size_beta2_gram', prec=prec, relW=ew, relH=eh)
+    assert ew < TOL and eh < TOL, (ew, eh)
 
 
 @pytest.mark.parametrize('beta', [2, 0.5, 0])
