@@ -93,6 +93,15 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_key(key):
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        e = d.get('records', {}).get(key)
+        return None if e is None else e.get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
 def pmc_traffic(N, C, R, precision, pp):
     """HBM bytes per fused launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 gfx950
     correction + WRITE_SIZE), keyed by shape / precision / kernel; None when this run's workload was not profiled."""
@@ -924,7 +933,8 @@ def main():
                     'kernel': 'nmfmu::fused_kernel<.., kEuc, .., kModeXB>', 'kernel_avg_launch_ms': rf['avg_launch_ms'],
                     'kernel_avg_launch_ms_w_step': rf['avg_launch_ms_w_step'], 'kernel_avg_launch_ms_h_step': rf['avg_launch_ms_h_step'],
                     'roofline': {'bound': 'hbm', 'achieved': rf['hbm']['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                 'frac': rf['hbm']['frac'], 'algorithmic_bytes_per_launch': rf['hbm']['algorithmic_bytes_per_launch']},
+                                 'frac': rf['hbm']['frac'], 'algorithmic_bytes_per_launch': rf['hbm']['algorithmic_bytes_per_launch'],
+                                 'traffic': pmc_traffic_key(f'{N}x{C}_r{R}_{a.precision}_xb')},
                     'speedup_over_12NCR_kernel': round(ent['ms_per_step'] / gleg['ms_per_step'], 3),
                     'clock_mhz': rf.get('clock_mhz'), 'power_w': rf.get('power_w')}
                 del gleg
