@@ -131,8 +131,9 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
  * load_state_dict changed W/H; the apply step keeps them current afterwards). */
 int nmfmu_pack_factor(const nmfmu_factor* fac, int rank, int r_pad, int precision, void* stream);
 
-/* nmfmu_pack_factor_scaled: images and column sums of f[row][r] * scale[r] (the master stays as it is).  PLCA feeds
- * the first GEMM of the fused kernel with the Z-scaled panel and the second with the unscaled one. */
+/* nmfmu_pack_factor_scaled: images of f[row][r] * scale[r] (the master stays as it is; since ABI 6 fac->colsum is NOT
+ * refreshed -- only the partial sums in colsum_part are written -- PLCA's EM reads none).  PLCA feeds the first GEMM of
+ * the fused kernel with the Z-scaled panel and the second with the unscaled one (scale = ones). */
 int nmfmu_pack_factor_scaled(const nmfmu_factor* fac, int rank, int r_pad, int precision, const float* scale,
                              void* stream);
 
@@ -455,6 +456,9 @@ int nmfmu_plca_em(float* f, int rows, int rank, int r_pad, const float* num, int
 int nmfmu_plca_normalize(float* f, int rows, int rank, int r_pad, const float* divider, float alpha, float* part,
                          float* colsum_out, void* stream);
 int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* stream);
+/* plca.py:253-260 in one launch: prior[r] = z[r] * relu(zgrad[r]); z <- prior (+ alpha - 1, clamped below at eps when
+ * alpha != 1), then z /= sum(z).  rank <= 256. */
+int nmfmu_plca_z(float* z, const float* zgrad, int rank, float alpha, float* prior, void* stream);
 
 /* ---- shift-invariant PLCA (SIPLCA / SIPLCA2 / SIPLCA3, plca.py:376-606) on the NMFD GEMM path ----------------------
  * Same EM update as PLCA with W (C, R, *T), H (B, R, *Lh): factors are addressed [outer][rank][inner], the unscaled

@@ -249,7 +249,17 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
   const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
   const int col = blockIdx.x * 32 + c4 * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int b = g; b < nblk; b += 32) {
+  int b = g;
+  // eight independent loads in flight per thread (a dependent chain made this launch latency-bound: 24 us for the 2 048
+  // partials of PLCA's EM pass); same summation order as the plain loop
+  for (; b + 7 * 32 < nblk; b += 8 * 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (size_t)(b + 32 * u) * r_pad + col);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+  }
+  for (; b < nblk; b += 32) {
     const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * r_pad + col);
     s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
   }

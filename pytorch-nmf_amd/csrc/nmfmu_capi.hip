@@ -222,6 +222,7 @@ static int pack_factor_common(const nmfmu_factor* fac, int rank, int r_pad, int 
   a.rows = fac->rows, a.rank = rank, a.rows_pad = fac->rows_pad;
   a.gamma = 1.f;
   a.scale = scale;
+  a.skip_colsum = scale != nullptr;   // the scaled packing serves PLCA's EM, which reads no column sums of the images' factor
   a.f16 = is_f16(precision);
   return launch_apply(r_pad, a, x3, /*pack_only=*/true, S(stream));
 }

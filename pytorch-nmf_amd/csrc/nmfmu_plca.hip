@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256) plca_kernel(float* __restrict__ f, int ro
   float cs = 0.f, zg = 0.f;
   if (r < rank) {
     const float v = vec[r];   // MODE 0: z_old[r];  MODE 1: divider[r]
-    for (int rl = g; rl < kPlcaRows; rl += groups) {
+#pragma unroll 4
+    for (int rl = g; rl < kPlcaRows; rl += groups) {   // (unrolled: several rows' loads in flight; f and num do not alias)
       const int row = row0 + rl;
       if (row >= rows) break;
       const size_t i = (size_t)row * rank + r;
@@ -64,6 +65,31 @@ __global__ void __launch_bounds__(256) plca_kernel(float* __restrict__ f, int ro
 __global__ void __launch_bounds__(256) plca_scale_kernel(float* __restrict__ f, int64_t n, int rank,
                                                          const float* __restrict__ colsum) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) f[i] /= colsum[i % rank];
+}
+
+// The latent update of plca.py:253-260 in one launch (round 4; it was a dozen R-element torch ops per EM iteration):
+// prior[r] = z[r] * relu(zgrad[r]) (what the factors' normalisation divides by); z <- prior (+ Dirichlet prior: + alpha - 1,
+// clamped below at eps); z /= sum(z).  One workgroup, rank <= 256, fixed-order sum.
+__global__ void __launch_bounds__(256) plca_z_kernel(float* __restrict__ z, const float* __restrict__ zgrad, int rank,
+                                                     float alpha, float* __restrict__ prior) {
+  __shared__ float red[256];
+  const int r = threadIdx.x;
+  float z1 = 0.f;
+  if (r < rank) {
+    z1 = z[r] * fmaxf(zgrad[r], 0.f);
+    prior[r] = z1;
+    if (alpha != 1.f) {
+      z1 += alpha - 1.f;
+      z1 = z1 > kEps ? z1 : kEps;
+    }
+  }
+  red[r] = z1;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (r < o) red[r] += red[r + o];
+    __syncthreads();
+  }
+  if (r < rank) z[r] = z1 / red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -171,6 +197,12 @@ int nmfmu_plca_scale(float* f, int rows, int rank, const float* colsum, void* st
   const int64_t n = (int64_t)rows * rank;
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(plca_scale_kernel, dim3(grid), dim3(256), 0, S(stream), f, n, rank, colsum);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_plca_z(float* z, const float* zgrad, int rank, float alpha, float* prior, void* stream) {
+  if (!z || !zgrad || !prior || rank <= 0 || rank > 256) return NMFMU_ERR_ARG;
+  hipLaunchKernelGGL(plca_z_kernel, dim3(1), dim3(256), 0, S(stream), z, zgrad, rank, alpha, prior);
   return (int)hipGetLastError();
 }
 

@@ -195,7 +195,8 @@ class _PlcaEM:
         self.cs2 = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)
         self.zg = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)
         self.zpad = torch.zeros(self.r_pad, dtype=torch.float32, device=dev)   # Z padded to r_pad for the kernels
-        self.div = torch.ones(self.r_pad, dtype=torch.float32, device=dev)
+        self.prior = torch.ones(self.r_pad, dtype=torch.float32, device=dev)   # what the factors' normalisation divides by
+        self.ones = torch.ones(self.r_pad, dtype=torch.float32, device=dev)
         self.repack()
 
     def _s(self):
@@ -203,10 +204,12 @@ class _PlcaEM:
 
     def repack(self):
         self.zpad[:self.R] = self.Z
+        # (both image sets through the scaled entry -- scale = ones for the plain one: it skips the column-sum finalize
+        # launches, whose results the EM iteration never reads)
         for plain, scaled in ((self.fW, self.fWz), (self.fH, self.fHz)):
-            self.be.pack_factor(plain, self.R, self.r_pad, self.prec)
-            _capi.check(self.lib.nmfmu_pack_factor_scaled(plain_struct(scaled), self.R, self.r_pad, self.prec,
-                                                          self.zpad.data_ptr(), self._s()), 'nmfmu_pack_factor_scaled')
+            for fb, sc in ((plain, self.ones), (scaled, self.zpad)):
+                _capi.check(self.lib.nmfmu_pack_factor_scaled(plain_struct(fb), self.R, self.r_pad, self.prec,
+                                                              sc.data_ptr(), self._s()), 'nmfmu_pack_factor_scaled')
 
     def divergence(self) -> float:
         self.be.loss(self.step_l, self.loss_part, self.loss_out)
@@ -219,43 +222,38 @@ class _PlcaEM:
                                            self.cs.data_ptr(), self.zg.data_ptr() if want_zgrad else None, self._s()),
                     'nmfmu_plca_em')
 
-    def _normalize(self, f, alpha, z_prior):
-        """plca.py:265-275 / 279-289 after the multiplication; returns the latent prior for the next factor."""
-        if z_prior is None:
-            z_prior = self.cs[:self.R].clone()          # get_norm of the multiplied factor
-        self.div[:self.R] = z_prior
-        _capi.check(self.lib.nmfmu_plca_normalize(f.data_ptr(), f.shape[0], self.R, self.r_pad, self.div.data_ptr(),
+    def _normalize(self, f, alpha):
+        """plca.py:265-275 / 279-289 after the multiplication: divide by the latent prior held in ``self.prior``."""
+        _capi.check(self.lib.nmfmu_plca_normalize(f.data_ptr(), f.shape[0], self.R, self.r_pad, self.prior.data_ptr(),
                                                   float(alpha), self.part.data_ptr(), self.cs2.data_ptr(), self._s()),
                     'nmfmu_plca_normalize')
         if alpha != 1:
             _capi.check(self.lib.nmfmu_plca_scale(f.data_ptr(), f.shape[0], self.R, self.cs2.data_ptr(), self._s()),
                         'nmfmu_plca_scale')
-        return z_prior
 
     def em_step(self, tW, tH, tZ, W_alpha, H_alpha, Z_alpha):
         """One EM iteration (plca.py:248-290): every update uses the gradients of ONE reconstruction."""
         self.be.mu_partial(self.step_w)
         self.be.mu_partial(self.step_h)
-        z_old = self.zpad.clone()
+        z_old = self.zpad                               # (still the old Z: repack() below refreshes it)
         # W's multiplication pass also yields Z.grad = sum W_old * (G^T H); the division by the latent prior, which needs
         # the new Z first (plca.py:253-270), is the separate normalize kernel
         self._em(self.W.data, self.step_w, z_old, tW, True)
-        cs_w = self.cs[:self.R].clone() if tW else None
-        z_prior = None
-        if tZ:                                          # plca.py:253-260
-            z1 = self.Z.data * self.zg[:self.R].relu()
-            z_prior = z1.clone()
-            if Z_alpha != 1:
-                z1 = z1 + (Z_alpha - 1)
-                z1 = torch.where(z1 > _EPS, z1, torch.full_like(z1, _EPS))
-            self.Z.data.copy_(z1 / z1.sum())
+        have_prior = False
+        if tZ:                                          # plca.py:253-260: one launch; prior = Z_old * relu(Z.grad)
+            _capi.check(self.lib.nmfmu_plca_z(self.Z.data.data_ptr(), self.zg.data_ptr(), self.R, float(Z_alpha),
+                                              self.prior.data_ptr(), self._s()), 'nmfmu_plca_z')
+            have_prior = True
         if tW:
-            if z_prior is None:
-                z_prior = cs_w
-            z_prior = self._normalize(self.W.data, W_alpha, z_prior)
+            if not have_prior:                          # frozen Z: get_norm of the multiplied W (plca.py:266-268)
+                self.prior[:self.R].copy_(self.cs[:self.R])
+                have_prior = True
+            self._normalize(self.W.data, W_alpha)
         if tH:
             self._em(self.H.data, self.step_h, z_old, True, False)
-            self._normalize(self.H.data, H_alpha, z_prior)
+            if not have_prior:                          # frozen Z and W: get_norm of the multiplied H
+                self.prior[:self.R].copy_(self.cs[:self.R])
+            self._normalize(self.H.data, H_alpha)
         self.repack()
 
 
