@@ -67,6 +67,10 @@ extern "C" {
 /* how the panel tile reaches LDS */
 #define NMFMU_STAGE_REG 0 /* global -> VGPR -> ds_write: no longer built, NMFMU_ERR_UNSUPPORTED */
 #define NMFMU_STAGE_DMA 1 /* global_load_lds (LDS-DMA)  */
+#define NMFMU_STAGE_DMA_SPLIT 2 /* as NMFMU_STAGE_DMA, and panel.p1_* / panel.p2_* are images of DIFFERENT matrices (PLCA: the
+                                   Z-scaled factor for the reconstruction, the unscaled one for the second GEMM).  Since ABI 6
+                                   the single-plane four-wave kernels stage ONE panel image and gather the second GEMM's
+                                   operands from it (ds_read_b64_tr_b16); a split panel must say so.  beta == 1, nmfmu_mu_partial */
 
 /* One factor (W or H) as the engine sees it. */
 typedef struct nmfmu_factor {

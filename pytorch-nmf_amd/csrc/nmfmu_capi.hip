@@ -59,7 +59,12 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   if (!st->xp && (mode == kModeMU || mode == kModeXB)) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
-  if (st->stage != NMFMU_STAGE_DMA) return NMFMU_ERR_UNSUPPORTED;   // the register-staged variant is no longer built
+  if (st->stage != NMFMU_STAGE_DMA && st->stage != NMFMU_STAGE_DMA_SPLIT) return NMFMU_ERR_UNSUPPORTED;   // (register staging: no longer built)
+  // split panel (PLCA: p1 = the Z-scaled factor, p2 = the unscaled one): the instantiation that stages BOTH images
+  if (st->stage == NMFMU_STAGE_DMA_SPLIT && mode == kModeMU && !(st->precision == NMFMU_PREC_BF16X3)) {
+    if (nmfmu_beta_kind(st->beta) != NMFMU_BETA_KL || st->block_rows != 128) return NMFMU_ERR_UNSUPPORTED;
+    mode = kModeMU2;
+  }
   if (st->r_pad != pad_rank(st->rank) || st->nsplit < 1) return NMFMU_ERR_ARG;
   const bool x3 = st->precision == NMFMU_PREC_BF16X3;
   if (x3 && (!st->owner.p1_lo || !st->panel.p1_lo)) return NMFMU_ERR_ARG;
@@ -95,7 +100,9 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     a.colsum_part = st->owner.colsum_part;
     a.l1 = st->l1, a.l2 = st->l2, a.gamma = st->gamma;
   }
-  if (mode == kModeXB) {   // beta == 2 without reconstruction: numerator slabs only (or the fused apply with the Gram images)
+  if (mode == kModeMU2) {
+    if (!a.slab_num || !a.p2_hi || fuse_apply) return NMFMU_ERR_ARG;
+  } else if (mode == kModeXB) {   // beta == 2 without reconstruction: numerator slabs only (or the fused apply with the Gram images)
     if (kind != kEuc || x3 || st->block_rows != 128) return NMFMU_ERR_UNSUPPORTED;
     if (!a.p2_hi || (!fuse_apply && !a.slab_num)) return NMFMU_ERR_ARG;
     if (fuse_apply && (!gm || st->r_pad > 128)) return NMFMU_ERR_ARG;

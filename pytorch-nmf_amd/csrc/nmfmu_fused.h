@@ -59,6 +59,9 @@
 #ifndef NMFMU_FUSED_G1_ASM
 #define NMFMU_FUSED_G1_ASM 1
 #endif
+#ifndef NMFMU_FUSED_TR_MINR
+#define NMFMU_FUSED_TR_MINR 32    // single-plane MU instances at padded rank >= this stage ONE panel image (FusedCfg::TR); 999 = off
+#endif
 
 
 namespace nmfmu {
@@ -74,7 +77,9 @@ enum BetaKind : int { kKL = 0, kEuc = 1, kIS = 2, kGen = 3, kSqrt = 4, kSqrt3 = 
 // owner @ (panel^T panel) needs only the rank x rank Gram matrix (nmfmu_gram_panel): in the fused-apply epilogue it is one
 // more small MFMA product per workgroup (owner fragments x Gram image), otherwise the apply kernel forms it from the fp32
 // master.  4*N*C*R flops per iteration instead of 12*N*C*R; HBM-bound on the X stream.
-enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2, kModeXB = 3 };
+// kModeMU2: kModeMU for a SPLIT panel -- the row-major image (first GEMM) and the transposed image (second GEMM) hold
+// different matrices (PLCA: the Z-scaled factor and the unscaled one), so both are staged (no FusedCfg::TR).
+enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2, kModeXB = 3, kModeMU2 = 4 };
 enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2, kPrecF16X = 3 };   // = NMFMU_PREC_* of include/nmfmu.h
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -147,7 +152,15 @@ struct FusedCfg {
   static constexpr bool LOSS = MODE == kModeLoss;
   static constexpr bool DEN = MODE == kModeDen;
   static constexpr bool XB = MODE == kModeXB;   // numerator = X @ panel only (beta == 2); only the P2 image is staged
-  static constexpr int NIMG = ((LOSS || XB) ? 1 : 2) * NPL;
+  // TR (round 4): padded rank 256, beta == 1, single plane -- the configs[4] shard.  Its k-tile is 64 KiB of panel (two
+  // images of 32 KiB), i.e. SIXTEEN 1-KiB LDS-DMA pieces per wave and tile at ~150 issue cycles each next to 2 048 cycles
+  // of MFMA, in ONE wave per SIMD: the kernel is DMA-issue-bound (and, at 1 345 W / 1.96 GHz, not at the power limit).
+  // With TR only the row-major image is staged and the second GEMM's k-contiguous operands are gathered from it by the
+  // transposing read ds_read_b64_tr_b16 (two per MFMA): half the pieces.  (The same idea lost in the ping-pong kernel,
+  // whose DMA issue is hidden behind the other half's MFMAs and which sits at the power limit -- round 2.)
+  static constexpr bool TR = R_PAD >= NMFMU_FUSED_TR_MINR && !X3 && MODE == kModeMU &&
+                             (R_PAD < 256 || BETA == kKL);   // (rank 256 with two accumulator sets: no registers for it)
+  static constexpr int NIMG = ((LOSS || XB || TR) ? 1 : 2) * NPL;
   static constexpr int P1HI = 0;
   static constexpr int P1LO = IMG;           // valid when X3
   static constexpr int P2HI = XB ? 0 : NPL * IMG;
@@ -173,7 +186,9 @@ struct FusedCfg {
   // kModeXB streams: four (fp32 target: three) ring stages, tiles t+1 .. t+3 in flight behind tile t (counted waits); at padded rank 128 the
   // ring is exactly as large as its epilogue's staging tile (4 waves x 32 rows x R_PAD floats)
   static constexpr int NSTAGE = DEEP ? (XF32 ? 3 : 4) : 2;   // (fp32 X buffers are 32 registers each: three of them)
-  static constexpr int EPI_BYTES = XB ? WAVES * 32 * R_PAD * 4 : 0;
+  // the fused-apply epilogue stages 4 waves x 32 rows x R_PAD floats in LDS (= two stages of two images; more than the
+  // ring of the single-image instances)
+  static constexpr int EPI_BYTES = (XB || TR) ? WAVES * 32 * R_PAD * 4 : 0;
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES;
 };
 
@@ -466,7 +481,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   } else {
     img_src[0] = reinterpret_cast<const char*>(a.p1_hi);
     if constexpr (X3) img_src[1] = reinterpret_cast<const char*>(a.p1_lo);
-    if constexpr (!C::LOSS) {
+    if constexpr (!C::LOSS && !C::TR) {
       img_src[C::NPL] = reinterpret_cast<const char*>(a.p2_hi);
       if constexpr (X3) img_src[C::NPL + 1] = reinterpret_cast<const char*>(a.p2_lo);
     }
@@ -638,6 +653,32 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   };
 
   // ---------------- GEMM2: num/den (owner rows x rank), contraction over the tile's 64 columns
+  // TR: ds_read_b64_tr_b16 works on groups of 16 lanes; lane 4a+b of a group receives element b of the 8-byte chunks
+  // addressed by lanes a, a+4, a+8, a+12 (probed on gfx950: tools/ubench/tr_probe.hip).  With source lane s = a + 4i
+  // pointing at (panel row k0 + i, ranks 4 (c0 + a) .. +3) the group reads a [4 rows] x [16 ranks] block and lane l ends
+  // up with rank 4 c0 + l for rows k0 .. k0+3: two such reads (rows +0..3 and +4..7) are the B operand of GEMM2, whose
+  // lane (j, hl) needs the 8 contraction rows 32 hl + 16 tt + 8 m2 + (0..7) of rank 32 rt + j.
+  // t_base[tt][m2][h]: byte offset of this lane's chunk for rank tile 0; rank tile rt = XOR with rt * 64 (slot bits 2-4).
+  int t_base[2][2][2] = {};
+  if constexpr (C::TR) {
+    const int grp = lane >> 4, s16 = lane & 15;
+    const int cslot = 2 * (grp & 1) + ((s16 & 3) >> 1);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2);
+          t_base[tt][m2][h] = row * ROWB + ((cslot ^ P1Swz<R_PAD>::of(row)) << 4) + 8 * (s16 & 1);
+        }
+  }
+  using s16x4_t = __attribute__((ext_vector_type(4))) short;
+  using u32x2_t = __attribute__((ext_vector_type(2))) uint32_t;
+  auto rd_tr = [&](const char* sb, int off) -> u32x2_t {
+    auto* p = (__attribute__((address_space(3))) s16x4_t*)(size_t)((unsigned)(size_t)(__attribute__((address_space(3))) char*)sb + (unsigned)off);
+    return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(p));
+  };
   auto gemm2 = [&](const char* sb, const GOps& g) {
     constexpr int NSTEP = RT * 4;
     constexpr int PF = 4;
@@ -648,9 +689,18 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       const int rt = step % RT, c = step / RT;
       return rt * 4096 + b_row + b_off[c >> 1][c & 1];
     };
+    auto fetch_h = [&](int step) -> u32x4 {   // GEMM2's B operand of `step`: from the transposed image, or gathered (TR)
+      if constexpr (C::TR) {
+        const int rt = step % RT, c = step / RT;
+        const u32x2_t lo = rd_tr(sb, t_base[c >> 1][c & 1][0] ^ (rt * 64)), hi = rd_tr(sb, t_base[c >> 1][c & 1][1] ^ (rt * 64));
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        return ld16(sb + C::P2HI + b_offs(step));
+      }
+    };
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      ring_h[p] = ld16(sb + C::P2HI + b_offs(p));
+      ring_h[p] = fetch_h(p);
       if constexpr (X3) ring_l[p] = ld16(sb + C::P2LO + b_offs(p));
     }
 #pragma unroll
@@ -661,7 +711,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       u32x4 bl;
       if constexpr (X3) bl = ring_l[step % PF];
       if (step + PF < NSTEP) {
-        ring_h[step % PF] = ld16(sb + C::P2HI + b_offs(step + PF));
+        ring_h[step % PF] = fetch_h(step + PF);
         if constexpr (X3) ring_l[step % PF] = ld16(sb + C::P2LO + b_offs(step + PF));
       }
       const u32x4 nh = {g.gnh[tt][4 * m2], g.gnh[tt][4 * m2 + 1], g.gnh[tt][4 * m2 + 2], g.gnh[tt][4 * m2 + 3]};
@@ -684,11 +734,12 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         op[rt] = mfma_op<OPT>(ph, bh, op[rt]);
       }
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, PF * C::NPL, 1);
+    constexpr int RDS = C::TR ? 2 : C::NPL;   // LDS reads per operand
+    __builtin_amdgcn_sched_group_barrier(0x100, PF * RDS, 1);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       __builtin_amdgcn_sched_group_barrier(0x008, X3 ? ((C::TWO_ACC && !C::XB) ? 6 : 3) : (((C::TWO_ACC && !C::XB) ? 2 : 1) + (C::XSPLIT ? 1 : 0)), 1);
-      if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, C::NPL, 1);
+      if (step + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, RDS, 1);
     }
   };
 
@@ -1007,6 +1058,7 @@ int launch_fused_dispatch(int beta_kind, int prec, int mode, const FusedArgs& a,
   NMFMU_CASE_MU(kPrecF16X)
   NMFMU_CASE_LOSS(kPrecF16X)
   NMFMU_CASE(kGen, kPrecBf16, kModeDen)
+  NMFMU_CASE(kKL, kPrecBf16, kModeMU2) NMFMU_CASE(kKL, kPrecF16, kModeMU2)
   NMFMU_CASE(kEuc, kPrecBf16, kModeXB) NMFMU_CASE(kEuc, kPrecF16, kModeXB)
   if constexpr (R_PAD <= 128) {   // (fp32 X buffers + rank-256 accumulators do not fit the 256 architectural VGPRs)
     NMFMU_CASE(kEuc, kPrecF16X, kModeXB)

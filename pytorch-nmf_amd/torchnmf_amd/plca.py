@@ -177,7 +177,7 @@ class _PlcaEM:
         ns_w = self.be.choose_nsplit(c_pad, n_pad, br, dev)
 
         def step(xp, owner, p1_src, p2_src, ns):
-            st = StepBuf(xp, owner, p2_src, R, self.r_pad, ns, self.prec, _capi.STAGE_DMA, br, 1.0, 1.0, 0.0, 0.0,
+            st = StepBuf(xp, owner, p2_src, R, self.r_pad, ns, self.prec, _capi.STAGE_DMA_SPLIT, br, 1.0, 1.0, 0.0, 0.0,
                          need_den=False)
             # split panel: reconstruction from the Z-scaled images, second GEMM from the unscaled ones
             st.struct.panel.p1_hi, st.struct.panel.p1_lo = _ptr(p1_src.p1_hi), _ptr(p1_src.p1_lo)

@@ -1830,6 +1830,38 @@ def test_cfg1_full_size_20_iterations_f16_unrounded_target(dev):
         del eng
 
 
+@pytest.mark.parametrize('prec,tol', [('bf16', 5e-3), ('f16', TOL), ('f16x', TOL)])
+def test_rank256_w_half_step_with_the_apply_in_its_epilogue(dev, prec, tol):
+    """Padded rank 256, beta = 1, a W tall enough (>= 512 row blocks) that its contraction is not split: the W half-step
+    applies nmf.py:78-92 in the kernel's epilogue and re-emits W's images through a 128 KiB LDS staging tile -- the launch
+    configs[4]'s shard runs.  (Round 4: the single-image instances allocated only their 64 KiB ring; the epilogue ran off
+    the end of it, no test came here, and the bench looked 20 % faster on the garbage.)  Two iterations, so that the images
+    the epilogue wrote are what the next half-steps read."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.engine import DenseMU
+    g = torch.Generator().manual_seed(256)
+    N, C, R = 300, 65600, 200
+    V = torch.rand(N, C, generator=g)
+    if prec != 'f16x':
+        V = V.bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = DenseMU(V.to(dev), W, H, 1.0, precision=prec)
+    assert eng.r_pad == 256 and eng.step_w.nsplit == 1 and eng.step_h.nsplit > 1
+    Wr, Hr = W0, H0
+    for _ in range(2):
+        eng.w_step()
+        eng.h_step()
+        Wr = O.nmf_w_step(V, Wr, Hr, 1, 1.0)
+        Hr = O.nmf_h_step(V, Wr, Hr, 1, 1.0)
+    torch.cuda.synchronize()
+    ew, eh = rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr)
+    record('rank256_fused_apply', prec=prec, relW=ew, relH=eh)
+    assert ew < tol and eh < tol, (ew, eh)
+    assert eng.divergence() == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, 1)), rel=20 * tol)
+
+
 @pytest.mark.parametrize('prec,tol', [('bf16', 5e-3), ('f16', TOL)])
 def test_cfg5_shard_slice_rank256(dev, prec, tol):
     """The rank-256 kernel of BASELINE configs[4]'s per-GPU shard on an 8192 x 16384 slice (the full 262144-column shard
