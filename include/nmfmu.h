@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 6 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+#define NMFMU_ABI_VERSION 7 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
                                3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
@@ -39,7 +39,10 @@ extern "C" {
                                5: nmfmu_gemm_desc.rag_c0 / rag_channels (ragged channels inside the GEMM grid), nmfmu_gemm_ragged_supported,
                                   nmfmu_conv_fold_parts_apply_h_tables / nmfmu_fold_hsum_parts_tables;
                                6: NMFMU_PREC_F16X (fp16 operands, fp32 target); nmfmu_gram_panel / nmfmu_xb_* (beta == 2 without
-                                  the reconstruction); NMFMU_ERR_ALLOC */
+                                  the reconstruction); NMFMU_ERR_ALLOC;
+                               7: nmfmu_gemm_desc.win_* / NMFMU_OPS_A_WIN (H numerator of NMFD / NMF2D / NMF3D without the unfolded Y),
+                                  nmfmu_conv_pack_wk, nmfmu_conv_apply_h_rows; nmfmu_gemm_desc.t_koff, nmfmu_convnd_tables / _table_bytes / _koff (implicit
+                                  operands with several shift axes) */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -303,12 +306,31 @@ typedef struct nmfmu_gemm_desc {
    * (row / column rag_c0.. of x / gn / gp at pitch n_ld).  Replaces a separate nmfmu_conv_ragged_rows launch (modes
    * 0 / 1) when nmfmu_gemm_ragged_supported().  rag_channels == 0: off. */
   int32_t rag_c0, rag_channels;
+  /* (ABI 7, appended) Window operand, ops == NMFMU_OPS_A_WIN with NMFMU_EPI_F32: the H numerator of the convolutive
+   * models without the unfolded Y matrix.  A is never stored: A[(b,j)][(t,c)] = P[(b, j + t)][c], where P = a_hi / a_lo
+   * are the row-major ratio planes of the H half-step ([t_batch * prod(l)][win_pitch] elements, l = lh + taps - 1 per
+   * shift axis) -- tile row (b, j) of k-tile (t, 64 channels) is row (b, j + t) of P, so the operand fetch is the plain
+   * plane fetch with a per-lane row map and a scalar tap offset.  B = [n_pad][k_pad] planes of W ordered
+   * k = (t * ceil(win_channels / 64) + ck) * 64 + c' (nmfmu_conv_pack_wk); k_len = prod(taps) * ceil(win_channels / 64) * 64;
+   * m_pad >= t_batch * prod(lh) rows (b, j), j flattened over the shift axes; n_pad a multiple of 32 (the padded rank).
+   * out[(b,j)][r] = sum_{c,t} P[(b, j + t)][c] W[c][r][t]   (conv backward wrt H, nmf.py:776-779 / 857-860 / 937-940). */
+  int32_t win_nd;          /* shift axes, 1 .. 3 */
+  int32_t win_lh[3];       /* H extent per axis (outermost first; the first win_nd entries) */
+  int32_t win_taps[3];     /* taps per axis */
+  int32_t win_channels;    /* C */
+  int32_t win_pitch;       /* elements per row of P (multiple of 64, >= ceil(C / 64) * 64) */
+  /* (ABI 7) Implicit operands (ops B_HU / B_HUT / A_HU) of an H with SEVERAL shift axes (NMF2D / NMF3D): win_nd > 1,
+   * win_lh / win_taps as above, the operand's hi / lo = the tables of nmfmu_convnd_tables, and t_koff = DEVICE copy of
+   * nmfmu_convnd_koff(ops, ..., k_pad) -- one int per 8-wide k-chunk.  Needs taps and V extent of the LAST axis to be
+   * multiples of 8.  NULL with win_nd <= 1: the one-axis form above (t_taps, t_lh). */
+  const int32_t* t_koff;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
 #define NMFMU_OPS_B_HU 1     /* B = Hu : rows (b,l), k = (r,t)  -- reversed-window table  (W half-step reconstruction) */
 #define NMFMU_OPS_B_HUT 2    /* B = HuT: rows (r,t), k = (b,l)  -- forward-window table   (W numerator)              */
 #define NMFMU_OPS_A_HU 3     /* A = Hu                                                     (H half-step reconstruction) */
+#define NMFMU_OPS_A_WIN 4    /* A = shifted rows of the ratio planes, B = W as [r][(t,c)]  (H numerator; see win_* below)  */
 
 /* nmfmu_conv_tables: the two window tables of H (B, R, Lh) for T taps, bf16 (hi[, lo]):
  *   rev[1 + (b R + r) JJ + jj] = { H[b][r][j], H[b][r][j-1], ..., H[b][r][j-7] }     j = jj - (T-1)
@@ -318,6 +340,26 @@ typedef struct nmfmu_gemm_desc {
 size_t nmfmu_conv_table_bytes(int batch, int rank, int lh, int taps);
 int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, void* rev_hi, void* rev_lo, void* fwd_hi,
                       void* fwd_lo, void* stream);
+
+/* Window tables for several shift axes, H (batch, rank, lh[0..ndim-1]), taps[0..ndim-1] (outermost axis first).  Let
+ * jj_d = lh_d + 2 taps_d - 2 and number the zero-padded lines of H (b, r, p_0, .., p_{n-2}), p_d in [0, jj_d), line
+ * (.., p_d, ..) = H[b][r][p_0 - (taps_0 - 1)] .. (all zero when an index falls outside H).  The tables are the one-axis
+ * tables of these lines along the last axis, concatenated:
+ *   rev[1 + (((b R + r) jj_0 + p_0) .. ) jj_last + p] = { line[j], line[j-1], .., line[j-7] },  j = p - (taps_last - 1)
+ *   fwd[...]                                          = { line[j], line[j+1], .., line[j+7] }
+ * chunk 0 all zero.  The chunk a GEMM lane fetches is (term of its tile row) + koff[k-chunk]:
+ *   rows (b, l), k = (r, t)  (B_HU, A_HU):  row term = b R JJ + sum_d (l_d + taps_d - 1) S_d,
+ *                                           koff[kc] = 1 + r JJ - sum_d t_d S_d              (t = the chunk's first tap)
+ *   rows (r, t), k = (b, l)  (B_HUT):       row term = r JJ + sum_d (taps_d - 1 - t_d) S_d,
+ *                                           koff[kc] = 1 + b R JJ + sum_d l_d S_d
+ * with S_last = 1, S_d = S_{d+1} jj_{d+1}, JJ = prod jj_d; koff = INT32_MIN for k-chunks in the padding of k.
+ * nmfmu_convnd_koff is host code and fills k_pad / 8 + 8 ints (the last 8 are spare: the kernel reads one k-tile ahead);
+ * the caller copies the array to the device. */
+size_t nmfmu_convnd_table_bytes(int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps);
+int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, void* rev_hi,
+                        void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream);
+int nmfmu_convnd_koff(int ops, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, int k_pad,
+                      int32_t* koff_host);
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
 /* NMFMU_PREC_F16 in the GEMM engine: fp16 operand planes / window tables (nmfmu_conv_tables_f16,
@@ -475,6 +517,18 @@ int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const f
                              void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
 int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, const float* y,
                       int bl_pad, void* stream);
+/* The two small kernels around the window-operand GEMM (NMFMU_OPS_A_WIN):
+ *   nmfmu_conv_pack_wk:      Wk[r][(t * CK + ck) * 64 + c'] = w[c = 64 ck + c'][r][t] (CK = ceil(channels / 64); taps =
+ *                            the product over the shift axes, innermost last), planes [rows_pad][k_pad] zero padded
+ *   nmfmu_conv_apply_h_rows: h (batch, rank, lh_total) in place by nmf.py:78-92 from num / den [(b,j)][ld] (den NULL:
+ *                            beta == 1, kl_den[r] = sum_{c,t} W[c][r][t]) */
+int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int rows_pad, int k_pad, int precision,
+                       void* wk_hi, void* wk_lo, void* stream);
+int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_total, const float* num, const float* den,
+                            const float* kl_den, int ld, float l1, float l2, float gamma, void* stream);
+/* slabs[0][i] += slabs[1][i] + .. + slabs[nslab-1][i], fixed order: the partials of a split-K NMFMU_EPI_F32 launch
+ * (k_split slabs of m_pad * n_ld floats) for a consumer that takes one slab.  slab_elems a multiple of 4. */
+int nmfmu_slab_sum(float* slabs, int64_t slab_elems, int nslab, void* stream);
 size_t nmfmu_plca3_part_bytes(int rank);
 int nmfmu_plca3(int mode, float* f, int outer, int rank, int inner, const float* num, int64_t num_pitch, const float* vec,
                 float alpha, int update, float* part, float* colsum_out, float* zgrad_out, void* stream);

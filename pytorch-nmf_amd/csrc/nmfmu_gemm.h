@@ -54,14 +54,26 @@ struct GemmArgs {
   float beta;
   // implicit Toeplitz operand (OPS != kOpsPlanes): the operand's *_hi / *_lo point to a window table
   int tB, tR, tT, tLh;   // H is (B, R, Lh), T taps
+  // ... with more than one shift axis (NMF2D / NMF3D): koff != nullptr.  The tables are the 1-D tables of every last-axis
+  // line of H zero-padded by T_d - 1 lines on both sides of every outer axis (nmfmu_convnd_tables), so the chunk index is
+  // still (a term of the tile row) + (a term of the k-chunk); the latter comes precomputed, one int per k-chunk
+  // (INT_MIN: padding of k), the former from win_lh / win_t / win_l below.  tT / tLh hold the products over the axes.
+  const int* koff;
   // ragged channels inside the grid (EPI_RATIO with an implicit Hu operand): channels [rag_c0, rag_C), at most 16, are
   // not part of the GEMM's own tiles (one or two rows would cost a whole tile row, i.e. a second scheduling round);
   // every workgroup carries one extra 16 x 16 MFMA block for them (see nt_gemm_kernel).  rag_C <= rag_c0: off.
   int rag_c0, rag_C;
+  // window operand (OPS == kOpsAWin): A[(b,j)][(t, c)] = P[(b, j + t)][c] -- the rows of A are shifted rows of the
+  // row-major plane(s) a_hi / a_lo (the ratio planes of the H half-step, [(b,l)][c]); nothing is unfolded.  Shift axes
+  // outermost first, missing leading axes have extent 1.
+  int win_lh[3], win_t[3], win_l[3];   // H extent, taps, V extent (= lh + t - 1) per shift axis
+  int win_rows;                        // B * prod(lh): rows of A that exist
+  int win_ck;                          // 64-channel k-tiles per tap (k = (t * win_ck + ck) * 64 + c')
+  unsigned win_pitch;                  // bytes per row of P
 };
 
 // which operand is fetched from a window table of H instead of from planes (nmfmu.h: NMFMU_OPS_*)
-enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3 };
+enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3, kOpsAWin = 4 };
 
 // Workgroup tile shape.  WM x WN waves, each MI x NI MFMA 32x32 blocks: 128 x 128, 256 threads, two workgroups per CU.
 // (A 256 x 256 / eight-wave instance of this template was built and parity-tested in round 2: half the operand bytes
@@ -74,6 +86,9 @@ struct GemmShape {
   static constexpr int BM = WM * MI * 32, BN = WN * NI * 32, THREADS = 64 * WM * WN;
 };
 using GemmSmall = GemmShape<2, 2, 2, 2>;
+// narrow-N tiles (128 x 32, 128 x 64) for the window-operand GEMM, whose N is the rank
+using GemmN32 = GemmShape<4, 1, 1, 1>;
+using GemmN64 = GemmShape<4, 1, 1, 2>;
 // (256 x 128 and 128 x 256 with eight 64 x 64 waves were measured too: same time as two 128 x 128 workgroups per CU.)
 
 template <bool X3, class SH>
@@ -90,7 +105,7 @@ struct GemmCfg {
   static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
 };
 
-template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT>
+template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT, bool ND>
 __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
   using C = GemmCfg<X3, SH>;
   static_assert(!(X3 && OPT == kOpF16), "fp16 operands are single-plane");
@@ -149,10 +164,11 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl)
-        src[op * C::NPL + pl] = bases[op * 2 + pl] + (size_t)(op == 0 ? bm * C::BM : bn * C::BN) * ldk;
+        src[op * C::NPL + pl] = bases[op * 2 + pl] + ((OPS == kOpsAWin && op == 0) ? (size_t)0 : (size_t)(op == 0 ? bm * C::BM : bn * C::BN) * ldk);
   }
+  constexpr bool kToep = OPS == kOpsBHu || OPS == kOpsBHuT || OPS == kOpsAHu;   // an operand fetched from window tables
   const char* tab[2] = {nullptr, nullptr};   // window table planes of the implicit operand
-  if constexpr (OPS != kOpsPlanes) {
+  if constexpr (kToep) {
     tab[0] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_hi : a.b_hi);
     tab[1] = reinterpret_cast<const char*>(OPS == kOpsAHu ? a.a_lo : a.b_lo);
   }
@@ -169,7 +185,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   constexpr int TROWS = TOP == 0 ? C::BM : C::BN;             // rows of the implicit operand's tile
   constexpr int TP = TOP == 0 ? C::PA : C::PB;
   constexpr int KPP = THREADS / TROWS;                        // k-chunks of the implicit operand per DMA pass
-  static_assert(OPS == kOpsPlanes || (KPP * TROWS == THREADS && KPP * TP == 8), "whole k-chunks per DMA pass");
+  static_assert(!kToep || (KPP * TROWS == THREADS && KPP * TP == 8), "whole k-chunks per DMA pass");
   constexpr bool kHuRows = OPS == kOpsBHu || OPS == kOpsAHu;  // rows (b,l), k = (r,t); else rows (r,t), k = (b,l)
   int trow = -1;      // chunk-index contribution of this thread's row (the same in all passes), -1 = padding row
   int tL = 0, tJJ = 0, tT8 = 0;
@@ -177,10 +193,24 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   // stage_issue call, which come strictly in k order (no integer division in the loop):
   //   rows-(b,l) operand: k = r T + 8 tc  -> (kq, kr) = (r, tc);   rows-(r,t) operand: k = b L + l0 -> (kq, kr) = (b, l0)
   int kq[4] = {0, 0, 0, 0}, kr[4] = {0, 0, 0, 0};
-  if constexpr (OPS != kOpsPlanes) {
+  int nd_soff[4] = {0, 0, 0, 0};      // ND: koff of the chunks the next stage_issue call fetches
+  if constexpr (kToep) {
     tL = a.tLh + a.tT - 1, tJJ = a.tLh + 2 * a.tT - 2, tT8 = a.tT / 8;
     const int row = (TOP == 0 ? bm : bn) * TROWS + (tid % TROWS);
-    if constexpr (kHuRows) {   // row = b L + l  ->  (b R) JJ + l + (T - 1)
+    if constexpr (ND) {        // several shift axes: the same two forms with one term per axis
+      const int jj2 = a.win_l[2] + a.win_t[2] - 1, jj1 = a.win_l[1] + a.win_t[1] - 1, jj0 = a.win_l[0] + a.win_t[0] - 1;
+      const int jjt = jj0 * jj1 * jj2;
+      if constexpr (kHuRows) {
+        const int l_tot = a.win_l[0] * a.win_l[1] * a.win_l[2];
+        const int b = row / l_tot, lf = row - b * l_tot;
+        const int l2 = lf % a.win_l[2], l01 = lf / a.win_l[2], l1 = l01 % a.win_l[1], l0 = l01 / a.win_l[1];
+        trow = b < a.tB ? b * a.tR * jjt + ((l0 + a.win_t[0] - 1) * jj1 + l1 + a.win_t[1] - 1) * jj2 + l2 + a.win_t[2] - 1 : -1;
+      } else {
+        const int r = row / a.tT, tf = row - r * a.tT;
+        const int t2 = tf % a.win_t[2], t01 = tf / a.win_t[2], t1 = t01 % a.win_t[1], t0 = t01 / a.win_t[1];
+        trow = r < a.tR ? r * jjt + ((a.win_t[0] - 1 - t0) * jj1 + a.win_t[1] - 1 - t1) * jj2 + a.win_t[2] - 1 - t2 : -1;
+      }
+    } else if constexpr (kHuRows) {   // row = b L + l  ->  (b R) JJ + l + (T - 1)
       const int b = row / tL, l = row - b * tL;
       trow = b < a.tB ? b * a.tR * tJJ + l + a.tT - 1 : -1;
     } else {                   // row = r T + t  ->  r JJ - t + (T - 1)
@@ -192,7 +222,8 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       // (wave-uniform: a wave's 64 lanes are 64 consecutive rows of ONE k-chunk -- kept in scalar registers, so the
       // per-k-tile position arithmetic below costs no vector instructions)
       const int kc = kt0 * 8 + KPP * p + __builtin_amdgcn_readfirstlane(tid / TROWS);     // 8 chunks per k-tile
-      if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
+      if constexpr (ND) kq[p] = kc, nd_soff[p] = a.koff[kc];     // the k-chunk itself: index into koff
+      else if constexpr (kHuRows) kq[p] = kc / tT8, kr[p] = kc - kq[p] * tT8;
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
   }
@@ -200,14 +231,18 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     // scalar part first (k position), then one vector add / select for the lane's row
     int soff;
     bool live;
-    if constexpr (kHuRows) soff = 1 + kq[p] * tJJ - 8 * kr[p], live = kq[p] < a.tR;
+    if constexpr (ND) soff = nd_soff[p], live = soff != INT_MIN;
+    else if constexpr (kHuRows) soff = 1 + kq[p] * tJJ - 8 * kr[p], live = kq[p] < a.tR;
     else soff = 1 + kq[p] * a.tR * tJJ + kr[p], live = kq[p] < a.tB;
     return (live && trow >= 0) ? trow + soff : 0;
   };
   auto toep_advance = [&]() {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      if constexpr (kHuRows) {
+      if constexpr (ND) {
+        kq[p] += 8;
+        nd_soff[p] = a.koff[kq[p]];     // for the NEXT k-tile: the scalar load has a whole k-tile to land (koff carries 8 spare ints)
+      } else if constexpr (kHuRows) {
         kr[p] += 8;
         while (kr[p] >= tT8) kr[p] -= tT8, ++kq[p];
       } else {
@@ -227,6 +262,35 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   unsigned voff_exp[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) voff_exp[p] = (unsigned)(thr_off + (size_t)p * (THREADS / 8) * ldk);
+  // ---- window operand (kOpsAWin): tile row m = (b, j) reads plane row (b, j + t); the row map is per thread and pass,
+  // the tap offset of the k-tile (t, ck) is scalar and advances with carries (k-tiles come strictly in order)
+  unsigned voff_win[4] = {0, 0, 0, 0};
+  int wk_ck = 0, wk_t1 = 0, wk_t2 = 0, wk_off = 0;
+  if constexpr (OPS == kOpsAWin) {
+    const int lh_tot = a.win_lh[0] * a.win_lh[1] * a.win_lh[2], l_tot = a.win_l[0] * a.win_l[1] * a.win_l[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(bm * C::BM + row_t + p * (THREADS / 8), a.win_rows - 1);
+      const int b = m / lh_tot, jf = m - b * lh_tot;
+      const int j2 = jf % a.win_lh[2], j01 = jf / a.win_lh[2], j1 = j01 % a.win_lh[1], j0 = j01 / a.win_lh[1];
+      voff_win[p] = (unsigned)(b * l_tot + (j0 * a.win_l[1] + j1) * a.win_l[2] + j2) * a.win_pitch + sslot * 16;
+    }
+    const int tf = kt0 / a.win_ck;
+    wk_ck = kt0 - tf * a.win_ck;
+    wk_t2 = tf % a.win_t[2];
+    const int t01 = tf / a.win_t[2];
+    wk_t1 = t01 % a.win_t[1];
+    wk_off = ((t01 / a.win_t[1]) * a.win_l[1] + wk_t1) * a.win_l[2] + wk_t2;
+  }
+  auto win_advance = [&]() {
+    if (++wk_ck == a.win_ck) {
+      wk_ck = 0, ++wk_off;
+      if (++wk_t2 == a.win_t[2]) {
+        wk_t2 = 0, wk_off += a.win_l[2] - a.win_t[2];
+        if (++wk_t1 == a.win_t[1]) wk_t1 = 0, wk_off += (a.win_l[1] - a.win_t[1]) * a.win_l[2];
+      }
+    }
+  };
   auto dma1k = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :
@@ -238,15 +302,17 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl) {
-        const bool implicit = OPS != kOpsPlanes && op == TOP;
-        const char* s0 = src[op * C::NPL + pl] + (size_t)(kt0 + kt) * (C::BK * 2);     // scalar
+        const bool implicit = kToep && op == TOP;
+        const char* s0 = (OPS == kOpsAWin && op == 0)
+                             ? src[op * C::NPL + pl] + (size_t)wk_off * a.win_pitch + wk_ck * (C::BK * 2)
+                             : src[op * C::NPL + pl] + (size_t)(kt0 + kt) * (C::BK * 2);     // scalar
         const int passes = op == 0 ? C::PA : C::PB;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           if (p < passes) {
             const unsigned dst = lds_base + buf * C::STAGE + tile_off(op, pl) + p * (THREADS * 16) + wave * 1024;
             if (implicit) dma1k(tab[pl], (unsigned)toep_index(p) * 16u, dst);
-            else dma1k(s0, voff_exp[p], dst);
+            else dma1k(s0, (OPS == kOpsAWin && op == 0) ? voff_win[p] : voff_exp[p], dst);
           }
         }
       }
@@ -260,7 +326,8 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
                 lds_base + 2 * C::STAGE + (buf * C::NPL + pl) * C::RAG_TILE + wave * 1024);
       }
     }
-    if constexpr (OPS != kOpsPlanes) toep_advance();
+    if constexpr (kToep) toep_advance();
+    if constexpr (OPS == kOpsAWin) win_advance();
   };
   (void)TP; (void)KPP;
   f32x4 racc = {0.f, 0.f, 0.f, 0.f};
@@ -513,7 +580,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   }
 }
 
-template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16, bool ND = false>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   using C = GemmCfg<X3, SH>;
   constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
@@ -521,7 +588,7 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
   constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT, ND>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {

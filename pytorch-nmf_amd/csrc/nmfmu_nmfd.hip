@@ -28,6 +28,19 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs
 #undef GF16
     return -2;
   }
+  if (a.koff) {
+    // implicit operands with several shift axes (NMF2D / NMF3D): the same combinations, ND instances
+#define N1(X, E, B, O) \
+  if (x3 == (X ? 1 : 0) && epi == E && (E == kEpiF32 || beta_kind == B) && ops == O) \
+    return launch_gemm_one<X, E, B, O, GemmSmall, kOpBf16, true>(a, s);
+#define NB(X, E, O) N1(X, E, kKL, O) N1(X, E, kEuc, O) N1(X, E, kIS, O) N1(X, E, kGen, O)
+    NB(false, kEpiRatio, kOpsBHu) NB(true, kEpiRatio, kOpsBHu) NB(false, kEpiRatio, kOpsAHu) NB(true, kEpiRatio, kOpsAHu)
+    NB(false, kEpiLoss, kOpsBHu) NB(true, kEpiLoss, kOpsBHu)
+    N1(false, kEpiF32, kEuc, kOpsBHuT) N1(true, kEpiF32, kEuc, kOpsBHuT)
+#undef NB
+#undef N1
+    return -2;
+  }
   // operand combinations that occur (nmfd_engine.py): RATIO with planes | B = Hu | A = Hu; F32 with planes | B = HuT;
   // LOSS with planes | B = Hu
 #define G1(X, E, B, O) \
@@ -42,6 +55,13 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs
     return x3 ? launch_gemm_one<true, kEpiF32, kEuc, kOpsBHuT>(a, s) : launch_gemm_one<false, kEpiF32, kEuc, kOpsBHuT>(a, s);
   if (epi == kEpiFold && ops == kOpsPlanes)
     return x3 ? launch_gemm_one<true, kEpiFold, kEuc>(a, s) : launch_gemm_one<false, kEpiFold, kEuc>(a, s);
+  if (epi == kEpiF32 && ops == kOpsAWin) {   // N = the (padded) rank: 32-, 64- or 128-wide tiles
+#define GW(SH) return x3 ? launch_gemm_one<true, kEpiF32, kEuc, kOpsAWin, SH>(a, s) : launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, SH>(a, s);
+    if (a.n_pad % 128 == 0) GW(GemmSmall)
+    if (a.n_pad % 64 == 0) GW(GemmN64)
+    GW(GemmN32)
+#undef GW
+  }
 #undef GB
 #undef G1
   return -2;
@@ -144,6 +164,53 @@ __global__ void __launch_bounds__(256) conv_tables_kernel(const float* __restric
   }
 }
 
+// The same tables for H with up to three shift axes (B, R, lh0, lh1, lh2): one 1-D table (along the last axis) per line
+// of H zero-padded by t_d - 1 lines on both sides of every outer axis, lines in (b, r, p0, p1) order -- see
+// nmfmu_convnd_tables in include/nmfmu.h.  One thread per chunk.
+struct ConvGeom {
+  int lh[3], t[3], l[3];   // H extent, taps, V extent (= lh + t - 1) per shift axis
+  int lh_tot, t_tot, l_tot;
+};
+
+__global__ void __launch_bounds__(256) convnd_tables_kernel(const float* __restrict__ H, int B, int R, ConvGeom g,
+                                                            u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo) {
+  const int jj2 = g.l[2] + g.t[2] - 1, jj1 = g.l[1] + g.t[1] - 1, jj0 = g.l[0] + g.t[0] - 1;
+  const int64_t n = 1 + (int64_t)B * R * jj0 * jj1 * jj2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float vr[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vr[e] = vf[e] = 0.f;
+    if (i > 0) {
+      const int64_t k = i - 1;
+      const int p2 = (int)(k % jj2);
+      const int64_t k1 = k / jj2;
+      const int p1 = (int)(k1 % jj1);
+      const int64_t k0 = k1 / jj1;
+      const int p0 = (int)(k0 % jj0), br = (int)(k0 / jj0);
+      const int j0 = p0 - (g.t[0] - 1), j1 = p1 - (g.t[1] - 1), j = p2 - (g.t[2] - 1);
+      if (j0 >= 0 && j0 < g.lh[0] && j1 >= 0 && j1 < g.lh[1]) {
+        const float* row = H + (((size_t)br * g.lh[0] + j0) * g.lh[1] + j1) * g.lh[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int jr = j - e, jf = j + e;
+          if (jr >= 0 && jr < g.lh[2]) vr[e] = row[jr];
+          if (jf >= 0 && jf < g.lh[2]) vf[e] = row[jf];
+        }
+      }
+    }
+    u32x4 rh, rl, fh, fl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h = pack_bf16(vr[2 * e], vr[2 * e + 1]);
+      rh[e] = h, rl[e] = pack_bf16(vr[2 * e] - bf16_lo(h), vr[2 * e + 1] - bf16_hi(h));
+      h = pack_bf16(vf[2 * e], vf[2 * e + 1]);
+      fh[e] = h, fl[e] = pack_bf16(vf[2 * e] - bf16_lo(h), vf[2 * e + 1] - bf16_hi(h));
+    }
+    rev_hi[i] = rh, fwd_hi[i] = fh;
+    if (rev_lo) rev_lo[i] = rl, fwd_lo[i] = fl;
+  }
+}
+
 // Toeplitz unfold of H (B, R, Lh): Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], both bf16 (hi[, lo]) zero padded.
 __global__ void __launch_bounds__(256) conv_unfold_kernel(const float* __restrict__ H, int B, int R, int Lh, int T,
                                                           uint16_t* hu_hi, uint16_t* hu_lo, uint16_t* hut_hi,
@@ -194,6 +261,25 @@ __global__ void __launch_bounds__(256) conv_unfold_kernel(const float* __restric
   }
 }
 
+// slabs[0][i] += slabs[1][i] + ... (fixed order): the split-K partials of a GEMM, before a consumer that takes one slab
+__global__ void __launch_bounds__(256) slab_sum_kernel(float* __restrict__ slabs, int64_t n4, int nslab) {
+  float4* p = reinterpret_cast<float4*>(slabs);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = p[i];
+    int sl = 1;
+    for (; sl + 4 <= nslab; sl += 4) {     // four loads in flight, added in slab order
+      const float4 v0 = p[sl * n4 + i], v1 = p[(sl + 1) * n4 + i], v2 = p[(sl + 2) * n4 + i], v3 = p[(sl + 3) * n4 + i];
+      acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x, acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
+      acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z, acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; sl < nslab; ++sl) {
+      const float4 v = p[sl * n4 + i];
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    p[i] = acc;
+  }
+}
+
 // out[r] = sum_{o, i} src[(o * R + r) * inner + i].  Two stages, fixed order (deterministic): grid (R, kRankChunks)
 // partial sums over contiguous `inner` runs, then one small block per r.
 constexpr int kRankChunks = 128;
@@ -202,20 +288,20 @@ __global__ void __launch_bounds__(256) rank_sums_partial_kernel(const float* __r
                                                                 float* __restrict__ part) {
   __shared__ float red[256];
   const int r = blockIdx.x, ch = blockIdx.y;
-  float s = 0.f;
-  for (int o = ch; o < outer; o += kRankChunks) {          // one (o, r) run = `inner` contiguous floats
-    const float* p = src + ((size_t)o * R + r) * inner;
-    for (int i = threadIdx.x; i < inner; i += 256) s += p[i];
-  }
-  if (outer < kRankChunks) {                                // few long runs (H: outer = batch): split the run instead
-    s = 0.f;
-    for (int o = 0; o < outer; ++o) {
-      const float* p = src + ((size_t)o * R + r) * inner;
-      const int per = (inner + kRankChunks - 1) / kRankChunks;
-      const int lo = ch * per, hi = min(inner, lo + per);
-      for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
-    }
-  }
+  // the (o, i) pairs of rank r, flattened, in kRankChunks equal ranges (whatever the shape: many short runs -- W of a
+  // small-kernel NMF2D, 64 runs of 128 -- or few long ones -- H); four independent partial sums per thread
+  const int64_t total = (int64_t)outer * inner;
+  const int64_t per = (total + kRankChunks - 1) / kRankChunks;
+  const int64_t lo = ch * per, hi = min(total, lo + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  auto at = [&](int64_t e) {
+    const int o = (int)(e / inner), i = (int)(e - (int64_t)o * inner);
+    return src[((size_t)o * R + r) * inner + i];
+  };
+  int64_t e = lo + threadIdx.x;
+  for (; e + 768 < hi; e += 1024) s0 += at(e), s1 += at(e + 256), s2 += at(e + 512), s3 += at(e + 768);
+  for (; e < hi; e += 256) s0 += at(e);
+  const float s = (s0 + s1) + (s2 + s3);
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -293,6 +379,8 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
     for (int sl = 1; sl < num_slabs; ++sl)     // split-K partials of the numerator GEMM ([slab][c_pad][rp_pad])
       nv[i] += (in && update) ? num[(size_t)sl * c_pad * rp_pad + (size_t)c * rp_pad + kk] : 0.f;
     dv[i] = (in && update && !klm) ? den[(size_t)c * rp_pad + kk] : 0.f;
+    for (int sl = 1; sl < num_slabs; ++sl)
+      dv[i] += (in && update && !klm) ? den[(size_t)sl * c_pad * rp_pad + (size_t)c * rp_pad + kk] : 0.f;
   }
   // ... then the beta == 1 denominators sum_{b,j} H[b][r][j], handed over as per-block partials of the kernel that
   // updated H (kl_hpart[r][n_hparts]).  With T >= 64 a 64-wide k range touches at most two ranks: every wave finishes
@@ -684,11 +772,6 @@ __global__ void __launch_bounds__(512) conv_ragged_rows_kernel(RaggedArgs a) {
 // first and missing leading axes have extent 1, so 1-D .. 3-D share this code.  Used by the explicit-operand path
 // only (these layers are small: the reference's own examples are (33,50) x 3x3 and (64,64,100) x 5x5x20).
 // ------------------------------------------------------------------------------------------------------------
-struct ConvGeom {
-  int lh[3], t[3], l[3];   // H extent, taps, V extent (= lh + t - 1) per shift axis
-  int lh_tot, t_tot, l_tot;
-};
-
 // Hu [(b,l)][(r,t)] and HuT [(r,t)][(b,l)], bf16 (hi[, lo]) zero padded: one thread per 8 consecutive columns.
 // The row index is decomposed once per thread and the column index once, then advanced with carries (the naive
 // per-element div/mod chain made this kernel ALU-bound at ~2.5 ms for a 256 x 512 frame).
@@ -760,6 +843,51 @@ __global__ void __launch_bounds__(256) convnd_fold_apply_h_kernel(float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// H numerator as a window-operand GEMM (NMFMU_OPS_A_WIN): the two small kernels around it.
+// ------------------------------------------------------------------------------------------------------------
+// Wk[r][(t * CK + ck) * 64 + c'] = W[c = ck * 64 + c'][r][t], zero padded: the B operand.  One thread per 16-byte chunk.
+__global__ void __launch_bounds__(256) conv_pack_wk_kernel(const float* __restrict__ W, int C, int R, int T, int CK,
+                                                           int rows_pad, int k_pad, uint16_t* hi, uint16_t* lo, int f16) {
+  const int64_t n8 = (int64_t)rows_pad * (k_pad / 8);
+  const int ct = CK * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (k_pad / 8)), k0 = (int)(i % (k_pad / 8)) * 8;
+    const int t = k0 / ct, c0 = k0 - t * ct;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r < R && t < T && c0 + e < C) ? W[((size_t)(c0 + e) * R + r) * T + t] : 0.f;
+    u32x4 h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t h = pack_img(v[2 * e], v[2 * e + 1], f16);
+      h4[e] = h;
+      l4[e] = pack_bf16(v[2 * e] - bf16_lo(h), v[2 * e + 1] - bf16_hi(h));
+    }
+    const size_t o = (size_t)r * k_pad + k0;
+    *reinterpret_cast<u32x4*>(hi + o) = h4;
+    if (lo) *reinterpret_cast<u32x4*>(lo + o) = l4;
+  }
+}
+
+// H (B, R, lh_tot) in place from num / den [(b,j)][ld] (rows = positions, columns = rank).  One thread per position.
+__global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restrict__ H, int B, int R, int lh_tot,
+                                                                const float* __restrict__ num,
+                                                                const float* __restrict__ den,
+                                                                const float* __restrict__ kl_den, int ld, float l1,
+                                                                float l2, float gamma) {
+  const int64_t n = (int64_t)B * lh_tot;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / lh_tot), jf = (int)(i - (int64_t)b * lh_tot);
+    const float* nrow = num + (size_t)i * ld;
+    const float* drow = den ? den + (size_t)i * ld : nullptr;
+    for (int r = 0; r < R; ++r) {
+      const size_t o = ((size_t)b * R + r) * lh_tot + jf;
+      H[o] = mu_update(H[o], nrow[r], kl_den ? kl_den[r] : drow[r], kl_den != nullptr, l1, l2, gamma);
+    }
+  }
+}
+
 }  // namespace nmfmu
 
 using namespace nmfmu;
@@ -767,6 +895,22 @@ using namespace nmfmu;
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
+
+static int make_geom(int nd, const int32_t* lh, const int32_t* taps, ConvGeom* g) {
+  if (nd < 1 || nd > 3 || !lh || !taps) return NMFMU_ERR_ARG;
+  for (int d = 0; d < 3; ++d) g->lh[d] = g->t[d] = g->l[d] = 1;
+  int64_t lt = 1, tt = 1, ht = 1;
+  for (int d = 0; d < nd; ++d) {
+    const int s = 3 - nd + d;
+    if (lh[d] <= 0 || taps[d] <= 0) return NMFMU_ERR_ARG;
+    g->lh[s] = lh[d], g->t[s] = taps[d], g->l[s] = lh[d] + taps[d] - 1;
+    lt *= g->l[s], tt *= taps[d], ht *= lh[d];
+  }
+  if (lt > INT32_MAX / 4 || tt > INT32_MAX / 4) return NMFMU_ERR_ARG;
+  g->l_tot = (int)lt, g->t_tot = (int)tt, g->lh_tot = (int)ht;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -784,7 +928,8 @@ int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops) {
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
-  if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % 128 || d->k_pad % 128)
+  const int n_mult = d->ops == NMFMU_OPS_A_WIN ? 32 : 128;   // the window-operand GEMM has narrow-N tiles (N = rank)
+  if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % n_mult || d->k_pad % 128)
     return NMFMU_ERR_ARG;
   const int x3 = d->precision == NMFMU_PREC_BF16X3, f16 = d->precision == NMFMU_PREC_F16;
   if (x3 && (!d->a_lo || !d->b_lo)) return NMFMU_ERR_ARG;
@@ -810,8 +955,33 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   a.out = d->out;
   a.m_valid = d->m_valid, a.n_valid = d->n_valid;
   a.beta = d->beta;
-  if (d->ops < NMFMU_OPS_PLANES || d->ops > NMFMU_OPS_A_HU) return NMFMU_ERR_ARG;
-  if (d->ops != NMFMU_OPS_PLANES) {
+  if (d->ops < NMFMU_OPS_PLANES || d->ops > NMFMU_OPS_A_WIN) return NMFMU_ERR_ARG;
+  ConvGeom geom{};
+  const bool nd_geom = d->ops == NMFMU_OPS_A_WIN || (d->ops != NMFMU_OPS_PLANES && d->win_nd > 1);
+  if (nd_geom) {
+    if (d->t_batch <= 0 || d->t_rank <= 0 || make_geom(d->win_nd, d->win_lh, d->win_taps, &geom)) return NMFMU_ERR_ARG;
+    for (int i = 0; i < 3; ++i) a.win_lh[i] = geom.lh[i], a.win_t[i] = geom.t[i], a.win_l[i] = geom.l[i];
+  }
+  if (d->ops == NMFMU_OPS_A_WIN) {
+    // A[(b,j)][(t,c)] = P[(b, j + t)][c]: rows of the plane(s) a_hi / a_lo ([batch * prod(l)][win_pitch]) shifted by the tap
+    if (epilogue != NMFMU_EPI_F32 || f16 || a.k_split != 1) return NMFMU_ERR_ARG;
+    if (d->win_pitch <= 0 || d->win_pitch % 64 || d->win_channels <= 0 || d->win_channels > d->win_pitch) return NMFMU_ERR_ARG;
+    a.win_ck = (d->win_channels + 63) / 64;
+    if (a.win_ck * 64 > d->win_pitch) return NMFMU_ERR_ARG;
+    a.win_pitch = (unsigned)d->win_pitch * 2u;
+    if ((int64_t)d->t_batch * geom.lh_tot > d->m_pad || (int64_t)d->t_batch * geom.l_tot * a.win_pitch >= ((int64_t)1 << 32)) return NMFMU_ERR_ARG;
+    a.win_rows = d->t_batch * geom.lh_tot;
+    if ((int64_t)a.k_len != (int64_t)geom.t_tot * a.win_ck * 64) return NMFMU_ERR_ARG;   // k = (t, ck, c')
+  } else if (nd_geom) {
+    // window tables of an H with several shift axes (nmfmu_convnd_tables); t_koff from nmfmu_convnd_koff, on the device
+    if (!d->t_koff || f16 || epilogue == NMFMU_EPI_FOLD || d->rag_channels > 0) return NMFMU_ERR_ARG;
+    if (geom.t[2] % 8 || geom.l[2] % 8) return NMFMU_ERR_ARG;
+    a.tB = d->t_batch, a.tR = d->t_rank, a.tT = geom.t_tot, a.tLh = geom.lh_tot;
+    a.koff = d->t_koff;
+    const int64_t bl = (int64_t)a.tB * geom.l_tot, rt = (int64_t)a.tR * geom.t_tot;
+    const int hu_rows = d->ops == NMFMU_OPS_A_HU ? d->m_pad : d->n_pad;
+    if (d->ops == NMFMU_OPS_B_HUT ? (hu_rows < rt || d->k_pad < bl) : (hu_rows < bl || d->k_pad < rt)) return NMFMU_ERR_ARG;
+  } else if (d->ops != NMFMU_OPS_PLANES) {
     a.tB = d->t_batch, a.tR = d->t_rank, a.tT = d->t_taps, a.tLh = d->t_lh;
     if (a.tB <= 0 || a.tR <= 0 || a.tT <= 0 || a.tLh <= 0 || a.tT % 8 || (a.tLh + a.tT - 1) % 8) return NMFMU_ERR_ARG;
     const int64_t bl = (int64_t)a.tB * (a.tLh + a.tT - 1), rt = (int64_t)a.tR * a.tT;   // logical extents of Hu
@@ -953,7 +1123,7 @@ int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, con
                                  const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
                                  int c_pad, int rp_pad, float l1, float l2, float gamma, int update, int precision,
                                  void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream) {
-  if (num_slabs < 1 || num_slabs > 8) return NMFMU_ERR_ARG;
+  if (num_slabs < 1 || num_slabs > 64) return NMFMU_ERR_ARG;
   if (precision != NMFMU_PREC_BF16 && precision != NMFMU_PREC_BF16X3 && precision != NMFMU_PREC_F16) return NMFMU_ERR_ARG;
   if ((precision == NMFMU_PREC_BF16X3) != (wm_lo != nullptr)) return NMFMU_ERR_ARG;
   return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
@@ -1091,21 +1261,6 @@ int nmfmu_conv_fold_parts_apply_h_sums(float* h, int batch, int rank, int lh, in
                           gamma, stream);
 }
 
-static int make_geom(int nd, const int32_t* lh, const int32_t* taps, ConvGeom* g) {
-  if (nd < 1 || nd > 3 || !lh || !taps) return NMFMU_ERR_ARG;
-  for (int d = 0; d < 3; ++d) g->lh[d] = g->t[d] = g->l[d] = 1;
-  int64_t lt = 1, tt = 1, ht = 1;
-  for (int d = 0; d < nd; ++d) {
-    const int s = 3 - nd + d;
-    if (lh[d] <= 0 || taps[d] <= 0) return NMFMU_ERR_ARG;
-    g->lh[s] = lh[d], g->t[s] = taps[d], g->l[s] = lh[d] + taps[d] - 1;
-    lt *= g->l[s], tt *= taps[d], ht *= lh[d];
-  }
-  if (lt > INT32_MAX / 4 || tt > INT32_MAX / 4) return NMFMU_ERR_ARG;
-  g->l_tot = (int)lt, g->t_tot = (int)tt, g->lh_tot = (int)ht;
-  return 0;
-}
-
 int nmfmu_convnd_unfold(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps,
                         void* hu_hi, void* hu_lo, void* hut_hi, void* hut_lo, int bl_pad, int rp_pad, void* stream) {
   ConvGeom g;
@@ -1140,6 +1295,81 @@ int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* 
   const int64_t n = (int64_t)batch * rank * g.lh_tot;
   hipLaunchKernelGGL(convnd_fold_apply_h_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), out, batch, rank, g, y,
                      (const float*)nullptr, y /* non-null: skips the den loop */, bl_pad, 0.f, 0.f, 1.f, out);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int rows_pad, int k_pad, int precision,
+                       void* wk_hi, void* wk_lo, void* stream) {
+  if (!w || !wk_hi || channels <= 0 || rank <= 0 || taps <= 0 || rows_pad < rank || k_pad % 8) return NMFMU_ERR_ARG;
+  const int ck = (channels + 63) / 64;
+  if ((int64_t)k_pad < (int64_t)taps * ck * 64) return NMFMU_ERR_ARG;
+  if (precision == NMFMU_PREC_BF16X3 && !wk_lo) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)rows_pad * (k_pad / 8);
+  hipLaunchKernelGGL(conv_pack_wk_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, channels, rank, taps, ck, rows_pad,
+                     k_pad, (uint16_t*)wk_hi, (uint16_t*)(precision == NMFMU_PREC_BF16X3 ? wk_lo : nullptr),
+                     (int)(precision == NMFMU_PREC_F16));
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_total, const float* num, const float* den,
+                            const float* kl_den, int ld, float l1, float l2, float gamma, void* stream) {
+  if (!h || !num || (!den && !kl_den) || batch <= 0 || rank <= 0 || lh_total <= 0 || ld < rank) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * lh_total;
+  hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh_total, num,
+                     den, kl_den, ld, l1, l2, gamma);
+  return (int)hipGetLastError();
+}
+
+size_t nmfmu_convnd_table_bytes(int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps) {
+  ConvGeom g;
+  if (batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g)) return 0;
+  size_t n = (size_t)batch * rank;
+  for (int d = 0; d < 3; ++d) n *= (size_t)(g.l[d] + g.t[d] - 1);
+  return (1 + n) * 16;
+}
+
+int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, void* rev_hi,
+                        void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream) {
+  ConvGeom g;
+  if (!h || !rev_hi || !fwd_hi || batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g)) return NMFMU_ERR_ARG;
+  if (g.t[2] % 8 || g.l[2] % 8 || (rev_lo == nullptr) != (fwd_lo == nullptr)) return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)(nmfmu_convnd_table_bytes(batch, rank, ndim, lh, taps) / 16);
+  if (n > INT32_MAX) return NMFMU_ERR_ARG;     // chunk indices are 32-bit in the GEMM
+  hipLaunchKernelGGL(convnd_tables_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, g, (u32x4*)rev_hi,
+                     (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_convnd_koff(int ops, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, int k_pad,
+                      int32_t* koff_host) {
+  ConvGeom g;
+  if (!koff_host || batch <= 0 || rank <= 0 || k_pad <= 0 || k_pad % 8 || make_geom(ndim, lh, taps, &g)) return NMFMU_ERR_ARG;
+  if (g.t[2] % 8 || g.l[2] % 8) return NMFMU_ERR_ARG;
+  const int64_t jj2 = g.l[2] + g.t[2] - 1, jj1 = g.l[1] + g.t[1] - 1, jj0 = g.l[0] + g.t[0] - 1, jjt = jj0 * jj1 * jj2;
+  if (1 + (int64_t)batch * rank * jjt > INT32_MAX) return NMFMU_ERR_ARG;
+  for (int kc = k_pad / 8; kc < k_pad / 8 + 8; ++kc) koff_host[kc] = INT32_MIN;   // spare: the kernel reads one k-tile ahead
+  if (ops == NMFMU_OPS_B_HU || ops == NMFMU_OPS_A_HU) {           // k = (r, t0, t1, t2): chunk = 8 consecutive t2
+    for (int kc = 0; kc < k_pad / 8; ++kc) {
+      const int k0 = kc * 8, r = k0 / g.t_tot, tf = k0 - r * g.t_tot;
+      const int t2 = tf % g.t[2], t01 = tf / g.t[2], t1 = t01 % g.t[1], t0 = t01 / g.t[1];
+      koff_host[kc] = r < rank ? (int32_t)(1 + r * jjt - ((int64_t)t0 * jj1 + t1) * jj2 - t2) : INT32_MIN;
+    }
+  } else if (ops == NMFMU_OPS_B_HUT) {                            // k = (b, l0, l1, l2): chunk = 8 consecutive l2
+    for (int kc = 0; kc < k_pad / 8; ++kc) {
+      const int k0 = kc * 8, b = k0 / g.l_tot, lf = k0 - b * g.l_tot;
+      const int l2 = lf % g.l[2], l01 = lf / g.l[2], l1 = l01 % g.l[1], l0 = l01 / g.l[1];
+      koff_host[kc] = b < batch ? (int32_t)(1 + (int64_t)b * rank * jjt + ((int64_t)l0 * jj1 + l1) * jj2 + l2) : INT32_MIN;
+    }
+  } else {
+    return NMFMU_ERR_ARG;
+  }
+  return NMFMU_OK;
+}
+
+int nmfmu_slab_sum(float* slabs, int64_t slab_elems, int nslab, void* stream) {
+  if (!slabs || slab_elems <= 0 || slab_elems % 4 || nslab < 1) return NMFMU_ERR_ARG;
+  if (nslab == 1) return NMFMU_OK;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(slab_elems / 4)), dim3(256), 0, S(stream), slabs, slab_elems / 4, nslab);
   return (int)hipGetLastError();
 }
 

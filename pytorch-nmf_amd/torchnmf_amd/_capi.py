@@ -52,12 +52,14 @@ class GemmDesc(C.Structure):
                 ('gp_hi', C.c_void_p), ('gp_lo', C.c_void_p), ('out', C.c_void_p), ('m_valid', C.c_int32),
                 ('n_valid', C.c_int32), ('ops', C.c_int32), ('t_batch', C.c_int32), ('t_rank', C.c_int32),
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
-                ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32)]
+                ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32),
+                ('win_nd', C.c_int32), ('win_lh', C.c_int32 * 3), ('win_taps', C.c_int32 * 3), ('win_channels', C.c_int32),
+                ('win_pitch', C.c_int32), ('t_koff', C.c_void_p)]
 
 
-ABI_VERSION = 6   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 7   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
-OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU = 0, 1, 2, 3
+OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU, OPS_A_WIN = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); every symbol include/nmfmu.h declares
 SIGNATURES = {
@@ -129,6 +131,15 @@ SIGNATURES = {
     'nmfmu_plca_z': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_pack_w_scaled': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_pack_wk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_apply_h_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_convnd_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_convnd_koff': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_slab_sum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'nmfmu_convnd_fold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     'nmfmu_plca3_part_bytes': (C.c_size_t, [C.c_int]),

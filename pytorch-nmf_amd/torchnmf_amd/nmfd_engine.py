@@ -149,9 +149,26 @@ class ConvMU(AsyncLossMixin):
         # Hu [(b,l)][(r,t)] = H[b][r][l-t] and its transpose: never materialised when the taps and the frame count are
         # multiples of 8 -- the GEMMs then fetch those operands chunk-wise from two window tables of H that are 8x H
         # (nmfmu_conv_tables) instead of T x H; otherwise explicit planes rebuilt every iteration (nmfmu_conv_unfold).
-        self.implicit = (nd == 1 and T % 8 == 0 and L % 8 == 0 and
-                         os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1')
-        if self.implicit:
+        # With several shift axes (round 4) the same holds when taps and V extent of the LAST axis are multiples of 8: the tables
+        # are those of every last-axis line of the zero-padded H (nmfmu_convnd_tables) and the k-chunk's share of the chunk
+        # index comes from a small precomputed array (nmfmu_convnd_koff).
+        self.implicit = (T % 8 == 0 and L % 8 == 0 if nd == 1 else
+                         own_loop and self.ts[-1] % 8 == 0 and self.ls[-1] % 8 == 0)
+        self.implicit = self.implicit and os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1'
+        self.koff = {}
+        if self.implicit and nd > 1:
+            nb = self.lib.nmfmu_convnd_table_bytes(B, R, nd, self._lh_arr, self._t_arr)
+            self.implicit = 0 < nb // 16 < 2 ** 31
+        if self.implicit and nd > 1:
+            for ops, kp in ((_capi.OPS_B_HU, rpp), (_capi.OPS_B_HUT, blp)):
+                host = torch.empty(kp // 8 + 8, dtype=torch.int32)
+                _capi.check(self.lib.nmfmu_convnd_koff(ops, B, R, nd, self._lh_arr, self._t_arr, kp, host.data_ptr()),
+                            'nmfmu_convnd_koff')
+                self.koff[ops] = host.to(dev)
+            self.koff[_capi.OPS_A_HU] = self.koff[_capi.OPS_B_HU]
+            self.hu = _Table(blp, rpp, nb, x3, dev)
+            self.hut = _Table(rpp, blp, nb, x3, dev)
+        elif self.implicit:
             nb = self.lib.nmfmu_conv_table_bytes(B, R, Lh, T)
             self.hu = _Table(blp, rpp, nb, x3, dev)     # reversed windows: rows (b,l), k = (r,t)
             self.hut = _Table(rpp, blp, nb, x3, dev)    # forward windows:  rows (r,t), k = (b,l)
@@ -191,9 +208,24 @@ class ConvMU(AsyncLossMixin):
         if self.fold_parts and want != '0':
             slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
             self.h_tail_rows, self.h_tail_split = tail_round_split(rpp // 128, blp // 128, slots, -(-Cc // 64), want)
-        ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
-        self.y = torch.empty(ny, dtype=torch.float32, device=dev)
-        self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)
+        # H numerator without Y at all (NMFMU_OPS_A_WIN): out[(b,j)][r] = sum_{t,c} GnT[(b, j + t)][c] W[c][r][t] -- the rows of the
+        # A operand are shifted rows of the ratio planes the H half-step has just written, so nothing is unfolded or folded
+        # (Y is 4 R T B L bytes: 537 MB for a 256 x 512 frame with 8 x 16 taps).  Any number of shift axes, no alignment
+        # rules.  The fold-parts path above stays where it applies (1-D, >= 128 taps: it multiplies no padding of the rank).
+        self.h_rows = (own_loop and T > 1 and not self.fold_parts and self.precision != _capi.PREC_F16 and
+                       2 * blp * cp < 2 ** 32 and os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
+        self.y = self.y_den = None
+        if self.h_rows:
+            self.wk_rows = 32 if R <= 32 else 64 if R <= 64 else pad(R)
+            self.wk_klen = T * (-(-Cc // 64)) * 64
+            self.wk = _Planes(self.wk_rows, pad(self.wk_klen), x3, dev)         # W as [r][(t, c)]
+            self.hj_pad = pad(B * Lh)
+            self.hnum = torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
+            self.hden = None if self.kl else torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
+        else:
+            ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
+            self.y = torch.empty(ny, dtype=torch.float32, device=dev)
+            self.y_den = None if self.kl else torch.empty(ny, dtype=torch.float32, device=dev)
         self.sum_h = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{b,j} H[b][r][j]
         self.sum_w = torch.zeros(R, dtype=torch.float32, device=dev)   # sum_{c,t} W[c][r][t]
         self.sum_part = torch.empty(R * 128, dtype=torch.float32, device=dev)
@@ -218,9 +250,20 @@ class ConvMU(AsyncLossMixin):
         # configs[3]: one workgroup per CU, the second slot idle): split the contraction in two when that fills the chip
         # better; the apply kernel adds the partials (beta == 1 fused-sums path only)
         tiles = (cp // 128) * (rpp // 128)
-        self.w_ksplit = 2 if (os.environ.get('TORCHNMF_AMD_NMFD_KSPLIT', '1') != '0' and self.fused_sums and
-                              tiles <= 256 and (blp // 64) % 2 == 0 and blp >= 2048) else 1
+        self.w_ksplit = 1
+        if os.environ.get('TORCHNMF_AMD_NMFD_KSPLIT', '1') != '0':
+            if self.fused_sums:
+                self.w_ksplit = 2 if (tiles <= 256 and (blp // 64) % 2 == 0 and blp >= 2048) else 1
+            else:
+                # the general form (round 4): few tiles and a very long contraction (NMF2D: 8 tiles x 2 048 k-tiles) -- as many
+                # parts as fill the workgroup slots, each at least eight k-tiles, dividing the k-tiles evenly
+                slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+                kt = blp // 64
+                want = min(64, slots // tiles, kt // 8)
+                self.w_ksplit = max([s_ for s_ in range(1, max(want, 1) + 1) if kt % s_ == 0])
         self.num_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
+        if self.den_w is not None:
+            self.den_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
         self._loss_main = (self.c_main // 128) * (blp // 128)      # partials of the GEMM part when the channels are ragged
         nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
         self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
@@ -250,10 +293,26 @@ class ConvMU(AsyncLossMixin):
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,
                            _ptr(out), m_valid, n_valid, ops, self.B, self.R, self.T, self.Lh, tile, n_ld, k_len, k_split,
                            tail_rows, self.c_main if ragged else 0, self.C if ragged else 0)
+        if ops != _capi.OPS_PLANES and self.nd > 1:
+            d.win_nd, d.win_lh, d.win_taps = self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts)
+            d.t_koff = self.koff[ops].data_ptr()
         timer = getattr(self, 'timer', None) if tag else None
         if timer is not None:
             timer.mark(tag + '<')
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
+        if timer is not None:
+            timer.mark(tag + '>')
+
+    def _gemm_win(self, planes: _Planes, out, tag=None):
+        """H numerator (or denominator) as the window-operand GEMM: out[(b,j)][r] from the ratio planes [(b,l)][c]."""
+        d = _capi.GemmDesc(_ptr(planes.hi), _ptr(planes.lo), _ptr(self.wk.hi), _ptr(self.wk.lo), self.hj_pad, self.wk_rows,
+                           self.wk.cols_pad, self.precision, self.beta, None, None, None, None, None, _ptr(out), 0, 0,
+                           _capi.OPS_A_WIN, self.B, self.R, self.T, self.Lh, 128, 0, self.wk_klen, 0, 0, 0, 0,
+                           self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts), self.C, planes.cols_pad)
+        timer = getattr(self, 'timer', None) if tag else None
+        if timer is not None:
+            timer.mark(tag + '<')
+        _capi.check(self.lib.nmfmu_gemm(C.byref(d), _capi.EPI_F32, _stream()), 'nmfmu_gemm')
         if timer is not None:
             timer.mark(tag + '>')
 
@@ -288,15 +347,35 @@ class ConvMU(AsyncLossMixin):
                 _ptr(self.wm.lo),
                 _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w_sums')
             return
-        _capi.check(self.lib.nmfmu_conv_apply_pack_w(
+        self._pack_w_planes(update)
+        if self.h_rows:
+            _capi.check(self.lib.nmfmu_conv_pack_wk(self.W.data_ptr(), self.C, self.R, self.T, self.wk.rows_pad,
+                                                    self.wk.cols_pad, self.precision, _ptr(self.wk.hi), _ptr(self.wk.lo),
+                                                    _stream()), 'nmfmu_conv_pack_wk')
+
+    def _pack_w_planes(self, update: bool):
+        slabs = self.w_ksplit
+        if update and slabs > 2:      # many split-K partials: a wide reduction first (the apply kernel has few blocks)
+            for buf in (self.num_w, self.den_w):
+                if buf is not None:
+                    _capi.check(self.lib.nmfmu_slab_sum(buf.data_ptr(), self.c_pad * self.rp_pad, slabs, _stream()),
+                                'nmfmu_slab_sum')
+            slabs = 1
+        # (the _sums entry without its partial-sum operands: the one that adds the split-K slabs of num / den)
+        _capi.check(self.lib.nmfmu_conv_apply_pack_w_sums(
             self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None,
-            _ptr(self.den_w) if update else None, self.sum_h.data_ptr() if (update and self.kl) else None, self.c_pad,
-            self.rp_pad, self.l1, self.l2, self.gamma, int(update), _ptr(self.wm.hi), _ptr(self.wm.lo),
-            _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w')
+            _ptr(self.den_w) if update else None, self.sum_h.data_ptr() if (update and self.kl) else None, None, 0, None,
+            slabs, self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update), self.precision,
+            _ptr(self.wm.hi), _ptr(self.wm.lo), _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()),
+            'nmfmu_conv_apply_pack_w_sums')
         self._rank_sums(self.W, self.C, self.T, self.sum_w)
 
     def _pack_h(self, sums: bool = True):
-        if self.implicit:
+        if self.implicit and self.nd > 1:
+            _capi.check(self.lib.nmfmu_convnd_tables(self.H.data_ptr(), self.B, self.R, self.nd, self._lh_arr, self._t_arr,
+                                                     _ptr(self.hu.hi), _ptr(self.hu.lo), _ptr(self.hut.hi),
+                                                     _ptr(self.hut.lo), _stream()), 'nmfmu_convnd_tables')
+        elif self.implicit:
             if self.precision == _capi.PREC_F16:
                 _capi.check(self.lib.nmfmu_conv_tables_f16(self.H.data_ptr(), self.B, self.R, self.Lh, self.T,
                                                            _ptr(self.hu.hi), _ptr(self.hut.hi), _stream()),
@@ -350,7 +429,7 @@ class ConvMU(AsyncLossMixin):
         self.recon_ratio_w()
         self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit, tag='num_w')
         if not self.kl:
-            self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w)
+            self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w, k_split=self.w_ksplit)
         self._pack_w(update=True)
 
     def h_step(self):
@@ -362,6 +441,16 @@ class ConvMU(AsyncLossMixin):
                 self._ragged(1, self.x_h, self.gnt, self.gpt)
         else:
             self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, tag='recon_h')
+        if self.h_rows:
+            self._gemm_win(self.gnt, self.hnum, tag='num_h')
+            if not self.kl:
+                self._gemm_win(self.gpt, self.hden)
+            _capi.check(self.lib.nmfmu_conv_apply_h_rows(
+                self.H.data_ptr(), self.B, self.R, self.Lh, self.hnum.data_ptr(), _ptr(self.hden),
+                self.sum_w.data_ptr() if self.kl else None, self.wk_rows, self.l1, self.l2, self.gamma, _stream()),
+                'nmfmu_conv_apply_h_rows')
+            self._pack_h()
+            return
         epi = _capi.EPI_FOLD if self.fold_parts else _capi.EPI_F32
         kc = -(-self.C // 64) * 64             # the contraction runs over the channels: skip the zero tail of the padding
         tail = dict(k_split=self.h_tail_split, tail_rows=self.h_tail_rows) if self.h_tail_rows else {}

@@ -852,6 +852,7 @@ def test_nmfd_fold_from_tile_diagonal_sums(dev, shape, beta, prec, monkeypatch):
     W0 = torch.randn(Cc, R, T, generator=g).abs()
     H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
     res = {}
+    monkeypatch.setenv('TORCHNMF_AMD_NMFD_H_ROWS', '0')      # the store-then-fold path is the comparison here
     for mode in ('0', '1'):
         monkeypatch.setenv('TORCHNMF_AMD_NMFD_FOLD_PARTS', mode)
         W, H = W0.clone().to(dev), H0.clone().to(dev)
@@ -1127,6 +1128,82 @@ def test_nmfd_f16_mode(dev, shape):
         ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 2, precision='f16')
     small = ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 1, precision='auto')
     assert small.precision_name == ('f16' if min(Cc, B * L, R * T) >= 1024 else 'bf16x3')
+
+
+@pytest.mark.parametrize('shape', [
+    # (B, C, ls, R, ks)
+    (2, 70, (24, 40), 5, (3, 8)),        # two batches, 70 channels = two 64-channel k-tiles per tap, rank -> 32-wide tile
+    (1, 64, (40, 33), 40, (4, 5)),       # rank 40 -> 64-wide tile, odd extents (no alignment rule on this path)
+    (1, 130, (10, 12, 14), 100, (2, 3, 2)),   # three shift axes, rank 100 -> 128-wide tile, three k-tiles per tap
+    (3, 20, (150,), 7, (30,)),           # one axis (NMFD below the fold-parts path's 128 taps)
+])
+@pytest.mark.parametrize('beta', [1, 0.5])
+def test_h_numerator_from_shifted_ratio_rows(dev, shape, beta, monkeypatch):
+    """H half-step with the numerator as the window-operand GEMM (NMFMU_OPS_A_WIN: no Y matrix, no fold) against the
+    oracle's conv backward pass (nmf.py:380-391 on the convolutive models) and against the engine's own Y + fold path."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, ls, R, ks = shape
+    g = torch.Generator().manual_seed(sum(ls) + R)
+    V = torch.rand(B, Cc, *ls, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, *ks, generator=g).abs()
+    H0 = torch.randn(B, R, *[l - k + 1 for l, k in zip(ls, ks)], generator=g).abs()
+    kind = {1: 'nmfd', 2: 'convnd', 3: 'convnd'}[len(ls)]
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, kind=kind)
+    res = {}
+    for rows in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_H_ROWS', rows)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, precision='bf16x3')
+        assert eng.h_rows == (rows == '1') and (eng.y is None) == (rows == '1')
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[rows] = (W.cpu(), H.cpu())
+        assert rel_err(res[rows][0], Wr) < TOL and rel_err(res[rows][1], Hr) < TOL
+    assert rel_err(res['1'][1], res['0'][1]) < 2e-5
+    monkeypatch.setenv('TORCHNMF_AMD_NMFD_H_ROWS', '1')
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = ConvMU(V.to(dev), W, H, beta, precision='bf16')
+    for _ in range(2):
+        eng.w_step()
+        eng.h_step()
+    assert rel_err(H.cpu(), Hr) < 2e-2 and bool(torch.isfinite(H).all())
+
+
+@pytest.mark.parametrize('shape', [
+    (2, 70, (24, 40), 5, (3, 8)),            # B, C, ls, R, ks: last axis 40 frames / 8 taps
+    (1, 130, (9, 32), 3, (4, 16)),           # R * T = 192: k padding inside the last k-tile pair
+    (2, 9, (6, 7, 16), 4, (2, 3, 8)),        # three shift axes
+])
+@pytest.mark.parametrize('beta', [1, 0.5])
+def test_implicit_operands_with_several_shift_axes(dev, shape, beta, monkeypatch):
+    """NMF2D / NMF3D with taps and frames of the last axis multiples of 8: the GEMMs fetch Hu / HuT from the window
+    tables of nmfmu_convnd_tables (no unfold kernel, no T-times-H planes).  Same products as the explicit operands:
+    must agree with them to fp32 rounding, and with the oracle (nmf.py:857-865, 937-942)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, ls, R, ks = shape
+    g = torch.Generator().manual_seed(sum(ls) + R)
+    V = torch.rand(B, Cc, *ls, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, *ks, generator=g).abs()
+    H0 = torch.randn(B, R, *[l - k + 1 for l, k in zip(ls, ks)], generator=g).abs()
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, beta, NO_STOP, 2, kind='convnd')
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_EXPLICIT', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, beta, precision='bf16x3')
+        assert eng.implicit == (mode == '0')
+        l0 = eng.divergence()
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        res[mode] = (W.cpu(), H.cpu(), l0, eng.divergence())
+    assert rel_err(res['0'][0], res['1'][0]) < 2e-6 and rel_err(res['0'][1], res['1'][1]) < 2e-6
+    assert res['0'][2] == pytest.approx(res['1'][2], rel=1e-6) and res['0'][3] == pytest.approx(res['1'][3], rel=1e-6)
+    assert rel_err(res['0'][0], Wr) < TOL and rel_err(res['0'][1], Hr) < TOL
+    assert res['0'][2] == pytest.approx(float(O.beta_div(O.convnd_reconstruct(H0, W0), V, beta)), rel=1e-4)
 
 
 @pytest.mark.parametrize('name,cls', [('2d_a', 'NMF2D'), ('2d_b', 'NMF2D'), ('3d_a', 'NMF3D')])

@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_static_queries():
     lib = _capi.load()
-    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 6
+    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 7
     assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
     assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
     assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED
@@ -169,7 +169,8 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
-    assert [f[0] for f in d._fields_][-7:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels']
+    assert [f[0] for f in d._fields_][-13:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels',
+                                                'win_nd', 'win_lh', 'win_taps', 'win_channels', 'win_pitch', 't_koff']
     # ragged channels inside the GEMM grid: eight workgroups share out a tile's frames -> >= 8 tiles of the explicit operand
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 1) == 1           # configs[3], W half-step
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_A_HU, 8192, 1024, 1) == 1           # ... H half-step
@@ -504,3 +505,73 @@ def test_tail_round_split_selection():
             rows, split = tail_round_split(30, 10, 512, kt, f'3,{want_split}')
             per = -(-kt // split)
             assert rows == 3 and 2 <= split <= want_split and (split - 1) * per < kt <= split * per
+
+
+@pytest.mark.parametrize('B,R,lhs,ts', [(2, 3, (5, 9), (3, 8)), (1, 2, (3, 4, 17), (2, 2, 8)), (2, 2, (17,), (8,)),
+                                         (1, 2, (6, 25), (4, 16))])
+def test_window_tables_with_several_shift_axes(B, R, lhs, ts):
+    """nmfmu_convnd_koff (host code) + the chunk-index rule of include/nmfmu.h (nmfmu_convnd_tables): a numpy model of the
+    tables, gathered as the GEMM lanes gather them, must reproduce the unfolded operands Hu[(b,l)][(r,t)] = H[b][r][l - t]
+    and its transpose (nmf.py:857-860 / 937-940: conv2d / conv3d with the flipped kernel)."""
+    import ctypes as C
+    import itertools
+    lib = _capi.load()
+    nd = len(lhs)
+    ls = tuple(lh + t - 1 for lh, t in zip(lhs, ts))
+    jj = tuple(lh + 2 * t - 2 for lh, t in zip(lhs, ts))
+    JJ = int(np.prod(jj))
+    S = [int(np.prod(jj[d + 1:])) for d in range(nd)]
+    rng = np.random.default_rng(5)
+    H = rng.random((B, R) + lhs).astype(np.float32)
+    arr = (C.c_int32 * nd)
+    nb = lib.nmfmu_convnd_table_bytes(B, R, nd, arr(*lhs), arr(*ts))
+    assert nb == 16 * (1 + B * R * JJ)
+    # numpy model of the two tables (8 values per chunk)
+    rev, fwd = np.zeros((nb // 16, 8), np.float32), np.zeros((nb // 16, 8), np.float32)
+    for b, r in itertools.product(range(B), range(R)):
+        for p in itertools.product(*[range(x) for x in jj]):
+            j = [pd - (t - 1) for pd, t in zip(p, ts)]
+            if any(not 0 <= jd < lh for jd, lh in zip(j[:-1], lhs[:-1])):
+                continue
+            line = H[(b, r) + tuple(j[:-1])]
+            i = 1 + (b * R + r) * JJ + sum(pd * sd for pd, sd in zip(p, S))
+            for e in range(8):
+                if 0 <= j[-1] - e < lhs[-1]:
+                    rev[i, e] = line[j[-1] - e]
+                if 0 <= j[-1] + e < lhs[-1]:
+                    fwd[i, e] = line[j[-1] + e]
+    L, T = int(np.prod(ls)), int(np.prod(ts))
+    rp_pad, bl_pad = -(-R * T // 128) * 128, -(-B * L // 128) * 128
+
+    def h_at(b, r, l, t):
+        j = tuple(ld - td for ld, td in zip(l, t))
+        return H[(b, r) + j] if all(0 <= jd < lh for jd, lh in zip(j, lhs)) else 0.0
+
+    # rows (b, l), k = (r, t)
+    koff = np.zeros(rp_pad // 8 + 8, np.int32)
+    assert lib.nmfmu_convnd_koff(_capi.OPS_B_HU, B, R, nd, arr(*lhs), arr(*ts), rp_pad, koff.ctypes.data) == 0
+    assert all(koff[R * T // 8:] == np.iinfo(np.int32).min)
+    for b in range(B):
+        for l in itertools.product(*[range(x) for x in ls]):
+            row_term = b * R * JJ + sum((ld + t - 1) * sd for ld, t, sd in zip(l, ts, S))
+            for kc in range(R * T // 8):
+                r, tf = divmod(8 * kc, T)
+                t = np.unravel_index(tf, ts)
+                want = [h_at(b, r, l, tuple(t[:-1]) + (t[-1] + e,)) for e in range(8)]
+                assert np.array_equal(rev[row_term + koff[kc]], np.array(want, np.float32))
+    # rows (r, t), k = (b, l)
+    koff = np.zeros(bl_pad // 8 + 8, np.int32)
+    assert lib.nmfmu_convnd_koff(_capi.OPS_B_HUT, B, R, nd, arr(*lhs), arr(*ts), bl_pad, koff.ctypes.data) == 0
+    assert all(koff[B * L // 8:] == np.iinfo(np.int32).min)
+    for r in range(R):
+        for t in itertools.product(*[range(x) for x in ts]):
+            row_term = r * JJ + sum((td_max - 1 - td) * sd for td_max, td, sd in zip(ts, t, S))
+            for kc in range(B * L // 8):
+                b, lf = divmod(8 * kc, L)
+                l = np.unravel_index(lf, ls)
+                want = [h_at(b, r, tuple(l[:-1]) + (l[-1] + e,), t) for e in range(8)]
+                assert np.array_equal(fwd[row_term + koff[kc]], np.array(want, np.float32))
+    # argument checks: last-axis alignment
+    bad = np.zeros(32, np.int32)
+    assert lib.nmfmu_convnd_koff(_capi.OPS_B_HU, 1, 1, 2, (C.c_int32 * 2)(4, 5), (C.c_int32 * 2)(2, 4), 128, bad.ctypes.data) == _capi.ERR_ARG
+    assert lib.nmfmu_convnd_koff(_capi.OPS_PLANES, 1, 1, 1, (C.c_int32 * 1)(9), (C.c_int32 * 1)(8), 128, bad.ctypes.data) == _capi.ERR_ARG
