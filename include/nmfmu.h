@@ -319,6 +319,13 @@ typedef struct nmfmu_gemm_desc {
   int32_t win_taps[3];     /* taps per axis */
   int32_t win_channels;    /* C */
   int32_t win_pitch;       /* elements per row of P (multiple of 64, >= ceil(C / 64) * 64) */
+  /* Fold F (0 / 1: none): with a rank of at most 32 / F the 32-wide N tile would multiply mostly padding; instead F
+   * consecutive taps of the LAST axis, t = F q + d, share one k position and go to F columns:
+   *   out[(b, jo, j')][r F + d] = sum_{c, to, q} P[(b, jo + to, j' + F q)][c] W[c][r][to][F q + d],   j' in [0, lh_last + F - 1)
+   * (1 / F of the MFMA work and operand traffic); the consumer adds num[..][j] = sum_d out[(.., j + d)][r F + d]
+   * (nmfmu_conv_apply_h_rows).  taps_last % F == 0, rank * F <= n_pad, m_pad >= batch * prod(lh_outer) * (lh_last + F - 1),
+   * k_len = prod(taps) / F * ceil(C / 64) * 64, B from nmfmu_conv_pack_wk with the same F. */
+  int32_t win_fold;
   /* (ABI 7) Implicit operands (ops B_HU / B_HUT / A_HU) of an H with SEVERAL shift axes (NMF2D / NMF3D): win_nd > 1,
    * win_lh / win_taps as above, the operand's hi / lo = the tables of nmfmu_convnd_tables, and t_koff = DEVICE copy of
    * nmfmu_convnd_koff(ops, ..., k_pad) -- one int per 8-wide k-chunk.  Needs taps and V extent of the LAST axis to be
@@ -517,15 +524,16 @@ int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const f
                              void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, void* stream);
 int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, const float* y,
                       int bl_pad, void* stream);
-/* The two small kernels around the window-operand GEMM (NMFMU_OPS_A_WIN):
- *   nmfmu_conv_pack_wk:      Wk[r][(t * CK + ck) * 64 + c'] = w[c = 64 ck + c'][r][t] (CK = ceil(channels / 64); taps =
- *                            the product over the shift axes, innermost last), planes [rows_pad][k_pad] zero padded
- *   nmfmu_conv_apply_h_rows: h (batch, rank, lh_total) in place by nmf.py:78-92 from num / den [(b,j)][ld] (den NULL:
- *                            beta == 1, kl_den[r] = sum_{c,t} W[c][r][t]) */
-int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int rows_pad, int k_pad, int precision,
-                       void* wk_hi, void* wk_lo, void* stream);
-int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_total, const float* num, const float* den,
-                            const float* kl_den, int ld, float l1, float l2, float gamma, void* stream);
+/* The two small kernels around the window-operand GEMM (NMFMU_OPS_A_WIN), F = nmfmu_gemm_desc.win_fold (>= 1):
+ *   nmfmu_conv_pack_wk:      Wk[r F + d][((to TQ + q) CK + ck) 64 + c'] = w[c = 64 ck + c'][r][to taps_last + F q + d]
+ *                            (CK = ceil(channels / 64), TQ = taps_last / F; taps = the product over the shift axes, innermost
+ *                            last), planes [rows_pad][k_pad] zero padded
+ *   nmfmu_conv_apply_h_rows: h (batch, rank, lh_outer, lh_last) in place by nmf.py:78-92 from num / den
+ *                            [(b, jo, j')][ld], j' < lh_last + F - 1 (den NULL: beta == 1, kl_den[r] = sum_{c,t} W[c][r][t]) */
+int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int taps_last, int fold, int rows_pad, int k_pad,
+                       int precision, void* wk_hi, void* wk_lo, void* stream);
+int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
+                            const float* den, const float* kl_den, int ld, float l1, float l2, float gamma, void* stream);
 /* slabs[0][i] += slabs[1][i] + .. + slabs[nslab-1][i], fixed order: the partials of a split-K NMFMU_EPI_F32 launch
  * (k_split slabs of m_pad * n_ld floats) for a consumer that takes one slab.  slab_elems a multiple of 4. */
 int nmfmu_slab_sum(float* slabs, int64_t slab_elems, int nslab, void* stream);

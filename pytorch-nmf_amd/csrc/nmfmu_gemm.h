@@ -69,6 +69,7 @@ struct GemmArgs {
   int win_lh[3], win_t[3], win_l[3];   // H extent, taps, V extent (= lh + t - 1) per shift axis
   int win_rows;                        // B * prod(lh): rows of A that exist
   int win_ck;                          // 64-channel k-tiles per tap (k = (t * win_ck + ck) * 64 + c')
+  int win_tstep;                       // rows of P per last-axis tap step (1; F when F taps are folded into N, see nmfmu.h)
   unsigned win_pitch;                  // bytes per row of P
 };
 
@@ -280,13 +281,13 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     wk_t2 = tf % a.win_t[2];
     const int t01 = tf / a.win_t[2];
     wk_t1 = t01 % a.win_t[1];
-    wk_off = ((t01 / a.win_t[1]) * a.win_l[1] + wk_t1) * a.win_l[2] + wk_t2;
+    wk_off = ((t01 / a.win_t[1]) * a.win_l[1] + wk_t1) * a.win_l[2] + wk_t2 * a.win_tstep;
   }
   auto win_advance = [&]() {
     if (++wk_ck == a.win_ck) {
-      wk_ck = 0, ++wk_off;
+      wk_ck = 0, wk_off += a.win_tstep;
       if (++wk_t2 == a.win_t[2]) {
-        wk_t2 = 0, wk_off += a.win_l[2] - a.win_t[2];
+        wk_t2 = 0, wk_off += a.win_l[2] - a.win_t[2] * a.win_tstep;
         if (++wk_t1 == a.win_t[1]) wk_t1 = 0, wk_off += (a.win_l[1] - a.win_t[1]) * a.win_l[2];
       }
     }

@@ -846,14 +846,18 @@ __global__ void __launch_bounds__(256) convnd_fold_apply_h_kernel(float* __restr
 // ------------------------------------------------------------------------------------------------------------
 // H numerator as a window-operand GEMM (NMFMU_OPS_A_WIN): the two small kernels around it.
 // ------------------------------------------------------------------------------------------------------------
-// Wk[r][(t * CK + ck) * 64 + c'] = W[c = ck * 64 + c'][r][t], zero padded: the B operand.  One thread per 16-byte chunk.
-__global__ void __launch_bounds__(256) conv_pack_wk_kernel(const float* __restrict__ W, int C, int R, int T, int CK,
-                                                           int rows_pad, int k_pad, uint16_t* hi, uint16_t* lo, int f16) {
+// Wk[r * F + d][((to * TQ + q) * CK + ck) * 64 + c'] = W[c = ck * 64 + c'][r][to * T_last + F q + d]  (TQ = T_last / F; F = 1:
+// Wk[r][(t * CK + ck) * 64 + c']), zero padded: the B operand.  One thread per 16-byte chunk.
+__global__ void __launch_bounds__(256) conv_pack_wk_kernel(const float* __restrict__ W, int C, int R, int T, int T_last, int F,
+                                                           int CK, int rows_pad, int k_pad, uint16_t* hi, uint16_t* lo, int f16) {
   const int64_t n8 = (int64_t)rows_pad * (k_pad / 8);
-  const int ct = CK * 64;
+  const int ct = CK * 64, TQ = T_last / F;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-    const int r = (int)(i / (k_pad / 8)), k0 = (int)(i % (k_pad / 8)) * 8;
-    const int t = k0 / ct, c0 = k0 - t * ct;
+    const int n = (int)(i / (k_pad / 8)), k0 = (int)(i % (k_pad / 8)) * 8;
+    const int r = n / F, dlt = n - r * F;
+    const int tq = k0 / ct, c0 = k0 - tq * ct;            // tq = to * TQ + q
+    const int to = tq / TQ, q = tq - to * TQ;
+    const int t = to * T_last + F * q + dlt;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (r < R && t < T && c0 + e < C) ? W[((size_t)(c0 + e) * R + r) * T + t] : 0.f;
@@ -864,28 +868,62 @@ __global__ void __launch_bounds__(256) conv_pack_wk_kernel(const float* __restri
       h4[e] = h;
       l4[e] = pack_bf16(v[2 * e] - bf16_lo(h), v[2 * e + 1] - bf16_hi(h));
     }
-    const size_t o = (size_t)r * k_pad + k0;
+    const size_t o = (size_t)n * k_pad + k0;
     *reinterpret_cast<u32x4*>(hi + o) = h4;
     if (lo) *reinterpret_cast<u32x4*>(lo + o) = l4;
   }
 }
 
-// H (B, R, lh_tot) in place from num / den [(b,j)][ld] (rows = positions, columns = rank).  One thread per position.
-__global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restrict__ H, int B, int R, int lh_tot,
-                                                                const float* __restrict__ num,
+// H (B, R, lh_outer, lh_last) in place from num / den [(b, jo, j')][ld], j' in [0, lh_last + F - 1): with F taps folded
+// into the columns, num[b][r][jo][j] = sum_d out[(b, jo, j + d)][r F + d] (fixed order).  One thread per (position, rank),
+// rank fastest: the lanes of a position read neighbouring columns of the same F rows.  (A block-per-line version that
+// staged the rows in LDS and one thread per position were both measured at 20-30 us for 124 k positions -- too few,
+// too serial blocks; this form is bandwidth-shaped.)
+__global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restrict__ H, int B, int R, int lh_outer, int lh_last,
+                                                                int F, const float* __restrict__ num,
                                                                 const float* __restrict__ den,
                                                                 const float* __restrict__ kl_den, int ld, float l1,
                                                                 float l2, float gamma) {
-  const int64_t n = (int64_t)B * lh_tot;
+  const int64_t n = (int64_t)B * lh_outer * lh_last * R;
+  const int lw = lh_last + F - 1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int b = (int)(i / lh_tot), jf = (int)(i - (int64_t)b * lh_tot);
-    const float* nrow = num + (size_t)i * ld;
-    const float* drow = den ? den + (size_t)i * ld : nullptr;
-    for (int r = 0; r < R; ++r) {
-      const size_t o = ((size_t)b * R + r) * lh_tot + jf;
-      H[o] = mu_update(H[o], nrow[r], kl_den ? kl_den[r] : drow[r], kl_den != nullptr, l1, l2, gamma);
+    const int r = (int)(i % R);
+    const int64_t pos = i / R;
+    const int j = (int)(pos % lh_last);
+    const int64_t bo = pos / lh_last;                        // (b, jo)
+    const int b = (int)(bo / lh_outer), jo = (int)(bo - (int64_t)b * lh_outer);
+    const size_t row0 = ((size_t)bo * lw + j) * ld + (size_t)r * F;
+    float neg = 0.f, pos_ = 0.f;
+    for (int d = 0; d < F; ++d) {
+      neg += num[row0 + (size_t)d * (ld + 1)];
+      if (den) pos_ += den[row0 + (size_t)d * (ld + 1)];
     }
+    const size_t o = (((size_t)b * R + r) * lh_outer + jo) * lh_last + j;
+    H[o] = mu_update(H[o], neg, kl_den ? kl_den[r] : pos_, kl_den != nullptr, l1, l2, gamma);
   }
+}
+
+// the two rank-sum stages in one launch for small inputs: one block per rank, fixed order
+__global__ void __launch_bounds__(1024) rank_sums_one_kernel(const float* __restrict__ src, int outer, int R, int inner,
+                                                             float* __restrict__ out) {
+  __shared__ float red[1024];
+  const int r = blockIdx.x;
+  const int64_t total = (int64_t)outer * inner;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  auto at = [&](int64_t e) {
+    const int o = (int)(e / inner), i = (int)(e - (int64_t)o * inner);
+    return src[((size_t)o * R + r) * inner + i];
+  };
+  int64_t e = threadIdx.x;
+  for (; e + 3072 < total; e += 4096) s0 += at(e), s1 += at(e + 1024), s2 += at(e + 2048), s3 += at(e + 3072);
+  for (; e < total; e += 1024) s0 += at(e);
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] = red[0];
 }
 
 }  // namespace nmfmu
@@ -969,9 +1007,15 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     a.win_ck = (d->win_channels + 63) / 64;
     if (a.win_ck * 64 > d->win_pitch) return NMFMU_ERR_ARG;
     a.win_pitch = (unsigned)d->win_pitch * 2u;
-    if ((int64_t)d->t_batch * geom.lh_tot > d->m_pad || (int64_t)d->t_batch * geom.l_tot * a.win_pitch >= ((int64_t)1 << 32)) return NMFMU_ERR_ARG;
-    a.win_rows = d->t_batch * geom.lh_tot;
-    if ((int64_t)a.k_len != (int64_t)geom.t_tot * a.win_ck * 64) return NMFMU_ERR_ARG;   // k = (t, ck, c')
+    // fold F: F consecutive last-axis taps share a k position and go to F columns of N; rows run over lh_last + F - 1
+    const int fold = d->win_fold > 1 ? d->win_fold : 1;
+    if (geom.t[2] % fold || (int64_t)d->t_rank * fold > d->n_pad) return NMFMU_ERR_ARG;
+    a.win_tstep = fold;
+    a.win_lh[2] = geom.lh[2] + fold - 1, a.win_t[2] = geom.t[2] / fold;
+    const int64_t rows = (int64_t)d->t_batch * geom.lh[0] * geom.lh[1] * a.win_lh[2];
+    if (rows > d->m_pad || (int64_t)d->t_batch * geom.l_tot * a.win_pitch >= ((int64_t)1 << 32)) return NMFMU_ERR_ARG;
+    a.win_rows = (int)rows;
+    if ((int64_t)a.k_len != (int64_t)(geom.t_tot / fold) * a.win_ck * 64) return NMFMU_ERR_ARG;   // k = (t_outer, q, ck, c')
   } else if (nd_geom) {
     // window tables of an H with several shift axes (nmfmu_convnd_tables); t_koff from nmfmu_convnd_koff, on the device
     if (!d->t_koff || f16 || epilogue == NMFMU_EPI_FOLD || d->rag_channels > 0) return NMFMU_ERR_ARG;
@@ -1074,6 +1118,10 @@ int nmfmu_conv_tables_f16(const float* h, int batch, int rank, int lh, int taps,
 
 int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* part, float* out, void* stream) {
   if (!src || !out || !part || outer <= 0 || rank <= 0 || inner <= 0) return NMFMU_ERR_ARG;
+  if ((int64_t)outer * inner <= (1 << 14)) {     // small (W of a short-kernel model): both stages in one launch
+    hipLaunchKernelGGL(rank_sums_one_kernel, dim3(rank), dim3(1024), 0, S(stream), src, outer, rank, inner, out);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(rank_sums_partial_kernel, dim3(rank, kRankChunks), dim3(256), 0, S(stream), src, outer, rank, inner,
                      part);
   hipLaunchKernelGGL(rank_sums_final_kernel, dim3(rank), dim3(kRankChunks), 0, S(stream), part, out);
@@ -1298,25 +1346,29 @@ int nmfmu_convnd_fold(float* out, int batch, int rank, int ndim, const int32_t* 
   return (int)hipGetLastError();
 }
 
-int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int rows_pad, int k_pad, int precision,
-                       void* wk_hi, void* wk_lo, void* stream) {
-  if (!w || !wk_hi || channels <= 0 || rank <= 0 || taps <= 0 || rows_pad < rank || k_pad % 8) return NMFMU_ERR_ARG;
+int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int taps_last, int fold, int rows_pad, int k_pad,
+                       int precision, void* wk_hi, void* wk_lo, void* stream) {
+  if (!w || !wk_hi || channels <= 0 || rank <= 0 || taps <= 0 || taps_last <= 0 || taps % taps_last || fold < 1 ||
+      taps_last % fold || rows_pad < rank * fold || k_pad % 8)
+    return NMFMU_ERR_ARG;
   const int ck = (channels + 63) / 64;
-  if ((int64_t)k_pad < (int64_t)taps * ck * 64) return NMFMU_ERR_ARG;
+  if ((int64_t)k_pad < (int64_t)(taps / fold) * ck * 64) return NMFMU_ERR_ARG;
   if (precision == NMFMU_PREC_BF16X3 && !wk_lo) return NMFMU_ERR_ARG;
   const int64_t n = (int64_t)rows_pad * (k_pad / 8);
-  hipLaunchKernelGGL(conv_pack_wk_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, channels, rank, taps, ck, rows_pad,
-                     k_pad, (uint16_t*)wk_hi, (uint16_t*)(precision == NMFMU_PREC_BF16X3 ? wk_lo : nullptr),
+  hipLaunchKernelGGL(conv_pack_wk_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, channels, rank, taps, taps_last, fold,
+                     ck, rows_pad, k_pad, (uint16_t*)wk_hi, (uint16_t*)(precision == NMFMU_PREC_BF16X3 ? wk_lo : nullptr),
                      (int)(precision == NMFMU_PREC_F16));
   return (int)hipGetLastError();
 }
 
-int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_total, const float* num, const float* den,
-                            const float* kl_den, int ld, float l1, float l2, float gamma, void* stream) {
-  if (!h || !num || (!den && !kl_den) || batch <= 0 || rank <= 0 || lh_total <= 0 || ld < rank) return NMFMU_ERR_ARG;
-  const int64_t n = (int64_t)batch * lh_total;
-  hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh_total, num,
-                     den, kl_den, ld, l1, l2, gamma);
+int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
+                            const float* den, const float* kl_den, int ld, float l1, float l2, float gamma, void* stream) {
+  if (!h || !num || (!den && !kl_den) || batch <= 0 || rank <= 0 || lh_outer <= 0 || lh_last <= 0 || fold < 1 ||
+      ld < rank * fold)
+    return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * lh_outer * lh_last * rank;
+  hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh_outer, lh_last,
+                     fold, num, den, kl_den, ld, l1, l2, gamma);
   return (int)hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
                 ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32),
                 ('win_nd', C.c_int32), ('win_lh', C.c_int32 * 3), ('win_taps', C.c_int32 * 3), ('win_channels', C.c_int32),
-                ('win_pitch', C.c_int32), ('t_koff', C.c_void_p)]
+                ('win_pitch', C.c_int32), ('win_fold', C.c_int32), ('t_koff', C.c_void_p)]
 
 
 ABI_VERSION = 7   # include/nmfmu.h: NMFMU_ABI_VERSION
@@ -131,10 +131,10 @@ SIGNATURES = {
     'nmfmu_plca_z': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_pack_w_scaled': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'nmfmu_conv_pack_wk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]),
-    'nmfmu_conv_apply_h_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_conv_pack_wk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_apply_h_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_convnd_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -217,9 +217,14 @@ class ConvMU(AsyncLossMixin):
         self.y = self.y_den = None
         if self.h_rows:
             self.wk_rows = 32 if R <= 32 else 64 if R <= 64 else pad(R)
-            self.wk_klen = T * (-(-Cc // 64)) * 64
-            self.wk = _Planes(self.wk_rows, pad(self.wk_klen), x3, dev)         # W as [r][(t, c)]
-            self.hj_pad = pad(B * Lh)
+            # a small rank would leave most of the 32-wide N tile as padding: F consecutive last-axis taps share a k position
+            # and take F columns each (nmfmu_gemm_desc.win_fold) -- 1 / F of the MFMA work and of the operand traffic
+            self.wk_fold = max([f for f in (4, 2) if R * f <= 32 and self.ts[-1] % f == 0] + [1])
+            if os.environ.get('TORCHNMF_AMD_NMFD_H_FOLD', '1') == '0':
+                self.wk_fold = 1
+            self.wk_klen = (T // self.wk_fold) * (-(-Cc // 64)) * 64
+            self.wk = _Planes(self.wk_rows, pad(self.wk_klen), x3, dev)         # W as [(r, d)][(to, q, c)]
+            self.hj_pad = pad(B * (Lh // self.lhs[-1]) * (self.lhs[-1] + self.wk_fold - 1))
             self.hnum = torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
             self.hden = None if self.kl else torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
         else:
@@ -308,7 +313,8 @@ class ConvMU(AsyncLossMixin):
         d = _capi.GemmDesc(_ptr(planes.hi), _ptr(planes.lo), _ptr(self.wk.hi), _ptr(self.wk.lo), self.hj_pad, self.wk_rows,
                            self.wk.cols_pad, self.precision, self.beta, None, None, None, None, None, _ptr(out), 0, 0,
                            _capi.OPS_A_WIN, self.B, self.R, self.T, self.Lh, 128, 0, self.wk_klen, 0, 0, 0, 0,
-                           self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts), self.C, planes.cols_pad)
+                           self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts), self.C, planes.cols_pad,
+                           self.wk_fold)
         timer = getattr(self, 'timer', None) if tag else None
         if timer is not None:
             timer.mark(tag + '<')
@@ -349,9 +355,9 @@ class ConvMU(AsyncLossMixin):
             return
         self._pack_w_planes(update)
         if self.h_rows:
-            _capi.check(self.lib.nmfmu_conv_pack_wk(self.W.data_ptr(), self.C, self.R, self.T, self.wk.rows_pad,
-                                                    self.wk.cols_pad, self.precision, _ptr(self.wk.hi), _ptr(self.wk.lo),
-                                                    _stream()), 'nmfmu_conv_pack_wk')
+            _capi.check(self.lib.nmfmu_conv_pack_wk(self.W.data_ptr(), self.C, self.R, self.T, self.ts[-1], self.wk_fold,
+                                                    self.wk.rows_pad, self.wk.cols_pad, self.precision, _ptr(self.wk.hi),
+                                                    _ptr(self.wk.lo), _stream()), 'nmfmu_conv_pack_wk')
 
     def _pack_w_planes(self, update: bool):
         slabs = self.w_ksplit
@@ -446,7 +452,8 @@ class ConvMU(AsyncLossMixin):
             if not self.kl:
                 self._gemm_win(self.gpt, self.hden)
             _capi.check(self.lib.nmfmu_conv_apply_h_rows(
-                self.H.data_ptr(), self.B, self.R, self.Lh, self.hnum.data_ptr(), _ptr(self.hden),
+                self.H.data_ptr(), self.B, self.R, self.Lh // self.lhs[-1], self.lhs[-1], self.wk_fold, self.hnum.data_ptr(),
+                _ptr(self.hden),
                 self.sum_w.data_ptr() if self.kl else None, self.wk_rows, self.l1, self.l2, self.gamma, _stream()),
                 'nmfmu_conv_apply_h_rows')
             self._pack_h()

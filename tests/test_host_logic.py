@@ -169,8 +169,8 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
-    assert [f[0] for f in d._fields_][-13:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels',
-                                                'win_nd', 'win_lh', 'win_taps', 'win_channels', 'win_pitch', 't_koff']
+    assert [f[0] for f in d._fields_][-14:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels',
+                                                'win_nd', 'win_lh', 'win_taps', 'win_channels', 'win_pitch', 'win_fold', 't_koff']
     # ragged channels inside the GEMM grid: eight workgroups share out a tile's frames -> >= 8 tiles of the explicit operand
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 1) == 1           # configs[3], W half-step
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_A_HU, 8192, 1024, 1) == 1           # ... H half-step
