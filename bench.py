@@ -27,7 +27,8 @@ timed next to it (`bf16_mode`).  Printed JSON also carries
   parity        the same k iterations on the GPU and in the CPU reference from identical V, W0, H0: relative errors;
   beta_sweep    BASELINE configs[2]: beta in {2, 0.5, 0} at the same shape (iterations/s, kernel fraction at
                 12*N*C*R, parity k = 3);
-  nmfd          BASELINE configs[3]: NMFD 1025 x 8192, rank 8, T = 400 (iterations/s, per-GEMM fractions, parity).
+  nmfd          BASELINE configs[3]: NMFD 1025 x 8192, rank 8, T = 400 (iterations/s, per-GEMM fractions, parity);
+  nmf2d         SURVEY 8 row f2 (no reference headline): NMF2D 1 x 64 x 256 x 512, rank 8, 8 x 16 kernel, fit()'s own mode.
 """
 import argparse
 import json
@@ -67,7 +68,7 @@ def parse():
     ap.add_argument('--no-sweep', action='store_true', help='skip the beta_sweep (configs[2]) and nmfd (configs[3]) sub-objects '
                     'of the default run')
     ap.add_argument('--beta', type=float, default=1.0)
-    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16', 'f16x'],
+    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16', 'f16x', 'auto'],
                     help="operand type of the headline leg: 'f16' (default: fp16 operands, bf16's MFMA rate, meets the 1e-4 "
                          "parity bar; nmf and nmfd workloads), 'bf16' (the type configs[1] names; factors ~2e-4 after 3 "
                          "iterations; default of the other workloads), 'bf16x3'")
@@ -350,6 +351,8 @@ def nmfd_line(a, sub=False):
         H = torch.randn(1, R, L - T + 1, device=dev, generator=g).abs_()
         title = f'NMFD 1x{Cc}x{L} rank={R} T={T}' + (' (BASELINE configs[3])' if (Cc, L, R, T) == (1025, 8192, 8, 400) else '')
     Vc, Wc, Hc = V.cpu(), W.cpu(), H.cpu()
+    if a.precision == 'auto':          # what fit() picks for this problem (one set-up sync)
+        a.precision = prec_head = ConvMU(V, W.clone(), H.clone(), beta, precision='auto').precision_name
     eng = ConvMU(V, W, H, beta, precision=a.precision)
 
     def step():
@@ -902,6 +905,7 @@ def main():
     # configs[2] = the beta sweep at this shape, configs[3] = NMFD.  Each with its own in-run parity check (k = 3).
     beta_sweep = None
     nmfd = None
+    nmf2d = None
     default_run = (world == 1 and not betamu and not a.no_sweep and beta == 1 and (N, C, R) == (4096, 65536, 128)
                    and a.precision in ('f16', 'bf16'))
     if default_run:
@@ -956,6 +960,16 @@ def main():
         line = nmfd_line(na, sub=True)
         nmfd = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
                                      'roofline', 'parity', 'cpu_baseline', 'fit')}
+        # row f2 (no reference headline): NMF2D on a 64-channel 256 x 512 frame, rank 8, 8 x 16 kernel, in the
+        # mode fit() picks there (fp16 operands: every contraction has >= 1024 terms); its in-run parity covers bf16 as well
+        na = argparse.Namespace(**vars(a))
+        na.workload, na.precision, na.rows, na.cols, na.rank, na.beta = 'nmf2d', 'auto', None, None, None, 1.0
+        na.telemetry_s = 0
+        if not do_cpu:
+            na.cpu_iters = 0
+        line = nmfd_line(na, sub=True)
+        nmf2d = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
+                                      'roofline', 'parity', 'cpu_baseline')}
 
     # ---- fit(): the call a torchnmf user makes, end to end; real_data_mode: a target fp16 does NOT hold exactly
     fit_obj, real = None, None
@@ -1008,7 +1022,7 @@ def main():
                        'launch': 'eager launches'},
             'roofline': head.get('roofline'), 'cpu_baseline': cpu, 'parity': parity,
             ('bf16_mode' if other == 'bf16' else 'parity_mode'): second,
-            'beta_sweep': beta_sweep, 'nmfd': nmfd, 'fit': fit_obj, 'real_data_mode': real,
+            'beta_sweep': beta_sweep, 'nmfd': nmfd, 'nmf2d': nmf2d, 'fit': fit_obj, 'real_data_mode': real,
         }
         if betamu:
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \

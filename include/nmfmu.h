@@ -363,8 +363,8 @@ int nmfmu_conv_tables(const float* h, int batch, int rank, int lh, int taps, voi
  * nmfmu_convnd_koff is host code and fills k_pad / 8 + 8 ints (the last 8 are spare: the kernel reads one k-tile ahead);
  * the caller copies the array to the device. */
 size_t nmfmu_convnd_table_bytes(int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps);
-int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, void* rev_hi,
-                        void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream);
+int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, int precision,
+                        void* rev_hi, void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream);   /* BF16 | BF16X3 (lo planes) | F16 */
 int nmfmu_convnd_koff(int ops, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, int k_pad,
                       int32_t* koff_host);
 

@@ -20,6 +20,20 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs
   if (f16) {
     // fp16 operands: the combinations of the beta == 1 NMFD iteration on implicit operands (nmfd_engine.py, precision 'f16')
     if (x3) return -2;
+    if (ops == kOpsAWin) {   // H numerator on shifted ratio rows (fp16 ratio planes and Wk planes)
+      if (epi != kEpiF32) return -2;
+      if (a.n_pad % 128 == 0) return launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, GemmSmall, kOpF16>(a, s);
+      if (a.n_pad % 64 == 0) return launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, GemmN64, kOpF16>(a, s);
+      return launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, GemmN32, kOpF16>(a, s);
+    }
+    if (a.koff) {            // several shift axes
+#define NF16(E, B, O) \
+  if (epi == E && (E == kEpiF32 || beta_kind == B) && ops == O) \
+    return launch_gemm_one<false, E, B, O, GemmSmall, kOpF16, true>(a, s);
+      NF16(kEpiRatio, kKL, kOpsBHu) NF16(kEpiRatio, kKL, kOpsAHu) NF16(kEpiLoss, kKL, kOpsBHu) NF16(kEpiF32, kEuc, kOpsBHuT)
+#undef NF16
+      return -2;
+    }
 #define GF16(E, B, O) \
   if (epi == E && (E == kEpiF32 || E == kEpiFold || beta_kind == B) && ops == O) \
     return launch_gemm_one<false, E, B, O, GemmSmall, kOpF16>(a, s);
@@ -173,7 +187,8 @@ struct ConvGeom {
 };
 
 __global__ void __launch_bounds__(256) convnd_tables_kernel(const float* __restrict__ H, int B, int R, ConvGeom g,
-                                                            u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo) {
+                                                            u32x4* rev_hi, u32x4* rev_lo, u32x4* fwd_hi, u32x4* fwd_lo,
+                                                            int f16) {
   const int jj2 = g.l[2] + g.t[2] - 1, jj1 = g.l[1] + g.t[1] - 1, jj0 = g.l[0] + g.t[0] - 1;
   const int64_t n = 1 + (int64_t)B * R * jj0 * jj1 * jj2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -201,9 +216,9 @@ __global__ void __launch_bounds__(256) convnd_tables_kernel(const float* __restr
     u32x4 rh, rl, fh, fl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      uint32_t h = pack_bf16(vr[2 * e], vr[2 * e + 1]);
+      uint32_t h = pack_img(vr[2 * e], vr[2 * e + 1], f16);
       rh[e] = h, rl[e] = pack_bf16(vr[2 * e] - bf16_lo(h), vr[2 * e + 1] - bf16_hi(h));
-      h = pack_bf16(vf[2 * e], vf[2 * e + 1]);
+      h = pack_img(vf[2 * e], vf[2 * e + 1], f16);
       fh[e] = h, fl[e] = pack_bf16(vf[2 * e] - bf16_lo(h), vf[2 * e + 1] - bf16_hi(h));
     }
     rev_hi[i] = rh, fwd_hi[i] = fh;
@@ -1002,7 +1017,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   }
   if (d->ops == NMFMU_OPS_A_WIN) {
     // A[(b,j)][(t,c)] = P[(b, j + t)][c]: rows of the plane(s) a_hi / a_lo ([batch * prod(l)][win_pitch]) shifted by the tap
-    if (epilogue != NMFMU_EPI_F32 || f16 || a.k_split != 1) return NMFMU_ERR_ARG;
+    if (epilogue != NMFMU_EPI_F32 || a.k_split != 1) return NMFMU_ERR_ARG;
     if (d->win_pitch <= 0 || d->win_pitch % 64 || d->win_channels <= 0 || d->win_channels > d->win_pitch) return NMFMU_ERR_ARG;
     a.win_ck = (d->win_channels + 63) / 64;
     if (a.win_ck * 64 > d->win_pitch) return NMFMU_ERR_ARG;
@@ -1018,7 +1033,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     if ((int64_t)a.k_len != (int64_t)(geom.t_tot / fold) * a.win_ck * 64) return NMFMU_ERR_ARG;   // k = (t_outer, q, ck, c')
   } else if (nd_geom) {
     // window tables of an H with several shift axes (nmfmu_convnd_tables); t_koff from nmfmu_convnd_koff, on the device
-    if (!d->t_koff || f16 || epilogue == NMFMU_EPI_FOLD || d->rag_channels > 0) return NMFMU_ERR_ARG;
+    if (!d->t_koff || epilogue == NMFMU_EPI_FOLD || d->rag_channels > 0) return NMFMU_ERR_ARG;
     if (geom.t[2] % 8 || geom.l[2] % 8) return NMFMU_ERR_ARG;
     a.tB = d->t_batch, a.tR = d->t_rank, a.tT = geom.t_tot, a.tLh = geom.lh_tot;
     a.koff = d->t_koff;
@@ -1380,15 +1395,16 @@ size_t nmfmu_convnd_table_bytes(int batch, int rank, int ndim, const int32_t* lh
   return (1 + n) * 16;
 }
 
-int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, void* rev_hi,
-                        void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream) {
+int nmfmu_convnd_tables(const float* h, int batch, int rank, int ndim, const int32_t* lh, const int32_t* taps, int precision,
+                        void* rev_hi, void* rev_lo, void* fwd_hi, void* fwd_lo, void* stream) {
   ConvGeom g;
   if (!h || !rev_hi || !fwd_hi || batch <= 0 || rank <= 0 || make_geom(ndim, lh, taps, &g)) return NMFMU_ERR_ARG;
   if (g.t[2] % 8 || g.l[2] % 8 || (rev_lo == nullptr) != (fwd_lo == nullptr)) return NMFMU_ERR_ARG;
+  if ((precision == NMFMU_PREC_BF16X3) != (rev_lo != nullptr) || precision == NMFMU_PREC_F16X) return NMFMU_ERR_ARG;
   const int64_t n = (int64_t)(nmfmu_convnd_table_bytes(batch, rank, ndim, lh, taps) / 16);
   if (n > INT32_MAX) return NMFMU_ERR_ARG;     // chunk indices are 32-bit in the GEMM
   hipLaunchKernelGGL(convnd_tables_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, g, (u32x4*)rev_hi,
-                     (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo);
+                     (u32x4*)rev_lo, (u32x4*)fwd_hi, (u32x4*)fwd_lo, (int)(precision == NMFMU_PREC_F16));
   return (int)hipGetLastError();
 }
 

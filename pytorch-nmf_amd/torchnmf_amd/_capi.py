@@ -136,8 +136,8 @@ SIGNATURES = {
     'nmfmu_conv_apply_h_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     'nmfmu_convnd_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_convnd_koff': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_slab_sum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'nmfmu_convnd_fold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

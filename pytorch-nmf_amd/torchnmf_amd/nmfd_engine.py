@@ -100,18 +100,29 @@ class ConvMU(AsyncLossMixin):
         self._t_arr = (C.c_int32 * nd)(*self.ts)
         for t_ in (W, H):
             assert t_.dtype == torch.float32 and t_.is_contiguous()
-        # 'f16' (fp16 operand planes, window tables and ratio planes: 11 significant bits at the bf16 MFMA rate) exists
-        # for the beta == 1 iteration on implicit operands with >= 128 taps (the fold-parts / fused-sums path): that is
-        # where NMFD is large enough for throughput to matter and for the rounding errors to average down (DESIGN.md
-        # section 4).  'auto' takes it there when the data fit fp16's range, the fp32-grade split mode otherwise.
-        f16_ok = (own_loop and nd == 1 and float(beta) == 1.0 and T % 8 == 0 and L % 8 == 0 and T >= 128 and
-                  os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1' and
-                  os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0' and
-                  os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
+        # 'f16' (fp16 operand planes, window tables and ratio planes: 11 significant bits at the bf16 MFMA rate) exists for
+        # the beta == 1 iteration on implicit operands, in two forms: one shift axis with >= 128 taps (the fold-parts /
+        # fused-sums path), and -- round 4 -- the path whose H numerator is the window-operand GEMM (any number of shift
+        # axes, fewer than 128 taps).  'auto' takes it where every contraction is long enough for the rounding errors to
+        # average down and the data fit fp16's range; the fp32-grade split mode otherwise.
+        aligned = (self.ts[-1] % 8 == 0 and self.ls[-1] % 8 == 0 and os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1')
+        f16_fold = (nd == 1 and T >= 128 and os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0' and
+                    os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
+        f16_rows = ((nd > 1 or 1 < T < 128) and os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
+        f16_ok = own_loop and float(beta) == 1.0 and aligned and (f16_fold or f16_rows)
+        # (fold path: Y elements contract over the channels alone; window-operand path: over channels x taps)
+        long_enough = (min(Cc, B * L) >= self.F16_MIN_DIM and R * T >= self.F16_MIN_DIM) if f16_fold else \
+            min(Cc * T, B * L, R * T) >= self.F16_MIN_DIM
         if precision in (None, 'auto'):
             precision = 'bf16x3'
-            if (f16_ok and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0' and min(Cc, B * L) >= self.F16_MIN_DIM
-                    and R * T >= self.F16_MIN_DIM):
+            if (own_loop and nd == 1 and float(beta) == 1.0 and T >= 128 and (T % 8 or L % 8) and
+                    min(Cc, B * L) >= self.F16_MIN_DIM and R * T >= self.F16_MIN_DIM):
+                import warnings
+                warnings.warn(f"torchnmf_amd: NMFD with {T} taps over {L} frames: the single-plane fp16 mode needs taps and "
+                              "frames that are multiples of 8 (implicit Toeplitz operands); precision='auto' falls back to "
+                              "split bf16 at three times the matrix work.  Trim or pad the frame axis to a multiple of 8 "
+                              "for the fast mode.", stacklevel=3)
+            if f16_ok and os.environ.get('TORCHNMF_AMD_AUTO_F16', '1') != '0' and long_enough:
                 stats = torch.stack([V.abs().max(), W.abs().max(), H.abs().max(), V.abs().mean(), W.abs().mean(),
                                      H.abs().mean()]).tolist()          # one host sync at engine set-up
                 if max(stats[:3]) <= self.F16_MAX_ABS and min(stats[3:]) >= self.F16_MIN_MEAN:
@@ -119,8 +130,8 @@ class ConvMU(AsyncLossMixin):
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
         if precision == 'f16' and not f16_ok:
-            raise ValueError("precision 'f16' is built for NMFD with beta == 1, taps >= 128 and taps / frames that are "
-                             "multiples of 8 (implicit Toeplitz operands); use 'bf16x3' or 'bf16'")
+            raise ValueError("precision 'f16' is built for the convolutive models with beta == 1 and taps / frames (of the "
+                             "last shift axis) that are multiples of 8 (implicit Toeplitz operands); use 'bf16x3' or 'bf16'")
         self.precision_name = precision
         self.precision = _capi.PRECISIONS[precision]
         x3 = self.precision == _capi.PREC_BF16X3
@@ -212,8 +223,11 @@ class ConvMU(AsyncLossMixin):
         # A operand are shifted rows of the ratio planes the H half-step has just written, so nothing is unfolded or folded
         # (Y is 4 R T B L bytes: 537 MB for a 256 x 512 frame with 8 x 16 taps).  Any number of shift axes, no alignment
         # rules.  The fold-parts path above stays where it applies (1-D, >= 128 taps: it multiplies no padding of the rank).
-        self.h_rows = (own_loop and T > 1 and not self.fold_parts and self.precision != _capi.PREC_F16 and
-                       2 * blp * cp < 2 ** 32 and os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
+        self.h_rows = (own_loop and T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 32 and
+                       os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
+        if self.precision == _capi.PREC_F16 and not (self.fold_parts or self.h_rows):
+            raise ValueError("precision 'f16': this shape takes neither the fold-parts nor the window-operand path for the H "
+                             "numerator (fp16 planes are built for those two); use 'bf16x3' or 'bf16'")
         self.y = self.y_den = None
         if self.h_rows:
             self.wk_rows = 32 if R <= 32 else 64 if R <= 64 else pad(R)
@@ -379,7 +393,7 @@ class ConvMU(AsyncLossMixin):
     def _pack_h(self, sums: bool = True):
         if self.implicit and self.nd > 1:
             _capi.check(self.lib.nmfmu_convnd_tables(self.H.data_ptr(), self.B, self.R, self.nd, self._lh_arr, self._t_arr,
-                                                     _ptr(self.hu.hi), _ptr(self.hu.lo), _ptr(self.hut.hi),
+                                                     self.precision, _ptr(self.hu.hi), _ptr(self.hu.lo), _ptr(self.hut.hi),
                                                      _ptr(self.hut.lo), _stream()), 'nmfmu_convnd_tables')
         elif self.implicit:
             if self.precision == _capi.PREC_F16:

@@ -1121,13 +1121,74 @@ def test_nmfd_f16_mode(dev, shape):
         assert l0 == pytest.approx(float(O.beta_div(O.nmfd_reconstruct(H0, W0), V, 1)), rel=2e-3 if prec == 'bf16' else 3e-4)
     print(f'nmfd f16 {shape}: f16 relW={err["f16"][0]:.2e} relH={err["f16"][1]:.2e}; bf16 relW={err["bf16"][0]:.2e}')
     assert max(err['f16']) < 6e-4 and max(err['f16']) < 0.4 * max(err['bf16'])
-    with pytest.raises(ValueError):               # fewer than 128 taps / beta != 1: not built
-        ConvMU(V[:, :, :256].to(dev).contiguous(), W0[:, :, :16].clone().to(dev).contiguous(),
-               torch.rand(B, R, 241).to(dev), 1, precision='f16')
+    # fewer than 128 taps: the window-operand path (round 4) has fp16 planes too; beta != 1 / unaligned frames: not built
+    short = ConvMU(V[:, :, :256].to(dev).contiguous(), W0[:, :, :16].clone().to(dev).contiguous(),
+                   torch.rand(B, R, 241).to(dev), 1, precision='f16')
+    assert short.h_rows and not short.fold_parts
     with pytest.raises(ValueError):
         ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 2, precision='f16')
+    with pytest.raises(ValueError):
+        ConvMU(V[:, :, :251].to(dev).contiguous(), W0[:, :, :16].clone().to(dev).contiguous(),
+               torch.rand(B, R, 236).to(dev), 1, precision='f16')
     small = ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 1, precision='auto')
     assert small.precision_name == ('f16' if min(Cc, B * L, R * T) >= 1024 else 'bf16x3')
+
+
+@pytest.mark.parametrize('shape', [
+    (1, 64, (64, 128), 8, (8, 16)),          # B, C, ls, R, ks: NMF2D, every contraction >= 1024 -> 'auto' takes fp16
+    (2, 96, (2048,), 16, (64,)),             # NMFD below 128 taps
+    (1, 40, (12, 24, 32), 4, (2, 4, 8)),     # NMF3D (contractions too short for 'auto')
+])
+def test_fp16_operands_on_the_window_operand_path(dev, shape):
+    """precision 'f16' beyond the fold-parts path (round 4): fp16 window tables (1 - 3 shift axes), fp16 ratio planes,
+    fp16 W planes for the H numerator GEMM; beta == 1.  Same bar as the 1-D fold path: closer to the oracle than bf16 by a
+    wide margin, and 'auto' takes it exactly when every contraction has >= 1024 terms."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    B, Cc, ls, R, ks = shape
+    g = torch.Generator().manual_seed(sum(ls) + R)
+    V = torch.rand(B, Cc, *ls, generator=g) + 1e-3
+    W0 = torch.randn(Cc, R, *ks, generator=g).abs()
+    H0 = torch.randn(B, R, *[l - k + 1 for l, k in zip(ls, ks)], generator=g).abs()
+    kind = 'nmfd' if len(ls) == 1 else 'convnd'
+    Wr, Hr, _, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 3, kind=kind)
+    recon0 = O.nmfd_reconstruct(H0, W0) if len(ls) == 1 else O.convnd_reconstruct(H0, W0)
+    err = {}
+    for prec in ('f16', 'bf16'):
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = ConvMU(V.to(dev), W, H, 1, precision=prec)
+        assert eng.precision_name == prec and eng.h_rows and eng.implicit
+        l0 = eng.divergence()
+        for _ in range(3):
+            eng.w_step()
+            eng.h_step()
+        err[prec] = (rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr))
+        assert bool(torch.isfinite(W).all()) and bool(torch.isfinite(H).all())
+        assert l0 == pytest.approx(float(O.beta_div(recon0, V, 1)), rel=2e-3 if prec == 'bf16' else 3e-4)
+    print(f'f16 window path {shape}: f16 relW={err["f16"][0]:.2e} relH={err["f16"][1]:.2e}; bf16 relW={err["bf16"][0]:.2e} relH={err["bf16"][1]:.2e}')
+    assert max(err['f16']) < 6e-4 and max(err['f16']) < 0.4 * max(err['bf16'])
+    T, L = int(np.prod(ks)), int(np.prod(ls))
+    auto = ConvMU(V.to(dev), W0.clone().to(dev), H0.clone().to(dev), 1, precision='auto')
+    assert auto.precision_name == ('f16' if min(Cc * T, B * L, R * T) >= 1024 else 'bf16x3')
+    if auto.precision_name == 'f16':
+        assert max(err['f16']) < 2e-4
+
+
+def test_nmfd_auto_warns_when_alignment_costs_the_fp16_mode(dev):
+    """a spectrogram whose frame count is not a multiple of 8 cannot take the implicit operands, so
+    'auto' runs split bf16 at 3x the matrix work -- the user is told."""
+    from torchnmf_amd.nmfd_engine import ConvMU
+    g = torch.Generator().manual_seed(3)
+    V = (torch.rand(1, 1024, 1027, generator=g) + 1e-3).to(dev)
+    W, H = torch.rand(1024, 8, 128, generator=g).to(dev), torch.rand(1, 8, 900, generator=g).to(dev)
+    with pytest.warns(UserWarning, match='multiples of 8'):
+        eng = ConvMU(V, W, H, 1, precision='auto')
+    assert eng.precision_name == 'bf16x3' and not eng.implicit
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')               # aligned: fp16 mode, no warning
+        eng = ConvMU(V[:, :, :1024].contiguous(), W, H[:, :, :897].contiguous(), 1, precision='auto')
+    assert eng.precision_name == 'f16'
 
 
 @pytest.mark.parametrize('shape', [
