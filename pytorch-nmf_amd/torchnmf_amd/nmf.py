@@ -130,7 +130,11 @@ class BaseComponent(nn.Module):
                          Explicit: 'f16' (a V that fp16 does not hold exactly is rounded to 11 significant bits: a few
                          1e-5 per iteration, ~3e-4 after 200), 'f16x', 'bf16x3', 'bf16' (V and operands rounded to
                          bf16: objective within 1e-4, factors ~1e-3).
-                         The environment variable TORCHNMF_AMD_PRECISION overrides the default.
+                         The convolutive models (NMFD / NMF2D / NMF3D): 'f16' for beta == 1 when taps and frames of
+                         the last shift axis are multiples of 8, every contraction has >= 1024 terms and the data fit
+                         fp16's range; otherwise 'bf16x3'.
+                         The environment variable TORCHNMF_AMD_PRECISION overrides the default.  After the call
+                         ``self.last_precision`` names the mode that ran.
           process_group  a torch.distributed group: V and W are then this rank's column shard
                          (V[:, Cg], W[Cg]); H is replicated.
           allreduce      sharded fits only: 'single' = ONE all-reduce of the packed [numerator | denominator] buffer per
@@ -170,6 +174,7 @@ class BaseComponent(nn.Module):
             self._ar_overlap = None if allreduce is None else allreduce == 'overlap'
             self._ar_direct = None if allreduce is None else allreduce == 'direct'
             eng = self._make_engine(V, beta, l1, l2, precision, process_group)
+        self.last_precision = getattr(eng, 'precision_name', None)   # what 'auto' resolved to (plain attribute, not state)
 
         has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
         assert not has_bad, "Target should be non-negative."

@@ -1174,6 +1174,25 @@ def test_fp16_operands_on_the_window_operand_path(dev, shape):
         assert max(err['f16']) < 2e-4
 
 
+def test_nmf2d_default_fit_takes_fp16_operands(dev):
+    """NMF2D.fit with its default precision on a problem whose contractions all have >= 1024 terms: 'auto' -> fp16
+    operands (1x the MFMA work), 20 iterations through the asynchronous checkpoint loop, within 1e-4 of the oracle's
+    20 iterations (nmf.py:297-409 on the conv2d model)."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF2D
+    g = torch.Generator().manual_seed(77)
+    V = torch.rand(1, 64, 64, 128, generator=g) + 1e-3
+    W0 = torch.randn(64, 8, 8, 16, generator=g).abs()
+    H0 = torch.randn(1, 8, 57, 113, generator=g).abs()
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 20, kind='convnd')
+    m = NMF2D(W=W0, H=H0).to(dev)
+    n = m.fit(V.to(dev), beta=1, tol=NO_STOP, max_iter=20)
+    assert n == nr == 20 and m.last_precision == 'f16'
+    ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
+    print(f'NMF2D default fit, 20 iterations: rel W={ew:.2e} H={eh:.2e}')
+    assert ew < TOL and eh < TOL
+
+
 def test_nmfd_auto_warns_when_alignment_costs_the_fp16_mode(dev):
     """a spectrogram whose frame count is not a multiple of 8 cannot take the implicit operands, so
     'auto' runs split bf16 at 3x the matrix work -- the user is told."""
