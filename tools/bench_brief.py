@@ -29,3 +29,6 @@ for b, e in ((d.get('beta_sweep') or {}).get('betas') or {}).items():
 if d.get('nmfd'):
     n = d['nmfd']
     print(f"  nmfd: {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {n.get('parity')}")
+if d.get('nmf2d'):
+    n = d['nmf2d']
+    print(f"  nmf2d ({n['dtype']}): {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {(n.get('parity') or {}).get('modes')}")
