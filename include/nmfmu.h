@@ -312,7 +312,8 @@ typedef struct nmfmu_gemm_desc {
    * shift axis) -- tile row (b, j) of k-tile (t, 64 channels) is row (b, j + t) of P, so the operand fetch is the plain
    * plane fetch with a per-lane row map and a scalar tap offset.  B = [n_pad][k_pad] planes of W ordered
    * k = (t * ceil(win_channels / 64) + ck) * 64 + c' (nmfmu_conv_pack_wk); k_len = prod(taps) * ceil(win_channels / 64) * 64;
-   * m_pad >= t_batch * prod(lh) rows (b, j), j flattened over the shift axes; n_pad a multiple of 32 (the padded rank).
+   * m_pad >= t_batch * prod(lh) rows (b, j), j flattened over the shift axes; n_pad a multiple of 32 (the padded rank);
+   * the planes P must be smaller than 2 GiB each (32-bit lane offsets).
    * out[(b,j)][r] = sum_{c,t} P[(b, j + t)][c] W[c][r][t]   (conv backward wrt H, nmf.py:776-779 / 857-860 / 937-940). */
   int32_t win_nd;          /* shift axes, 1 .. 3 */
   int32_t win_lh[3];       /* H extent per axis (outermost first; the first win_nd entries) */

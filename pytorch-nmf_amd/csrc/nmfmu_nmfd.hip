@@ -1028,7 +1028,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     a.win_tstep = fold;
     a.win_lh[2] = geom.lh[2] + fold - 1, a.win_t[2] = geom.t[2] / fold;
     const int64_t rows = (int64_t)d->t_batch * geom.lh[0] * geom.lh[1] * a.win_lh[2];
-    if (rows > d->m_pad || (int64_t)d->t_batch * geom.l_tot * a.win_pitch >= ((int64_t)1 << 32)) return NMFMU_ERR_ARG;
+    if (rows > d->m_pad || (int64_t)d->t_batch * geom.l_tot * a.win_pitch >= ((int64_t)1 << 31)) return NMFMU_ERR_ARG;   // 32-bit lane offsets
     a.win_rows = (int)rows;
     if ((int64_t)a.k_len != (int64_t)(geom.t_tot / fold) * a.win_ck * 64) return NMFMU_ERR_ARG;   // k = (t_outer, q, ck, c')
   } else if (nd_geom) {

@@ -223,7 +223,7 @@ class ConvMU(AsyncLossMixin):
         # A operand are shifted rows of the ratio planes the H half-step has just written, so nothing is unfolded or folded
         # (Y is 4 R T B L bytes: 537 MB for a 256 x 512 frame with 8 x 16 taps).  Any number of shift axes, no alignment
         # rules.  The fold-parts path above stays where it applies (1-D, >= 128 taps: it multiplies no padding of the rank).
-        self.h_rows = (own_loop and T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 32 and
+        self.h_rows = (own_loop and T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 31 and
                        os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
         if self.precision == _capi.PREC_F16 and not (self.fold_parts or self.h_rows):
             raise ValueError("precision 'f16': this shape takes neither the fold-parts nor the window-operand path for the H "
