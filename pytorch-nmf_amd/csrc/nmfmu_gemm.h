@@ -90,6 +90,9 @@ using GemmSmall = GemmShape<2, 2, 2, 2>;
 // narrow-N tiles (128 x 32, 128 x 64) for the window-operand GEMM, whose N is the rank
 using GemmN32 = GemmShape<4, 1, 1, 1>;
 using GemmN64 = GemmShape<4, 1, 1, 2>;
+// 64 x 128: the explicit operand of a reconstruction / W-numerator GEMM when the model has at most 64 channels (with
+// GemmN64 for the transposed problem): half the MFMA work and explicit-operand traffic of a half-empty 128-row tile
+using GemmM64 = GemmShape<1, 4, 2, 1>;
 // (256 x 128 and 128 x 256 with eight 64 x 64 waves were measured too: same time as two 128 x 128 workgroups per CU.)
 
 template <bool X3, class SH>

@@ -26,11 +26,20 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs
       if (a.n_pad % 64 == 0) return launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, GemmN64, kOpF16>(a, s);
       return launch_gemm_one<false, kEpiF32, kEuc, kOpsAWin, GemmN32, kOpF16>(a, s);
     }
-    if (a.koff) {            // several shift axes
-#define NF16(E, B, O) \
+    if (a.koff) {            // several shift axes; at most 64 channels: 64-row (resp. 64-column) tiles on the channel side
+#define NF16(E, B, O, SH) \
   if (epi == E && (E == kEpiF32 || beta_kind == B) && ops == O) \
-    return launch_gemm_one<false, E, B, O, GemmSmall, kOpF16, true>(a, s);
-      NF16(kEpiRatio, kKL, kOpsBHu) NF16(kEpiRatio, kKL, kOpsAHu) NF16(kEpiLoss, kKL, kOpsBHu) NF16(kEpiF32, kEuc, kOpsBHuT)
+    return launch_gemm_one<false, E, B, O, SH, kOpF16, true>(a, s);
+      if (ops != kOpsAHu && a.m_pad == 64) {
+        NF16(kEpiRatio, kKL, kOpsBHu, GemmM64) NF16(kEpiLoss, kKL, kOpsBHu, GemmM64) NF16(kEpiF32, kEuc, kOpsBHuT, GemmM64)
+        return -2;
+      }
+      if (ops == kOpsAHu && a.n_pad == 64) {
+        NF16(kEpiRatio, kKL, kOpsAHu, GemmN64)
+        return -2;
+      }
+      NF16(kEpiRatio, kKL, kOpsBHu, GemmSmall) NF16(kEpiRatio, kKL, kOpsAHu, GemmSmall) NF16(kEpiLoss, kKL, kOpsBHu, GemmSmall)
+      NF16(kEpiF32, kEuc, kOpsBHuT, GemmSmall)
 #undef NF16
       return -2;
     }
@@ -44,13 +53,24 @@ int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs
   }
   if (a.koff) {
     // implicit operands with several shift axes (NMF2D / NMF3D): the same combinations, ND instances
-#define N1(X, E, B, O) \
+#define N1(X, E, B, O, SH) \
   if (x3 == (X ? 1 : 0) && epi == E && (E == kEpiF32 || beta_kind == B) && ops == O) \
-    return launch_gemm_one<X, E, B, O, GemmSmall, kOpBf16, true>(a, s);
-#define NB(X, E, O) N1(X, E, kKL, O) N1(X, E, kEuc, O) N1(X, E, kIS, O) N1(X, E, kGen, O)
-    NB(false, kEpiRatio, kOpsBHu) NB(true, kEpiRatio, kOpsBHu) NB(false, kEpiRatio, kOpsAHu) NB(true, kEpiRatio, kOpsAHu)
-    NB(false, kEpiLoss, kOpsBHu) NB(true, kEpiLoss, kOpsBHu)
-    N1(false, kEpiF32, kEuc, kOpsBHuT) N1(true, kEpiF32, kEuc, kOpsBHuT)
+    return launch_gemm_one<X, E, B, O, SH, kOpBf16, true>(a, s);
+#define NB(X, E, O, SH) N1(X, E, kKL, O, SH) N1(X, E, kEuc, O, SH) N1(X, E, kIS, O, SH) N1(X, E, kGen, O, SH)
+    if (ops != kOpsAHu && a.m_pad == 64) {      // at most 64 channels: 64-row tiles on the channel side
+      NB(false, kEpiRatio, kOpsBHu, GemmM64) NB(true, kEpiRatio, kOpsBHu, GemmM64)
+      NB(false, kEpiLoss, kOpsBHu, GemmM64) NB(true, kEpiLoss, kOpsBHu, GemmM64)
+      N1(false, kEpiF32, kEuc, kOpsBHuT, GemmM64) N1(true, kEpiF32, kEuc, kOpsBHuT, GemmM64)
+      return -2;
+    }
+    if (ops == kOpsAHu && a.n_pad == 64) {      // ... 64-column tiles in the transposed problem
+      NB(false, kEpiRatio, kOpsAHu, GemmN64) NB(true, kEpiRatio, kOpsAHu, GemmN64)
+      return -2;
+    }
+    NB(false, kEpiRatio, kOpsBHu, GemmSmall) NB(true, kEpiRatio, kOpsBHu, GemmSmall)
+    NB(false, kEpiRatio, kOpsAHu, GemmSmall) NB(true, kEpiRatio, kOpsAHu, GemmSmall)
+    NB(false, kEpiLoss, kOpsBHu, GemmSmall) NB(true, kEpiLoss, kOpsBHu, GemmSmall)
+    N1(false, kEpiF32, kEuc, kOpsBHuT, GemmSmall) N1(true, kEpiF32, kEuc, kOpsBHuT, GemmSmall)
 #undef NB
 #undef N1
     return -2;
@@ -981,8 +1001,12 @@ int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops) {
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
-  const int n_mult = d->ops == NMFMU_OPS_A_WIN ? 32 : 128;   // the window-operand GEMM has narrow-N tiles (N = rank)
-  if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % 128 || d->n_pad % n_mult || d->k_pad % 128)
+  // tiles are 128 x 128, except: the window-operand GEMM has narrow-N tiles (N = rank), and implicit operands with several
+  // shift axes take a 64-row (B_HU / B_HUT) resp. 64-column (A_HU) tile when the channel side is exactly 64
+  const bool nd_ops = d->ops != NMFMU_OPS_PLANES && d->ops != NMFMU_OPS_A_WIN && d->win_nd > 1;
+  const int n_mult = d->ops == NMFMU_OPS_A_WIN ? 32 : (nd_ops && d->ops == NMFMU_OPS_A_HU && d->n_pad == 64) ? 64 : 128;
+  const int m_mult = (nd_ops && d->ops != NMFMU_OPS_A_HU && d->m_pad == 64) ? 64 : 128;
+  if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % m_mult || d->n_pad % n_mult || d->k_pad % 128)
     return NMFMU_ERR_ARG;
   const int x3 = d->precision == NMFMU_PREC_BF16X3, f16 = d->precision == NMFMU_PREC_F16;
   if (x3 && (!d->a_lo || !d->b_lo)) return NMFMU_ERR_ARG;

@@ -200,7 +200,11 @@ class ConvMU(AsyncLossMixin):
                                bool(self.lib.nmfmu_gemm_ragged_supported(_capi.OPS_B_HU, self.c_main, blp, Cc - self.c_main)) and
                                bool(self.lib.nmfmu_gemm_ragged_supported(_capi.OPS_A_HU, blp, self.c_main, Cc - self.c_main)) and
                                os.environ.get('TORCHNMF_AMD_NMFD_RAGGED_IN_GRID', '1') != '0')
-        rz = self.ragged                        # the GEMM then leaves the padding rows / columns of the ratio planes alone
+        # at most 64 channels with several shift axes: the GEMMs' channel side runs 64-row / 64-column tiles (half the MFMA work
+        # and explicit-operand traffic of a half-empty 128 tile); the planes keep their 128 pitch
+        self.c_rows = 64 if (nd > 1 and self.implicit and Cc <= 64 and
+                             os.environ.get('TORCHNMF_AMD_NMFD_NARROW', '1') != '0') else None
+        rz = self.ragged or bool(self.c_rows)   # the GEMM then leaves the padding rows / columns of the ratio planes alone
         self.gn = _Planes(cp, blp, x3, dev, rz)     # W half-step ratio, [c][(b,l)]
         self.gnt = _Planes(blp, cp, x3, dev, rz)    # H half-step ratio, [(b,l)][c]
         self.gp = None if self.kl else _Planes(cp, blp, x3, dev, rz)
@@ -375,11 +379,13 @@ class ConvMU(AsyncLossMixin):
 
     def _pack_w_planes(self, update: bool):
         slabs = self.w_ksplit
-        if update and slabs > 2:      # many split-K partials: a wide reduction first (the apply kernel has few blocks)
+        if update and (slabs > 2 or (slabs > 1 and self.c_rows)):
+            # many split-K partials: a wide reduction first (the apply kernel has few blocks).  A slab holds the rows the GEMM
+            # ran over (c_rows of them when the channel side uses the 64-row tile)
             for buf in (self.num_w, self.den_w):
                 if buf is not None:
-                    _capi.check(self.lib.nmfmu_slab_sum(buf.data_ptr(), self.c_pad * self.rp_pad, slabs, _stream()),
-                                'nmfmu_slab_sum')
+                    _capi.check(self.lib.nmfmu_slab_sum(buf.data_ptr(), (self.c_rows or self.c_pad) * self.rp_pad, slabs,
+                                                        _stream()), 'nmfmu_slab_sum')
             slabs = 1
         # (the _sums entry without its partial-sum operands: the one that adds the split-K slabs of num / den)
         _capi.check(self.lib.nmfmu_conv_apply_pack_w_sums(
@@ -442,14 +448,15 @@ class ConvMU(AsyncLossMixin):
             if not self.ragged_in_grid:
                 self._ragged(0, self.x_w, self.gn, self.gp)
         else:
-            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, tag='recon_w')
+            self._gemm(self.wm, self.hu, _capi.EPI_RATIO, x=self.x_w, gn=self.gn, gp=self.gp, m_rows=self.c_rows,
+                       tag='recon_w')
 
     def w_step(self):
         """nmf.py:367-378 for the conv1d model."""
         self.recon_ratio_w()
-        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit, tag='num_w')
+        self._gemm(self.gn, self.hut, _capi.EPI_F32, out=self.num_w, k_split=self.w_ksplit, m_rows=self.c_rows, tag='num_w')
         if not self.kl:
-            self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w, k_split=self.w_ksplit)
+            self._gemm(self.gp, self.hut, _capi.EPI_F32, out=self.den_w, k_split=self.w_ksplit, m_rows=self.c_rows)
         self._pack_w(update=True)
 
     def h_step(self):
@@ -460,7 +467,8 @@ class ConvMU(AsyncLossMixin):
             if not self.ragged_in_grid:
                 self._ragged(1, self.x_h, self.gnt, self.gpt)
         else:
-            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, tag='recon_h')
+            self._gemm(self.hu, self.wm, _capi.EPI_RATIO, x=self.x_h, gn=self.gnt, gp=self.gpt, n_rows=self.c_rows,
+                       tag='recon_h')
         if self.h_rows:
             self._gemm_win(self.gnt, self.hnum, tag='num_h')
             if not self.kl:
@@ -526,7 +534,7 @@ class ConvMU(AsyncLossMixin):
     def _loss_device(self):
         """Enqueue beta_div(conv1d reconstruction, V) (nmf.py:360-361 / 400-401); the value as a float64[1] device tensor."""
         self._gemm(self.wm, self.hu, _capi.EPI_LOSS, x=self.x_w, out=self.loss_part, m_valid=self.C,
-                   n_valid=self.B * self.L, m_rows=self.c_main if self.ragged else None)
+                   n_valid=self.B * self.L, m_rows=self.c_main if self.ragged else self.c_rows)
         if self.ragged:
             self._ragged(2, self.x_w)
         return self.loss_part.double().sum().reshape(1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, NMF2D: window-operand H numerator, N-D implicit operands, split-K W numerator: focused tests + benches + trace
 OUT=gpurun_out/r4z; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "h_numerator or several_shift or nmf2d or siplca or SIPLCA or fold_from_tile or wide or nmfd or fp16_operands" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" ; tail -4 $OUT/pytest.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "h_numerator or several_shift or nmf2d or siplca or SIPLCA or fold_from_tile or fp16_operands" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" ; tail -4 $OUT/pytest.log
 show() { python - <<PY
 import json
 d=json.load(open("$1")); print("$2", d["config"]["precision"], "it/s", d["iters_per_s"], {k: v["avg_launch_ms"] for k, v in d["roofline"].get("per_gemm", {}).items()}, (d.get("parity") or {}).get("modes"))
