@@ -535,6 +535,9 @@ int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int tap
                        int precision, void* wk_hi, void* wk_lo, void* stream);
 int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
                             const float* den, const float* kl_den, int ld, float l1, float l2, float gamma, void* stream);
+/* ... and the sum alone: out (batch, rank, lh_outer, lh_last) = the folded numerator (shift-invariant PLCA's own update) */
+int nmfmu_conv_rows_fold(float* out, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num, int ld,
+                         void* stream);
 /* slabs[0][i] += slabs[1][i] + .. + slabs[nslab-1][i], fixed order: the partials of a split-K NMFMU_EPI_F32 launch
  * (k_split slabs of m_pad * n_ld floats) for a consumer that takes one slab.  slab_elems a multiple of 4. */
 int nmfmu_slab_sum(float* slabs, int64_t slab_elems, int nslab, void* stream);

@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restric
                                                                 int F, const float* __restrict__ num,
                                                                 const float* __restrict__ den,
                                                                 const float* __restrict__ kl_den, int ld, float l1,
-                                                                float l2, float gamma) {
+                                                                float l2, float gamma, float* __restrict__ fold_out) {
   const int64_t n = (int64_t)B * lh_outer * lh_last * R;
   const int lw = lh_last + F - 1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -934,7 +934,8 @@ __global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restric
       if (den) pos_ += den[row0 + (size_t)d * (ld + 1)];
     }
     const size_t o = (((size_t)b * R + r) * lh_outer + jo) * lh_last + j;
-    H[o] = mu_update(H[o], neg, kl_den ? kl_den[r] : pos_, kl_den != nullptr, l1, l2, gamma);
+    if (fold_out) fold_out[o] = neg;    // the sum only (shift-invariant PLCA applies its own update)
+    else H[o] = mu_update(H[o], neg, kl_den ? kl_den[r] : pos_, kl_den != nullptr, l1, l2, gamma);
   }
 }
 
@@ -1407,7 +1408,7 @@ int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_
     return NMFMU_ERR_ARG;
   const int64_t n = (int64_t)batch * lh_outer * lh_last * rank;
   hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh_outer, lh_last,
-                     fold, num, den, kl_den, ld, l1, l2, gamma);
+                     fold, num, den, kl_den, ld, l1, l2, gamma, (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1462,6 +1463,16 @@ int nmfmu_slab_sum(float* slabs, int64_t slab_elems, int nslab, void* stream) {
   if (!slabs || slab_elems <= 0 || slab_elems % 4 || nslab < 1) return NMFMU_ERR_ARG;
   if (nslab == 1) return NMFMU_OK;
   hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(slab_elems / 4)), dim3(256), 0, S(stream), slabs, slab_elems / 4, nslab);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_rows_fold(float* out, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num, int ld,
+                         void* stream) {
+  if (!out || !num || batch <= 0 || rank <= 0 || lh_outer <= 0 || lh_last <= 0 || fold < 1 || ld < rank * fold)
+    return NMFMU_ERR_ARG;
+  const int64_t n = (int64_t)batch * lh_outer * lh_last * rank;
+  hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), out, batch, rank, lh_outer, lh_last,
+                     fold, num, (const float*)nullptr, num /* non-null: closed form, unused */, ld, 0.f, 0.f, 1.f, out);
   return (int)hipGetLastError();
 }
 

@@ -139,6 +139,8 @@ SIGNATURES = {
     'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_convnd_koff': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'nmfmu_conv_rows_fold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p]),
     'nmfmu_slab_sum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'nmfmu_convnd_fold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p]),

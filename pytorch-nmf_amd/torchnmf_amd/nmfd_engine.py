@@ -81,7 +81,8 @@ class ConvMU(AsyncLossMixin):
     F16_MIN_MEAN = 2.0 ** -10
 
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', update_W=True, update_H=True, own_loop=True):
-        # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM) needs the plain Y buffer
+        # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM): none of the paths that fuse this engine's
+        # own update into a GEMM's neighbours (fold parts, fused sums, ragged channels), split bf16 unless told otherwise
         self.lib = _capi.load()
         if not torch.cuda.is_available():
             raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
@@ -163,8 +164,7 @@ class ConvMU(AsyncLossMixin):
         # With several shift axes (round 4) the same holds when taps and V extent of the LAST axis are multiples of 8: the tables
         # are those of every last-axis line of the zero-padded H (nmfmu_convnd_tables) and the k-chunk's share of the chunk
         # index comes from a small precomputed array (nmfmu_convnd_koff).
-        self.implicit = (T % 8 == 0 and L % 8 == 0 if nd == 1 else
-                         own_loop and self.ts[-1] % 8 == 0 and self.ls[-1] % 8 == 0)
+        self.implicit = (T % 8 == 0 and L % 8 == 0 if nd == 1 else self.ts[-1] % 8 == 0 and self.ls[-1] % 8 == 0)
         self.implicit = self.implicit and os.environ.get('TORCHNMF_AMD_NMFD_EXPLICIT', '0') != '1'
         self.koff = {}
         if self.implicit and nd > 1:
@@ -227,7 +227,7 @@ class ConvMU(AsyncLossMixin):
         # A operand are shifted rows of the ratio planes the H half-step has just written, so nothing is unfolded or folded
         # (Y is 4 R T B L bytes: 537 MB for a 256 x 512 frame with 8 x 16 taps).  Any number of shift axes, no alignment
         # rules.  The fold-parts path above stays where it applies (1-D, >= 128 taps: it multiplies no padding of the rank).
-        self.h_rows = (own_loop and T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 31 and
+        self.h_rows = (T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 31 and
                        os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
         if self.precision == _capi.PREC_F16 and not (self.fold_parts or self.h_rows):
             raise ValueError("precision 'f16': this shape takes neither the fold-parts nor the window-operand path for the H "

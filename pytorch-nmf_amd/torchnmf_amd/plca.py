@@ -322,7 +322,7 @@ class _ConvPlcaEM:
 
     def divergence(self) -> float:
         e = self.eng
-        e._gemm(self.wm_s, e.hu, _capi.EPI_LOSS, x=e.x_w, out=e.loss_part, m_valid=e.C, n_valid=e.B * e.L)
+        e._gemm(self.wm_s, e.hu, _capi.EPI_LOSS, x=e.x_w, out=e.loss_part, m_valid=e.C, n_valid=e.B * e.L, m_rows=e.c_rows)
         return float(e.loss_part.double().sum().item())
 
     def _plca3(self, mode, f, outer, inner, num, pitch, vec, alpha, update, want_zg):
@@ -347,12 +347,21 @@ class _ConvPlcaEM:
     def em_step(self, tW, tH, tZ, W_alpha, H_alpha, Z_alpha):
         e = self.eng
         # one reconstruction (twice, once per output layout) feeds every update of the iteration
-        e._gemm(self.wm_s, e.hu, _capi.EPI_RATIO, x=e.x_w, gn=e.gn)            # Gn [c][(b,l)]
-        e._gemm(e.gn, e.hut, _capi.EPI_F32, out=e.num_w)                        # (G^T H) [c][(r,t)], unscaled
-        e._gemm(e.hu, self.wm_s, _capi.EPI_RATIO, x=e.x_h, gn=e.gnt)           # Gn [(b,l)][c]
-        e._gemm(e.wmt, e.gnt, _capi.EPI_F32, out=e.y)                           # Y [(r,t)][(b,l)] from the unscaled W
-        _capi.check(self.lib.nmfmu_convnd_fold(self.numh.data_ptr(), e.B, e.R, e.nd, e._lh_arr, e._t_arr, e.y.data_ptr(),
-                                               e.bl_pad, self._s()), 'nmfmu_convnd_fold')
+        e._gemm(self.wm_s, e.hu, _capi.EPI_RATIO, x=e.x_w, gn=e.gn, m_rows=e.c_rows)       # Gn [c][(b,l)]
+        e._gemm(e.gn, e.hut, _capi.EPI_F32, out=e.num_w, k_split=e.w_ksplit, m_rows=e.c_rows)   # (G^T H) [c][(r,t)], unscaled
+        if e.w_ksplit > 1:                                                      # split-K partials -> slab 0
+            _capi.check(self.lib.nmfmu_slab_sum(e.num_w.data_ptr(), (e.c_rows or e.c_pad) * e.rp_pad, e.w_ksplit, self._s()),
+                        'nmfmu_slab_sum')
+        e._gemm(e.hu, self.wm_s, _capi.EPI_RATIO, x=e.x_h, gn=e.gnt, n_rows=e.c_rows)       # Gn [(b,l)][c]
+        if e.h_rows:
+            # (G W) without the unfolded Y: the window-operand GEMM over shifted rows of Gn^T with the unscaled W
+            e._gemm_win(e.gnt, e.hnum)
+            _capi.check(self.lib.nmfmu_conv_rows_fold(self.numh.data_ptr(), e.B, e.R, e.Lh // e.lhs[-1], e.lhs[-1], e.wk_fold,
+                                                      e.hnum.data_ptr(), e.wk_rows, self._s()), 'nmfmu_conv_rows_fold')
+        else:
+            e._gemm(e.wmt, e.gnt, _capi.EPI_F32, out=e.y)                       # Y [(r,t)][(b,l)] from the unscaled W
+            _capi.check(self.lib.nmfmu_convnd_fold(self.numh.data_ptr(), e.B, e.R, e.nd, e._lh_arr, e._t_arr, e.y.data_ptr(),
+                                                   e.bl_pad, self._s()), 'nmfmu_convnd_fold')
         z_old = self.Z.clone()
         # Z.grad = sum W * (G^T H): the em pass over W with update = 0
         self._plca3(0, self.W, e.C, e.T, e.num_w, e.rp_pad, z_old, 1.0, False, True)

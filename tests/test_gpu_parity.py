@@ -1769,6 +1769,33 @@ def test_siplca_implicit_operands_against_oracle(dev):
         assert rel_err(p.data.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize('cls,shape', [('SIPLCA2', (2, 6, (12, 24), 3, (3, 8))), ('SIPLCA3', (1, 70, (5, 6, 16), 2, (2, 2, 8))),
+                                       ('SIPLCA2', (1, 5, (9, 11), 4, (2, 3)))])
+def test_siplca_several_shift_axes_on_window_tables_against_oracle(dev, cls, shape, monkeypatch):
+    """SIPLCA2 / SIPLCA3 (plca.py:452-606): with taps and frames of the last axis multiples of 8 the EM step's GEMMs take
+    their H operands from the window tables of nmfmu_convnd_tables; (G W) comes from the window-operand GEMM over shifted
+    rows of the ratio planes (no Y, no fold); the (G^T H) GEMM is contraction-split.  Against the oracle, and the third
+    shape (unaligned) on explicit operands against the store-then-fold path."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd import plca
+    B, Cc, ls, R, ks = shape
+    g = torch.Generator().manual_seed(sum(ls) + R)
+    V = torch.rand(B, Cc, *ls, generator=g)
+    W0, H0 = torch.rand(Cc, R, *ks, generator=g), torch.rand(B, R, *[l - k + 1 for l, k in zip(ls, ks)], generator=g)
+    Z0 = torch.rand(R, generator=g)
+    Wr, Hr, Zr, nr, _, _ = O.plca_fit(V, W0, H0, Z0, tol=NO_STOP, max_iter=4, W_alpha=1.001)
+    res = {}
+    for rows in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_NMFD_H_ROWS', rows)
+        m = getattr(plca, cls)(W=W0, H=H0, Z=Z0).to(dev)
+        n, _ = m.fit(V.to(dev), tol=NO_STOP, max_iter=4, W_alpha=1.001)
+        assert n == nr
+        for p, ref in ((m.W, Wr), (m.H, Hr), (m.Z, Zr)):
+            assert rel_err(p.data.cpu(), ref) < TOL
+        res[rows] = m.H.data.cpu()
+    assert rel_err(res['1'], res['0']) < 2e-5
+
+
 @pytest.mark.parametrize('rank', [129, 200])
 def test_auto_precision_meets_the_parity_bar_above_rank_128(dev, rank):
     from oracle import mu_oracle as O
