@@ -446,7 +446,8 @@ def nmfd_line(a, sub=False):
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(ach / peak, 4), 'traffic': None,
                      'kernel': 'nmfmu::nt_gemm_kernel (mean over the GEMM launches of an iteration: reconstruction + ratio of both '
-                               'half-steps, W numerator, H numerator with the fold epilogue)',
+                               'half-steps, W numerator, H numerator ' + ('as the window-operand GEMM over shifted ratio rows)'
+                                                                          if getattr(eng, 'h_rows', False) else 'with the fold epilogue)'),
                      'avg_launch_ms': round(gemm_ms, 5), 'per_gemm': per_gemm,
                      'clock_mhz': tel.get('clock_mhz') if tel else None, 'power_w': tel.get('power_w') if tel else None,
                      'telemetry': tel,
