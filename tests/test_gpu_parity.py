@@ -1256,7 +1256,7 @@ def test_h_numerator_from_shifted_ratio_rows(dev, shape, beta, monkeypatch):
     (1, 130, (9, 32), 3, (4, 16)),           # R * T = 192: k padding inside the last k-tile pair
     (2, 9, (6, 7, 16), 4, (2, 3, 8)),        # three shift axes
 ])
-@pytest.mark.parametrize('beta', [1, 0.5])
+@pytest.mark.parametrize('beta', [1, 0.5, 2, 0])
 def test_implicit_operands_with_several_shift_axes(dev, shape, beta, monkeypatch):
     """NMF2D / NMF3D with taps and frames of the last axis multiples of 8: the GEMMs fetch Hu / HuT from the window
     tables of nmfmu_convnd_tables (no unfold kernel, no T-times-H planes).  Same products as the explicit operands:
