@@ -410,7 +410,9 @@ int nmfmu_conv_unfold(const float* h, int batch, int rank, int lh, int taps, voi
  * part: rank * 128 floats of scratch (deterministic two-stage sum). */
 int nmfmu_rank_sums(const float* src, int outer, int rank, int inner, float* part, float* out, void* stream);
 
-/* nmf.py:78-92 for W (channels, rank, taps) in place; num/den fp32 [c_pad][rp_pad]; kl_den[rank] or den. */
+/* nmf.py:78-92 for W (channels, rank, taps) in place; num/den fp32 [c_pad][rp_pad]; kl_den[rank] or den.
+ * (This entry and nmfmu_conv_apply_pack_w below are the un-fused forms: kept for bindings written against earlier ABI
+ * versions; the Python host calls nmfmu_conv_apply_pack_w_sums, whose optional operands make it a superset.) */
 int nmfmu_conv_apply_w(float* w, int channels, int rank, int taps, const float* num, const float* den,
                        const float* kl_den, int rp_pad, float l1, float l2, float gamma, void* stream);
 
