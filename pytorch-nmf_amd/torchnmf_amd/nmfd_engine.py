@@ -73,6 +73,20 @@ def tail_round_split(mt: int, nt: int, slots: int, k_tiles: int, want: str = '1'
     return rows, split
 
 
+def w_contraction_split(tiles: int, k_tiles: int, slots: int) -> int:
+    """Split of the W-numerator GEMM's contraction (round 4, the general form): few output tiles and a very long contraction
+    (NMF2D: 8 tiles x 2 048 k-tiles) -- as many parts as fill the workgroup slots, at most 64, each at least eight k-tiles,
+    dividing the k-tiles evenly (nmfmu_gemm wants k_tiles % k_split == 0)."""
+    want = min(64, slots // max(tiles, 1), k_tiles // 8)
+    return max([s for s in range(1, max(want, 1) + 1) if k_tiles % s == 0])
+
+
+def h_tap_fold(rank: int, taps_last: int) -> int:
+    """Taps of the last axis folded into the 32-wide N tile of the window-operand GEMM (nmfmu_gemm_desc.win_fold): the
+    largest F in {4, 2} with rank * F <= 32 that divides the taps of the last axis, else 1."""
+    return max([f for f in (4, 2) if rank * f <= 32 and taps_last % f == 0] + [1])
+
+
 class ConvMU(AsyncLossMixin):
     """Engine for ``NMFD.fit``: V (B, C, L), W (C, R, T), H (B, R, L-T+1); W / H updated in place."""
 
@@ -237,7 +251,7 @@ class ConvMU(AsyncLossMixin):
             self.wk_rows = 32 if R <= 32 else 64 if R <= 64 else pad(R)
             # a small rank would leave most of the 32-wide N tile as padding: F consecutive last-axis taps share a k position
             # and take F columns each (nmfmu_gemm_desc.win_fold) -- 1 / F of the MFMA work and of the operand traffic
-            self.wk_fold = max([f for f in (4, 2) if R * f <= 32 and self.ts[-1] % f == 0] + [1])
+            self.wk_fold = h_tap_fold(R, self.ts[-1])
             if os.environ.get('TORCHNMF_AMD_NMFD_H_FOLD', '1') == '0':
                 self.wk_fold = 1
             self.wk_klen = (T // self.wk_fold) * (-(-Cc // 64)) * 64
@@ -278,12 +292,8 @@ class ConvMU(AsyncLossMixin):
             if self.fused_sums:
                 self.w_ksplit = 2 if (tiles <= 256 and (blp // 64) % 2 == 0 and blp >= 2048) else 1
             else:
-                # the general form (round 4): few tiles and a very long contraction (NMF2D: 8 tiles x 2 048 k-tiles) -- as many
-                # parts as fill the workgroup slots, each at least eight k-tiles, dividing the k-tiles evenly
                 slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
-                kt = blp // 64
-                want = min(64, slots // tiles, kt // 8)
-                self.w_ksplit = max([s_ for s_ in range(1, max(want, 1) + 1) if kt % s_ == 0])
+                self.w_ksplit = w_contraction_split(tiles, blp // 64, slots)
         self.num_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
         if self.den_w is not None:
             self.den_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)

@@ -575,3 +575,20 @@ def test_window_tables_with_several_shift_axes(B, R, lhs, ts):
     bad = np.zeros(32, np.int32)
     assert lib.nmfmu_convnd_koff(_capi.OPS_B_HU, 1, 1, 2, (C.c_int32 * 2)(4, 5), (C.c_int32 * 2)(2, 4), 128, bad.ctypes.data) == _capi.ERR_ARG
     assert lib.nmfmu_convnd_koff(_capi.OPS_PLANES, 1, 1, 1, (C.c_int32 * 1)(9), (C.c_int32 * 1)(8), 128, bad.ctypes.data) == _capi.ERR_ARG
+
+
+def test_convolutive_host_rules_of_round_4():
+    """nmfd_engine.w_contraction_split / h_tap_fold: the split of the W-numerator GEMM's contraction and the tap fold of the
+    window-operand GEMM (pure host rules; the kernels take whatever they say)."""
+    from torchnmf_amd.nmfd_engine import h_tap_fold, w_contraction_split
+    # NMF2D bench shape: 8 tiles, 2 048 k-tiles, 512 slots -> 64 parts of 32 k-tiles
+    assert w_contraction_split(8, 2048, 512) == 64
+    assert w_contraction_split(225, 128, 512) == 2            # configs[3]-like: two parts fill the second slot
+    assert w_contraction_split(600, 4096, 512) == 1           # more tiles than slots: no split
+    assert w_contraction_split(1, 20, 512) == 2               # at least eight k-tiles per part
+    assert w_contraction_split(4, 7 * 11, 512) in (1, 7)      # must divide the k-tiles
+    for tiles, kt in ((1, 2), (3, 1000), (17, 4096), (500, 64)):
+        s = w_contraction_split(tiles, kt, 512)
+        assert 1 <= s <= 64 and kt % s == 0 and (s == 1 or (kt // s >= 8 and tiles * s <= 512))
+    assert h_tap_fold(8, 16) == 4 and h_tap_fold(5, 8) == 4 and h_tap_fold(7, 30) == 2 and h_tap_fold(16, 16) == 2
+    assert h_tap_fold(8, 3) == 1 and h_tap_fold(17, 16) == 1 and h_tap_fold(40, 8) == 1 and h_tap_fold(9, 6) == 2
