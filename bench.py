@@ -395,8 +395,8 @@ def nmfd_line(a, sub=False):
     eng.timer = None
     tel = SmiSampler(0).under_load(step, a.telemetry_s) if a.telemetry_s > 0 else None
     fit_obj = None
-    if a.workload == 'nmfd' and beta == 1:      # what the user calls: NMFD.fit end to end (200 iterations, 20 loss checkpoints)
-        fit_obj = fit_leg(a, V, Wc, Hc, beta, a.precision, dev, ms, cls_name='NMFD')
+    if beta == 1:      # what the user calls: NMFD.fit / NMF2D.fit end to end (200 iterations, 20 loss checkpoints)
+        fit_obj = fit_leg(a, V, Wc, Hc, beta, a.precision, dev, ms, cls_name='NMFD' if a.workload == 'nmfd' else 'NMF2D')
     gflop = 2.0 * Cc * L * R * T
     per_gemm = {k: {'avg_launch_ms': round(sum(v) / len(v), 5),
                     'frac': round(gflop / (sum(v) / len(v) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)} for k, v in spans.items()}
@@ -970,7 +970,7 @@ def main():
             na.cpu_iters = 0
         line = nmfd_line(na, sub=True)
         nmf2d = {k: line[k] for k in ('metric', 'value', 'unit', 'iters_per_s', 'ms_per_step', 'blocks_ms_per_step', 'dtype',
-                                      'roofline', 'parity', 'cpu_baseline')}
+                                      'roofline', 'parity', 'cpu_baseline', 'fit')}
 
     # ---- fit(): the call a torchnmf user makes, end to end; real_data_mode: a target fp16 does NOT hold exactly
     fit_obj, real = None, None

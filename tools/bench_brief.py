@@ -31,4 +31,4 @@ if d.get('nmfd'):
     print(f"  nmfd: {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {n.get('parity')}")
 if d.get('nmf2d'):
     n = d['nmf2d']
-    print(f"  nmf2d ({n['dtype']}): {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {(n.get('parity') or {}).get('modes')}")
+    print(f"  nmf2d ({n['dtype']}): {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {(n.get('parity') or {}).get('modes')}; fit loop {(n.get('fit') or {}).get('iters_per_s_loop')} it/s")
