@@ -1062,12 +1062,14 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
     if (geom.t[2] % 8 || geom.l[2] % 8) return NMFMU_ERR_ARG;
     a.tB = d->t_batch, a.tR = d->t_rank, a.tT = geom.t_tot, a.tLh = geom.lh_tot;
     a.koff = d->t_koff;
+    if (nmfmu_convnd_table_bytes(a.tB, a.tR, d->win_nd, d->win_lh, d->win_taps) >= ((size_t)1 << 31)) return NMFMU_ERR_ARG;   // 32-bit lane offsets
     const int64_t bl = (int64_t)a.tB * geom.l_tot, rt = (int64_t)a.tR * geom.t_tot;
     const int hu_rows = d->ops == NMFMU_OPS_A_HU ? d->m_pad : d->n_pad;
     if (d->ops == NMFMU_OPS_B_HUT ? (hu_rows < rt || d->k_pad < bl) : (hu_rows < bl || d->k_pad < rt)) return NMFMU_ERR_ARG;
   } else if (d->ops != NMFMU_OPS_PLANES) {
     a.tB = d->t_batch, a.tR = d->t_rank, a.tT = d->t_taps, a.tLh = d->t_lh;
     if (a.tB <= 0 || a.tR <= 0 || a.tT <= 0 || a.tLh <= 0 || a.tT % 8 || (a.tLh + a.tT - 1) % 8) return NMFMU_ERR_ARG;
+    if (nmfmu_conv_table_bytes(a.tB, a.tR, a.tLh, a.tT) >= ((size_t)1 << 31)) return NMFMU_ERR_ARG;   // 32-bit lane offsets
     const int64_t bl = (int64_t)a.tB * (a.tLh + a.tT - 1), rt = (int64_t)a.tR * a.tT;   // logical extents of Hu
     const int hu_rows = d->ops == NMFMU_OPS_A_HU ? d->m_pad : d->n_pad;
     if (d->ops == NMFMU_OPS_B_HUT ? (hu_rows < rt || d->k_pad < bl) : (hu_rows < bl || d->k_pad < rt)) return NMFMU_ERR_ARG;

@@ -183,7 +183,7 @@ class ConvMU(AsyncLossMixin):
         self.koff = {}
         if self.implicit and nd > 1:
             nb = self.lib.nmfmu_convnd_table_bytes(B, R, nd, self._lh_arr, self._t_arr)
-            self.implicit = 0 < nb // 16 < 2 ** 31
+            self.implicit = 0 < nb < 2 ** 31          # the GEMM lanes address the table with 32-bit byte offsets
         if self.implicit and nd > 1:
             for ops, kp in ((_capi.OPS_B_HU, rpp), (_capi.OPS_B_HUT, blp)):
                 host = torch.empty(kp // 8 + 8, dtype=torch.int32)
@@ -193,6 +193,10 @@ class ConvMU(AsyncLossMixin):
             self.koff[_capi.OPS_A_HU] = self.koff[_capi.OPS_B_HU]
             self.hu = _Table(blp, rpp, nb, x3, dev)
             self.hut = _Table(rpp, blp, nb, x3, dev)
+        elif self.implicit and self.lib.nmfmu_conv_table_bytes(B, R, Lh, T) >= 2 ** 31:
+            self.implicit = False                     # (32-bit byte offsets into the table: explicit planes beyond 2 GiB)
+            self.hu = _Planes(blp, rpp, x3, dev)
+            self.hut = _Planes(rpp, blp, x3, dev)
         elif self.implicit:
             nb = self.lib.nmfmu_conv_table_bytes(B, R, Lh, T)
             self.hu = _Table(blp, rpp, nb, x3, dev)     # reversed windows: rows (b,l), k = (r,t)
