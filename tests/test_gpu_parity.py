@@ -1193,6 +1193,24 @@ def test_nmf2d_default_fit_takes_fp16_operands(dev):
     assert ew < TOL and eh < TOL
 
 
+@pytest.mark.parametrize('cls,ls', [('NMF2D', (12, 10)), ('NMF3D', (5, 6, 7))])
+def test_convnd_default_kernel_size_one(dev, cls, ls):
+    """The reference's default kernel_size is 1 (nmf.py:838, 920; its own construct tests use it): the conv model is then
+    plain NMF over (batch x positions) -- one tap, no window-operand path, explicit operands."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd import nmf as anmf
+    g = torch.Generator().manual_seed(len(ls))
+    V = torch.rand(2, 5, *ls, generator=g) + 1e-3
+    m = getattr(anmf, cls)(V.shape, rank=4)
+    assert tuple(m.W.shape) == (5, 4) + (1,) * len(ls) and tuple(m.H.shape) == (2, 4) + ls
+    W0, H0 = m.W.data.clone(), m.H.data.clone()
+    m = m.to(dev)
+    n = m.fit(V.to(dev), beta=1, tol=NO_STOP, max_iter=10)
+    Wr, Hr, nr, _, _ = O.fit(V, W0, H0, 1, NO_STOP, 10, kind='convnd')
+    assert n == nr and rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+    assert tuple(m().shape) == tuple(V.shape)
+
+
 def test_nmfd_auto_warns_when_alignment_costs_the_fp16_mode(dev):
     """a spectrogram whose frame count is not a multiple of 8 cannot take the implicit operands, so
     'auto' runs split bf16 at 3x the matrix work -- the user is told."""
