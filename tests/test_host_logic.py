@@ -592,3 +592,52 @@ def test_convolutive_host_rules_of_round_4():
         assert 1 <= s <= 64 and kt % s == 0 and (s == 1 or (kt // s >= 8 and tiles * s <= 512))
     assert h_tap_fold(8, 16) == 4 and h_tap_fold(5, 8) == 4 and h_tap_fold(7, 30) == 2 and h_tap_fold(16, 16) == 2
     assert h_tap_fold(8, 3) == 1 and h_tap_fold(17, 16) == 1 and h_tap_fold(40, 8) == 1 and h_tap_fold(9, 6) == 2
+
+
+@pytest.mark.parametrize('B,Cc,R,lhs,ts,F', [(2, 5, 3, (4, 7), (2, 4), 4), (1, 3, 2, (6,), (6,), 2), (2, 4, 5, (3, 2, 5), (2, 2, 3), 1),
+                                              (1, 70, 8, (3, 9), (2, 8), 4)])
+def test_window_operand_gemm_contract(B, Cc, R, lhs, ts, F):
+    """The contract of NMFMU_OPS_A_WIN + win_fold as include/nmfmu.h states it, in numpy, against the oracle's conv
+    backward pass wrt H (nmf.py:857-860 through autograd; oracle._convnd_grad_h): rows of A are shifted rows of the ratio
+    plane P[(b,l)][c]; k = (t_outer, q, ck, c'); B = the nmfmu_conv_pack_wk layout; F taps of the last axis go to F
+    columns and the consumer adds out[(.., j + d)][r F + d] over d."""
+    from oracle import mu_oracle as O
+    nd = len(lhs)
+    ls = tuple(lh + t - 1 for lh, t in zip(lhs, ts))
+    rng = np.random.default_rng(11)
+    G = rng.random((B, Cc) + ls).astype(np.float64)                  # the ratio Gn[b][c][l]
+    W = rng.random((Cc, R) + ts).astype(np.float64)
+    H = np.zeros((B, R) + lhs)
+    want = O._convnd_grad_h(torch.from_numpy(G), torch.from_numpy(W), torch.from_numpy(H)).numpy()
+    L, T, CK = int(np.prod(ls)), int(np.prod(ts)), -(-Cc // 64)
+    P = np.zeros((B * L, CK * 64))                                    # [(b,l)][c], channel padding zero
+    P[:, :Cc] = np.moveaxis(G, 1, -1).reshape(B * L, Cc)
+    TQ, T_outer = ts[-1] // F, T // ts[-1]
+    # B operand: Wk[r F + d][((to TQ + q) CK + ck) 64 + c'] = W[c][r][to T_last + F q + d]
+    Wf = W.reshape(Cc, R, T)
+    Wk = np.zeros((R * F, T_outer * TQ * CK * 64))
+    for r in range(R):
+        for d in range(F):
+            for to in range(T_outer):
+                for q in range(TQ):
+                    k0 = (to * TQ + q) * CK * 64
+                    Wk[r * F + d, k0:k0 + Cc] = Wf[:, r, to * ts[-1] + F * q + d]
+    # A operand rows (b, jo, j'), j' < lh_last + F - 1; k-tile (to, q): row (b, jo + to, j' + F q) of P
+    lw = lhs[-1] + F - 1
+    outer = lhs[:-1]
+    rows = [(b,) + jo + (jp,) for b in range(B) for jo in np.ndindex(*outer) for jp in range(lw)]
+    out = np.zeros((len(rows), R * F))
+    for i, (b, *jo, jp) in enumerate(rows):
+        a_row = []
+        for to in np.ndindex(*ts[:-1]):
+            for q in range(TQ):
+                l = tuple(j + t for j, t in zip(jo, to)) + (jp + F * q,)
+                a_row.append(P[b * L + int(np.ravel_multi_index(l, ls))])
+        out[i] = Wk @ np.concatenate(a_row)
+    # the consumer (nmfmu_conv_apply_h_rows / nmfmu_conv_rows_fold)
+    out = out.reshape((B,) + outer + (lw, R * F))
+    got = np.zeros((B, R) + lhs)
+    for r in range(R):
+        for d in range(F):
+            got[:, r] += out[..., d:d + lhs[-1], r * F + d]
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
