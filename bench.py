@@ -91,7 +91,10 @@ def parse():
     ap.add_argument('--telemetry-s', type=float, default=0.8, help='seconds of back-to-back iterations (untimed, after the '
                     'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
                     'into roofline.clock_mhz / power_w (0 disables)')
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.precision == 'auto' and a.workload not in ('nmfd', 'nmf2d'):
+        ap.error("--precision auto: only for --workload nmfd / nmf2d (the dense workloads report 'auto' as real_data_mode)")
+    return a
 
 
 def pmc_traffic_key(key):
