@@ -1042,7 +1042,7 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   }
   if (d->ops == NMFMU_OPS_A_WIN) {
     // A[(b,j)][(t,c)] = P[(b, j + t)][c]: rows of the plane(s) a_hi / a_lo ([batch * prod(l)][win_pitch]) shifted by the tap
-    if (epilogue != NMFMU_EPI_F32 || a.k_split != 1) return NMFMU_ERR_ARG;
+    if (epilogue != NMFMU_EPI_F32) return NMFMU_ERR_ARG;      // (k_split > 1: partial slabs as for any EPI_F32 launch)
     if (d->win_pitch <= 0 || d->win_pitch % 64 || d->win_channels <= 0 || d->win_channels > d->win_pitch) return NMFMU_ERR_ARG;
     a.win_ck = (d->win_channels + 63) / 64;
     if (a.win_ck * 64 > d->win_pitch) return NMFMU_ERR_ARG;

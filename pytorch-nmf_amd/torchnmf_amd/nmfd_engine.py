@@ -261,8 +261,15 @@ class ConvMU(AsyncLossMixin):
             self.wk_klen = (T // self.wk_fold) * (-(-Cc // 64)) * 64
             self.wk = _Planes(self.wk_rows, pad(self.wk_klen), x3, dev)         # W as [(r, d)][(to, q, c)]
             self.hj_pad = pad(B * (Lh // self.lhs[-1]) * (self.lhs[-1] + self.wk_fold - 1))
-            self.hnum = torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
-            self.hden = None if self.kl else torch.empty(self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
+            # few positions and a long (t, c) contraction (a short spectrogram with many bins): split the contraction over the
+            # idle workgroup slots, nmfmu_slab_sum adds the partials
+            self.h_ksplit = 1
+            if os.environ.get('TORCHNMF_AMD_NMFD_KSPLIT', '1') != '0':
+                slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+                self.h_ksplit = w_contraction_split((self.hj_pad // 128) * -(-self.wk_rows // 128), self.wk_klen // 64, slots)
+            self.hnum = torch.empty(self.h_ksplit * self.hj_pad * self.wk_rows, dtype=torch.float32, device=dev)
+            self.hden = None if self.kl else torch.empty(self.h_ksplit * self.hj_pad * self.wk_rows, dtype=torch.float32,
+                                                         device=dev)
         else:
             ny = (self.lib.nmfmu_fold_part_bytes(rpp, blp) // 4) * self.h_tail_split if self.fold_parts else rpp * blp
             self.y = torch.empty(ny, dtype=torch.float32, device=dev)
@@ -344,7 +351,7 @@ class ConvMU(AsyncLossMixin):
         """H numerator (or denominator) as the window-operand GEMM: out[(b,j)][r] from the ratio planes [(b,l)][c]."""
         d = _capi.GemmDesc(_ptr(planes.hi), _ptr(planes.lo), _ptr(self.wk.hi), _ptr(self.wk.lo), self.hj_pad, self.wk_rows,
                            self.wk.cols_pad, self.precision, self.beta, None, None, None, None, None, _ptr(out), 0, 0,
-                           _capi.OPS_A_WIN, self.B, self.R, self.T, self.Lh, 128, 0, self.wk_klen, 0, 0, 0, 0,
+                           _capi.OPS_A_WIN, self.B, self.R, self.T, self.Lh, 128, 0, self.wk_klen, self.h_ksplit, 0, 0, 0,
                            self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts), self.C, planes.cols_pad,
                            self.wk_fold)
         timer = getattr(self, 'timer', None) if tag else None
@@ -353,6 +360,9 @@ class ConvMU(AsyncLossMixin):
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), _capi.EPI_F32, _stream()), 'nmfmu_gemm')
         if timer is not None:
             timer.mark(tag + '>')
+        if self.h_ksplit > 1:
+            _capi.check(self.lib.nmfmu_slab_sum(out.data_ptr(), self.hj_pad * self.wk_rows, self.h_ksplit, _stream()),
+                        'nmfmu_slab_sum')
 
     def _ragged(self, mode, x, gn=None, gp=None):
         """The channels the reconstruction GEMM left out (mode 0: W half-step planes, 1: H half-step planes, 2: loss)."""
