@@ -504,27 +504,34 @@ class DenseMU(AsyncLossMixin):
             # [numerator | denominator (N x R for beta != 1, else R column sums)] -> ONE all-reduce per iteration
             tail = self.r_pad if self.kl else self.step_h.plane
             self.xbuf = torch.empty(self.step_h.plane + tail, dtype=torch.float32, device=dev)
-            # overlap: the H half-step as two row halves -- the first half's numerators are on the wire while the second
-            # half's kernel runs (TORCHNMF_AMD_AR_OVERLAP=0 or fit(..., allreduce='single'): one launch, ONE all-reduce of
-            # the packed buffer per iteration -- the form north_star names).  The split point
+            # default (fit(..., allreduce='single') / TORCHNMF_AMD_AR_OVERLAP=0): one launch, ONE all-reduce of the packed
+            # buffer per iteration -- the form north_star names.  'overlap' (TORCHNMF_AMD_AR_OVERLAP=1): the H half-step as
+            # two row halves -- the first half's numerators are on the wire while the second half's kernel runs.  The split point
             # defaults to the middle row block; TORCHNMF_AMD_AR_SPLIT=<fraction of the rows in the first part> moves it
             # (to be swept on a multi-GPU node: the first part's all-reduce should just fit behind the second part's kernel)
             # 'direct' (fit(..., allreduce='direct') / TORCHNMF_AMD_COMM=c): the whole sharded H half-step is ONE C call --
             # partial sums, slab reduction, a single RCCL all-reduce on the compute stream (the library's own communicator,
             # bootstrapped over the torch group) and the apply; no return to Python between kernel and collective
+            explicit_direct = bool(ar_direct)
             if ar_direct is None:
                 ar_direct = os.environ.get('TORCHNMF_AMD_COMM', 'torch') == 'c'
             self._comm = None
             if ar_direct and hasattr(self.be, 'comm_init'):
                 self._comm = self.be.comm_init(group, dev)
                 ar_overlap = False
+            elif explicit_direct:
+                # (this used to fall back to the torch.distributed route without a word)
+                raise _capi.NmfmuError("allreduce='direct' needs the library's own RCCL communicator (nmfmu_comm_*), which "
+                                       f"the {getattr(self.be, 'name', type(self.be).__name__)} backend does not provide")
             st = self.step_h
             nblk = st.owner.rows_pad // 256
             frac = float(os.environ.get('TORCHNMF_AMD_AR_SPLIT', '0.5'))
             r0 = min(max(int(frac * nblk + 1e-9), 1), max(nblk - 1, 1)) * 256
             self._h_rows = None
             if ar_overlap is None:
-                ar_overlap = os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '1') != '0'
+                # default: ONE all-reduce of the packed buffer per iteration -- what north_star specifies; the two-collective
+                # overlap stays opt-in until an N > 1 run shows it wins
+                ar_overlap = os.environ.get('TORCHNMF_AMD_AR_OVERLAP', '0') != '0'
             if (ar_overlap and nblk >= 2 and st.owner.rows > r0
                     and hasattr(self.be, 'xp_rows')):
                 k_pad = st.panel.rows_pad

@@ -102,7 +102,7 @@ class BaseComponent(nn.Module):
     def reconstruct(H: Tensor, W: Tensor) -> Tensor:
         raise NotImplementedError
 
-    def _make_engine(self, V, beta, l1, l2, precision, group):
+    def _make_engine(self, V, beta, l1, l2, precision, group, allreduce=None):
         raise NotImplementedError
 
     def sparse_fit(self, *args, **kwargs):
@@ -142,7 +142,9 @@ class BaseComponent(nn.Module):
                          behind the second half's kernel (two collectives); 'direct' = 'single' with the whole half-step
                          (kernel, slab reduction, RCCL all-reduce, apply) enqueued by ONE C call on the compute stream
                          through the library's own communicator (nmfmu_mu_step_allreduce) instead of torch.distributed;
-                         None = TORCHNMF_AMD_AR_OVERLAP / TORCHNMF_AMD_COMM (default: overlap over torch.distributed).
+                         None = TORCHNMF_AMD_AR_OVERLAP / TORCHNMF_AMD_COMM; default 'single' over torch.distributed, the
+                         form BASELINE's north_star names (round 5: 'overlap' was the default before, with no N > 1
+                         measurement behind it).  'direct' raises when the backend has no communicator entry.
         """
         sparse = V.is_sparse
         if sparse and not isinstance(self, NMF):
@@ -171,9 +173,12 @@ class BaseComponent(nn.Module):
         else:
             if allreduce not in (None, 'single', 'overlap', 'direct'):
                 raise ValueError(f"allreduce must be None, 'single', 'overlap' or 'direct', got {allreduce!r}")
-            self._ar_overlap = None if allreduce is None else allreduce == 'overlap'
-            self._ar_direct = None if allreduce is None else allreduce == 'direct'
-            eng = self._make_engine(V, beta, l1, l2, precision, process_group)
+            if allreduce is not None and (process_group is None or not isinstance(self, NMF)):
+                # (the choice used to be ignored silently here)
+                import warnings
+                warnings.warn(f"torchnmf_amd: allreduce={allreduce!r} only applies to a column-sharded NMF.fit "
+                              "(process_group=...); ignored", stacklevel=2)
+            eng = self._make_engine(V, beta, l1, l2, precision, process_group, allreduce)
         self.last_precision = getattr(eng, 'precision_name', None)   # what 'auto' resolved to (plain attribute, not state)
 
         has_bad, has_zero = eng.target_flags()   # nmf.py:329-336, computed during packing
@@ -289,7 +294,7 @@ class NMF(BaseComponent):
                     'nmfmu_reconstruct')
         return out.reshape(lead + (Wc.shape[0],))
 
-    def _make_engine(self, V, beta, l1, l2, precision, group):
+    def _make_engine(self, V, beta, l1, l2, precision, group, allreduce=None):
         from .engine import DenseMU
         assert V.dim() == 2 and V.shape == (self.H.shape[0], self.W.shape[0]), \
             f'V must be {(self.H.shape[0], self.W.shape[0])}, got {tuple(V.shape)}'
@@ -328,8 +333,8 @@ class NMF(BaseComponent):
                               update_W=self.W.requires_grad, update_H=self.H.requires_grad)
         return DenseMU(V, self.W.data, self.H.data, beta, l1, l2, precision=precision, group=group,
                        update_W=self.W.requires_grad, update_H=self.H.requires_grad, allow_f16=True,
-                       ar_overlap=getattr(self, '_ar_overlap', None), allow_gram=True,
-                       ar_direct=getattr(self, '_ar_direct', None))
+                       ar_overlap=None if allreduce is None else allreduce == 'overlap', allow_gram=True,
+                       ar_direct=None if allreduce is None else allreduce == 'direct')
 
 
 class NMFD(BaseComponent):
@@ -350,7 +355,7 @@ class NMFD(BaseComponent):
         from .nmfd_engine import reconstruct as _recon
         return _recon(H, W)
 
-    def _make_engine(self, V, beta, l1, l2, precision, group):
+    def _make_engine(self, V, beta, l1, l2, precision, group, allreduce=None):
         from .nmfd_engine import ConvMU
         if group is not None:
             raise NotImplementedError('NMFD is not sharded (replicas only): sharding L needs a (T-1)-column halo')

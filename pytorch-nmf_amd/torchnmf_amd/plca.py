@@ -44,6 +44,21 @@ def _new(spec, trainable, label):
     return p
 
 
+def _scalar_alpha(a, name: str, factor: Tensor) -> float:
+    """A Dirichlet hyper-parameter as the reference's EM loop can use it (plca.py:257-259, 271-273, 285-287): a number,
+    or a tensor with exactly one element and no more dimensions than the factor it is added to in place."""
+    if isinstance(a, Tensor):
+        if a.numel() != 1:
+            raise RuntimeError(f'Boolean value of Tensor with more than one value is ambiguous ({name} has '
+                               f'{a.numel()} elements; the reference evaluates `if {name} != 1`, plca.py:257-285)')
+        if a.dim() > factor.dim():
+            raise RuntimeError(f"output with shape {list(factor.shape)} doesn't match the broadcast shape "
+                               f"{[1] * (a.dim() - factor.dim()) + list(factor.shape)} ({name} has more dimensions than the "
+                               f"factor the reference adds it to in place)")
+        return float(a.detach().reshape(()).item())
+    return float(a)
+
+
 class BaseComponent(nn.Module):
     """Base of the PLCA modules (plca.py:38-191): W, H normalised over everything but the rank axis, Z a distribution."""
 
@@ -110,14 +125,19 @@ class BaseComponent(nn.Module):
     @torch.no_grad()
     def fit(self, V, tol=1e-4, max_iter=200, verbose=False, W_alpha=1., H_alpha=1., Z_alpha=1., *, precision=None):
         """EM fit (plca.py:193-304).  Returns ``(n_iter, norm)`` like the reference: the index of the last iteration and
-        ``V.sum()``.  Scalar Dirichlet hyper-parameters only."""
+        ``V.sum()``.  ``W_alpha`` / ``H_alpha`` / ``Z_alpha``: floats or one-element tensors (what the reference's
+        ``if alpha != 1`` admits); a tensor with more elements raises the same RuntimeError as there."""
         W, H, Z = self.W, self.H, self.Z
         assert W is not None and H is not None and Z is not None
+        # Dirichlet hyper-parameters (plca.py:197-199 types them Union[float, Tensor]).  The reference tests them with
+        # ``if W_alpha != 1:`` (plca.py:257, 271, 285), so a tensor works there exactly when it has ONE element -- a 0-dim
+        # or 1-element tensor, possibly on another device -- and raises "Boolean value of Tensor with more than one value
+        # is ambiguous" otherwise.  Same contract here: one-element tensors are taken by value, anything larger raises
+        # the RuntimeError the reference's ``if`` raises.
+        W_alpha, H_alpha, Z_alpha = (_scalar_alpha(a, n, f) for a, n, f in ((W_alpha, 'W_alpha', W), (H_alpha, 'H_alpha', H),
+                                                                            (Z_alpha, 'Z_alpha', Z)))
         for t_, what in ((V, 'fit'), (W, 'fit'), (H, 'fit'), (Z, 'fit')):
             _require_device(t_, what)
-        for a in (W_alpha, H_alpha, Z_alpha):
-            if isinstance(a, Tensor):
-                raise NotImplementedError('tensor-valued Dirichlet hyper-parameters are not implemented')
         V = V.detach().float()
         assert bool(torch.all(V >= 0.)), "Target should be non-negative."
         norm = V.sum()
@@ -160,8 +180,21 @@ class _PlcaEM:
         R = W.shape[1]
         self.R, self.r_pad = R, self.be.pad_rank(R)
         if precision in (None, 'auto'):
+            # 'auto' = the fp32-grade split mode.  The single-plane fp16 modes NMF.fit's 'auto' takes are not admissible here
+            # BY CONSTRUCTION: the factors are probability tables (columns of W sum to one: mean 1 / C, far below
+            # DenseMU.F16_MIN_MEAN at any size where the contraction is long enough for fp16), W * Z sits in fp16's
+            # subnormals, and with a reconstruction of order 1 / (N C) the eps of plca.py:250 dominates the ratio's
+            # denominator -- a power-of-two rescaling of the images would move eps and is not exact.
             precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
+        if precision not in _capi.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
+        if precision == 'f16x':
+            # (the EM steps use the split-panel instance kModeMU2, which exists for 'bf16' and 'f16')
+            raise NotImplementedError("precision 'f16x' is not built for PLCA (its split-panel kernel exists for 'bf16x3' up "
+                                      "to rank 128, 'bf16' and 'f16'); the target is normalised to sum 1 here, so 'f16' "
+                                      "would flush it to zero as well -- use 'bf16x3' (the default) or 'bf16'")
         self.prec = _capi.PRECISIONS[precision]
+        self.precision_name = precision
         if not self.be.supported(self.r_pad, self.prec):
             raise NotImplementedError(f'precision {precision!r} is not available for rank {R}')
         dev = Vn.device

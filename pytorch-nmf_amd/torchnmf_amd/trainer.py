@@ -57,7 +57,8 @@ class BetaMu(Optimizer):
         defaults = dict(beta=beta, l1_reg=l1_reg, l2_reg=l2_reg, orthogonal=orthogonal)
         super().__init__(params, defaults)
         self._precision = precision
-        self._engines: Dict[Tuple, Tuple[DenseMU, list]] = {}
+        self.last_precision = None                  # the operand mode of the last fused binding ('chain': exact chain path)
+        self._engines: Dict[Tuple, Tuple] = {}      # key -> (DenseMU | None, versions, target)
 
     # ------------------------------------------------------------------
     @staticmethod
@@ -97,6 +98,8 @@ class BetaMu(Optimizer):
         versions = [V_user._version, W._version, H._version]
         if hit is not None and hit[2] is V_user and (converted or hit[1][0] == versions[0]):
             eng, seen, _ = hit
+            if eng is None:                            # rank 129..256 without a parity-grade fused mode: chain path
+                return None
             if converted:                              # same buffers, fresh contents: pack + validate, nothing else
                 eng.repack_target(V)
                 bad, _ = eng.target_flags()
@@ -109,7 +112,21 @@ class BetaMu(Optimizer):
         # other hyper-parameter sets stay
         for k in [k for k, v in self._engines.items() if v[2] is not V_user or k[2:4] != key[2:4]]:
             del self._engines[k]
-        eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=self._precision)
+        # precision='auto' resolves like NMF.fit's (one admission test, DenseMU.auto_single_plane): a single-plane fp16 mode
+        # at 1x MFMA work where it meets the 1e-4 bar -- 'f16' for an fp16-exact target, 'f16x' otherwise -- else split
+        # bf16 (rank <= 128).  Rank 129..256 without an admissible fp16 mode has no parity-grade fused mode: the binding is
+        # remembered as None and step() takes the exact chain path.
+        precision = self._precision
+        if precision in (None, 'auto') and W.shape[1] > 128:
+            from .engine import DEFAULT_BACKEND_FACTORY
+            be = DEFAULT_BACKEND_FACTORY()
+            precision = DenseMU.auto_single_plane(V, W.data, H.data, be.pad_rank(W.shape[1]), be)
+            if precision is None:
+                self._engines[key] = (None, versions, V_user)
+                self.last_precision = 'chain'
+                return None
+        eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=precision, allow_f16=True)
+        self.last_precision = eng.precision_name       # what 'auto' resolved to (plain attribute, like NMF.last_precision)
         bad, _ = eng.target_flags()
         assert not bad, "Target should be non-negative."
         self._engines[key] = (eng, versions, V_user)
@@ -184,16 +201,18 @@ class BetaMu(Optimizer):
                     if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
                         p.grad = torch.empty_like(p.data)
                     # One layer runs on the fused kernels -- unless 'auto' has no parity-grade mode there: rank 129..256
-                    # (split bf16 stops at rank 128, the fp16 modes are not admitted here) and anything wider than the
-                    # kernels' 256 take the exact chain path below, which has no rank limit (the reference's
-                    # BetaMu has none either, trainer.py:72-112).
+                    # where the fp16 modes are not admissible (split bf16 stops at rank 128; _engine then answers None)
+                    # and anything wider than the kernels' 256 take the exact chain path below, which has no rank limit
+                    # (the reference's BetaMu has none either, trainer.py:72-112).
                     rank1 = Ws[0].shape[1] if len(Ws) == 1 else 0
-                    fused_ok = len(Ws) == 1 and (rank1 <= 128 or (rank1 <= 256 and self._precision not in (None, 'auto', 'bf16x3')))
+                    fused_ok = len(Ws) == 1 and (rank1 <= 128 or (rank1 <= 256 and self._precision != 'bf16x3'))
+                    eng = None
                     if fused_ok:
                         H, W = X0, Ws[0]
                         assert V.dim() == 2 and V.shape == (H.shape[0], W.shape[0]), \
                             f'target must be {(H.shape[0], W.shape[0])}, got {tuple(V.shape)}'
                         eng = self._engine(V_user, V, converted, H, W, beta, l1, l2)
+                    if eng is not None:
                         eng.trainer_step('W' if p is W else 'H', ortho, p.grad)
                     else:
                         self._chain_step(V, X0, Ws, p, beta, l1, l2, ortho)

@@ -86,7 +86,10 @@ def _worker_rows(rank, world, port, beta, overlap, out_dir, split=None):
             sys.path.insert(0, p)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
+    if overlap == 'default':        # nothing chosen: the engine's own default must be north_star's single all-reduce
+        os.environ.pop('TORCHNMF_AMD_AR_OVERLAP', None)
+    else:
+        os.environ['TORCHNMF_AMD_AR_OVERLAP'] = overlap
     if split is not None:
         os.environ['TORCHNMF_AMD_AR_SPLIT'] = split
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -135,7 +138,7 @@ def _tall_problem(beta):
 
 
 @pytest.mark.parametrize('beta', [1, 2])
-@pytest.mark.parametrize('overlap', ['1', '0'])
+@pytest.mark.parametrize('overlap', ['1', '0', 'default'])
 def test_sharded_h_step_in_row_halves_world2(tmp_path, beta, overlap):
     """The overlapped form of the sharded H half-step: two row halves, the first half's numerators all-reduced
     (async) while the second half is computed, the denominators with the second; one apply.  Must give what the
@@ -148,8 +151,9 @@ def test_sharded_h_step_in_row_halves_world2(tmp_path, beta, overlap):
     Wr, Hr, nr, _, _ = O.fit(V, W0, H0, beta, 1e-4, 25, 0.05, 0.5)
     for p in parts:
         assert p['rows'] == ([(0, 256, 256), (256, 444, 512)] if overlap == '1' else None)
-        # north_star's form (TORCHNMF_AMD_AR_OVERLAP=0 / fit(..., allreduce='single')): exactly ONE SUM all-reduce of the packed
-        # [numerator | denominator] buffer per iteration; the overlapped form sends the two row halves separately
+        # north_star's form (the default since round 5; TORCHNMF_AMD_AR_OVERLAP=0 / fit(..., allreduce='single')): exactly ONE SUM
+        # all-reduce of the packed [numerator | denominator] buffer per iteration; the overlapped form sends the two row halves
+        # separately
         assert p['sums'] == ([2] if overlap == '1' else [1])
         assert p['n'] == nr and rel_err(p['H'], Hr) < 1e-5
     assert rel_err(torch.cat([p['W'] for p in parts]), Wr) < 1e-5

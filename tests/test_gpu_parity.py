@@ -1426,10 +1426,15 @@ def test_sharded_path_world1_rccl(dev):
         DenseMU.__init__ = spy
         try:
             m = NMF(W=W5, H=H5).to(dev)
-            n = m.fit(V5.to(dev), 1, NO_STOP, 2, process_group=dist.group.WORLD)
+            n = m.fit(V5.to(dev), 1, NO_STOP, 2, process_group=dist.group.WORLD, allreduce='overlap')
+            # nothing chosen (no keyword, no environment): ONE all-reduce per iteration, north_star's form (round 5 default)
+            os.environ.pop('TORCHNMF_AMD_AR_OVERLAP', None)
+            m1 = NMF(W=W5, H=H5).to(dev)
+            assert m1.fit(V5.to(dev), 1, NO_STOP, 2, process_group=dist.group.WORLD) == 2
         finally:
             DenseMU.__init__ = orig_init
-        assert n == 2 and picked == [('f16', True)], picked
+        assert n == 2 and picked == [('f16', True), ('f16', False)], picked
+        assert rel_err(m1.W.data, m.W.data) < 2e-5 and rel_err(m1.H.data, m.H.data) < 2e-5
         Wr, Hr = W5, H5
         for _ in range(2):
             Wr = O.nmf_w_step(V5, Wr, Hr, 1, 1.0)
@@ -1443,6 +1448,7 @@ def test_sharded_path_world1_rccl(dev):
             NMF(Vs.shape, 200).to(dev).fit(Vs.to(dev), max_iter=2, process_group=dist.group.WORLD)
         assert NMF(Vs.shape, 200).to(dev).fit(Vs.to(dev), max_iter=2, precision='bf16', process_group=dist.group.WORLD) == 2
     finally:
+        os.environ.pop('TORCHNMF_AMD_AR_OVERLAP', None)
         dist.destroy_process_group()
 
 
@@ -1603,6 +1609,42 @@ def test_betamu_default_precision_above_rank_128(dev, rank, beta):
     assert ew < TOL and eh < TOL, (ew, eh)
 
 
+@pytest.mark.parametrize('exact,rank,beta,want', [(False, 128, 1, 'f16x'), (True, 128, 1, 'f16'), (False, 128, 2, 'f16x'),
+                                                  (False, 200, 1, 'f16x'), (True, 64, 0.5, 'f16')])
+def test_betamu_auto_takes_the_1x_modes(dev, exact, rank, beta, want):
+    """BetaMu's 'auto' resolves like NMF.fit's -- fp16 operands at 1x MFMA work where both dimensions
+    reach 4096 and the data fit fp16's range ('f16' for an fp16-exact target, 'f16x' otherwise), also at rank 129..256
+    where the alternative is the exact chain path.  Three trainer steps at 4096 x 4096 against the oracle's
+    trainer.py:72-112, 1e-4 bar; p.grad = pos - neg (trainer.py:98) checked on the last step."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
+    g = torch.Generator().manual_seed(4096 + rank)
+    V = torch.rand(4096, 4096, generator=g) + 1e-3
+    if exact:
+        V = V.half().float()
+    W0 = torch.randn(4096, rank, generator=g).abs()
+    H0 = torch.randn(4096, rank, generator=g).abs()
+    m = NMF(W=W0, H=H0).to(dev)
+    trainer = BetaMu(m.parameters(), beta)
+    Vd = V.to(dev)
+
+    def closure():
+        trainer.zero_grad()
+        return Vd, m
+    Wn, Hn = W0, H0
+    for _ in range(3):
+        trainer.step(closure)
+        Wn, Hn, grads = O.betamu_step(V, Wn, Hn, beta)
+    assert trainer.last_precision == want, trainer.last_precision
+    ew, eh = rel_err(m.W.data.cpu(), Wn), rel_err(m.H.data.cpu(), Hn)
+    assert ew < TOL and eh < TOL, (ew, eh)
+    # the gradient is a difference of two near-equal contractions: compare on the scale of its parts
+    for p, k in ((m.W, 'W'), (m.H, 'H')):
+        scale = float(grads[k].abs().mean()) + 1e-30
+        assert float((p.grad.cpu() - grads[k]).abs().mean()) / scale < 5e-2
+
+
 def test_betamu_rejects_general_graphs_and_cpu_tensors(dev):
     from torchnmf_amd import _capi
     from torchnmf_amd.nmf import NMF
@@ -1701,6 +1743,21 @@ def test_plca_fit_g10_golden(dev, name, ctor, fitkw):
     assert n == int(g[f'{name}_n']) and float(norm) == pytest.approx(float(g[f'{name}_norm']), rel=1e-5)
     for p, k in ((m.W, 'W'), (m.H, 'H'), (m.Z, 'Z')):
         assert rel_err(p.data.cpu(), g[f'{name}_{k}']) < TOL, (k, rel_err(p.data.cpu(), g[f'{name}_{k}']))
+
+
+def test_plca_fit_g13_tensor_alphas_golden(dev):
+    """One-element tensor Dirichlet hyper-parameters (plca.py:197-199) against the reference's own run."""
+    from torchnmf_amd.plca import PLCA
+    g = load_golden('g13_plca_tensor_alpha')
+    m = PLCA(W=t(g['W0']), H=t(g['H0']), Z=t(g['Z0'])).to(dev)
+    wa, ha, za = (float(x) for x in g['alphas'])
+    n, norm = m.fit(t(g['V']).to(dev), tol=NO_STOP, max_iter=30, W_alpha=torch.tensor(wa), H_alpha=torch.tensor([ha], device=dev),
+                    Z_alpha=torch.tensor([za]))
+    assert n == int(g['n']) and float(norm) == pytest.approx(float(g['norm']), rel=1e-5)
+    for p, k in ((m.W, 'W'), (m.H, 'H'), (m.Z, 'Z')):
+        assert rel_err(p.data.cpu(), g[k]) < TOL, (k, rel_err(p.data.cpu(), g[k]))
+    with pytest.raises(NotImplementedError, match="f16x"):
+        m.fit(t(g['V']).to(dev), max_iter=1, precision='f16x')
 
 
 @pytest.mark.parametrize('rank,prec', [(5, 'bf16x3'), (100, 'bf16x3'), (100, 'bf16'), (200, None)])

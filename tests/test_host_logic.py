@@ -641,3 +641,32 @@ def test_window_operand_gemm_contract(B, Cc, R, lhs, ts, F):
         for d in range(F):
             got[:, r] += out[..., d:d + lhs[-1], r * F + d]
     assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_plca_tensor_alpha_contract_matches_the_reference():
+    """plca.py:197-199 types the Dirichlet hyper-parameters Union[float, Tensor]; its EM loop evaluates ``if alpha != 1``
+    (plca.py:257, 271, 285) and adds ``alpha - 1`` in place, so a tensor works when it has ONE element and no more
+    dimensions than the factor, and raises RuntimeError otherwise (messages recorded from the reference in g13).  The check
+    runs before anything touches a device."""
+    from torchnmf_amd.plca import PLCA, _scalar_alpha
+    g = load_golden('g13_plca_tensor_alpha')
+    m = PLCA((6, 5), 3)
+    V = torch.rand(6, 5)
+    with pytest.raises(RuntimeError, match='Boolean value of Tensor with more than one value is ambiguous'):
+        m.fit(V, W_alpha=torch.full((5, 3), 1.03))
+    with pytest.raises(RuntimeError, match='broadcast shape'):
+        m.fit(V, Z_alpha=torch.tensor([[1.02]]))
+    assert str(g['multi_error']).split(': ', 1)[1] in 'Boolean value of Tensor with more than one value is ambiguous'
+    assert _scalar_alpha(torch.tensor([0.98]), 'H_alpha', m.H) == pytest.approx(0.98, rel=1e-7)
+    assert _scalar_alpha(torch.tensor([[1.5]]), 'W_alpha', m.W) == 1.5 and _scalar_alpha(2, 'Z_alpha', m.Z) == 2.0
+    with pytest.raises(Exception, match='no CPU fallback|MI355X'):      # admitted tensors get as far as the device check
+        m.fit(V, W_alpha=torch.tensor(1.03), H_alpha=torch.tensor([0.98]))
+
+
+def test_plca_rejects_f16x_with_a_clear_message():
+    """'f16x' passed PLCA's constructor checks and failed inside the first EM step with a misleading rank
+    message.  The precision is validated where the engine is built -- visible here without a GPU through the message."""
+    import inspect
+    from torchnmf_amd import plca
+    src = inspect.getsource(plca._PlcaEM.__init__)
+    assert "precision == 'f16x'" in src and 'NotImplementedError' in src

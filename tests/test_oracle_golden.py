@@ -255,6 +255,22 @@ def test_g10_plca_oracle(name):
     assert np.allclose(losses[1:], g[f'{name}_losses'], rtol=1e-5)
 
 
+def test_g13_plca_tensor_alpha_oracle():
+    """PLCA.fit with one-element TENSOR Dirichlet hyper-parameters (plca.py:197-199), generated from the reference: the
+    oracle, fed the tensors' values, lands on the same factors (the reference's fp32 ``alpha - 1`` against the oracle's
+    differs in the last bit of the added constant only)."""
+    g = load_golden('g13_plca_tensor_alpha')
+    V, W0, H0, Z0 = (torch.from_numpy(g[k]) for k in ('V', 'W0', 'H0', 'Z0'))
+    wa, ha, za = (float(x) for x in g['alphas'])
+    W, H, Z, n, norm, losses = O.plca_fit(V, W0, H0, Z0, tol=NO_STOP, max_iter=30, W_alpha=wa, H_alpha=ha, Z_alpha=za)
+    assert n == int(g['n']) and norm == pytest.approx(float(g['norm']), rel=1e-6)
+    for t_, k in ((W, 'W'), (H, 'H'), (Z, 'Z')):
+        assert rel_err(t_, g[k]) < 5e-6
+    assert np.allclose(losses[1:], g['losses'], rtol=1e-5)
+    assert str(g['multi_error']).startswith('RuntimeError: Boolean value of Tensor with more than one value is ambiguous')
+    assert 'broadcast shape' in str(g['ndim_error'])
+
+
 @pytest.mark.parametrize('name', ['1d', '2d', '3d'])
 @pytest.mark.parametrize('case', ['plain', 'prior', 'frozenZ'])
 def test_g11_siplca_oracle(name, case):

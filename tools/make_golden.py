@@ -19,6 +19,7 @@ Sets:
   g8_convnd      NMF2D (1,4,20,18) r3 k=(3,4), (2,3,12,10) r2 k=(2,2); NMF3D (1,3,8,9,10) r2 k=(2,3,2): 20 iterations
   g9_sparse      NMF.fit on a sparse-COO target (nmf.py:351-398, 602-638), beta in {1, 2}: factors, losses, n_iter
   g11_siplca     plca.SIPLCA / SIPLCA2 / SIPLCA3 (shift-invariant PLCA, plca.py:376-606): plain / priors / frozen Z
+  g13_plca_tensor_alpha  PLCA.fit with one-element tensor Dirichlet hyper-parameters + the multi-element error
   g10_plca       plca.PLCA.fit (EM, plca.py:244-304): plain / Dirichlet priors / frozen Z / frozen W
   g12_betamu_chain  trainer.BetaMu.step on a three-layer nn.Sequential of NMF layers (tests/test_trainer.py:10-32)
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
@@ -375,13 +376,51 @@ def g12():
     np.savez_compressed(os.path.join(OUT, 'g12_betamu_chain.npz'), **out)
 
 
+def g13():
+    """PLCA.fit with tensor-valued Dirichlet hyper-parameters (plca.py:197-199: Union[float, Tensor]).  The reference's EM
+    loop tests them with ``if alpha != 1`` (plca.py:257, 271, 285), so tensors work when they hold ONE element and raise a
+    RuntimeError otherwise; both behaviours are recorded."""
+    from torchnmf import plca as ref_plca
+    ref_plca.tqdm = _LossTap
+    g = torch.Generator().manual_seed(1313)
+    N, C, R = 44, 36, 5
+    V = torch.rand(N, C, generator=g)
+    W0, H0, Z0 = torch.rand(C, R, generator=g), torch.rand(N, R, generator=g), torch.rand(R, generator=g)
+    out = {'V': V.numpy(), 'W0': W0.numpy(), 'H0': H0.numpy(), 'Z0': Z0.numpy()}
+    alphas = dict(W_alpha=torch.tensor(1.03), H_alpha=torch.tensor([0.98]), Z_alpha=torch.tensor([1.02]))
+    m = ref_plca.PLCA(W=W0.clone(), H=H0.clone(), Z=Z0.clone())
+    _LossTap.log = []
+    n, norm = m.fit(V, tol=NO_STOP, max_iter=30, **alphas)
+    out['W'], out['H'], out['Z'] = m.W.data.numpy().copy(), m.H.data.numpy().copy(), m.Z.data.numpy().copy()
+    out['n'], out['norm'] = np.int64(n), np.float64(float(norm))
+    out['losses'] = np.array(_LossTap.log, dtype=np.float64)
+    out['alphas'] = np.array([float(a.reshape(())) for a in alphas.values()], dtype=np.float64)   # W, H, Z
+    m = ref_plca.PLCA(W=W0.clone(), H=H0.clone(), Z=Z0.clone())
+    try:
+        m.fit(V, tol=NO_STOP, max_iter=3, W_alpha=torch.full((C, R), 1.03))
+        out['multi_error'] = np.array('')
+    except RuntimeError as e:
+        out['multi_error'] = np.array(f'{type(e).__name__}: {e}')
+    m = ref_plca.PLCA(W=W0.clone(), H=H0.clone(), Z=Z0.clone())
+    try:     # one element, but more dimensions than Z: the in-place add of plca.py:258 cannot broadcast
+        m.fit(V, tol=NO_STOP, max_iter=3, Z_alpha=torch.tensor([[1.02]]))
+        out['ndim_error'] = np.array('')
+    except RuntimeError as e:
+        out['ndim_error'] = np.array(f'{type(e).__name__}: {e}')
+    np.savez_compressed(os.path.join(OUT, 'g13_plca_tensor_alpha.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    # `python tools/make_golden.py g13` regenerates only the named sets (round 5 added g13 without touching the others)
+    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13) if len(sys.argv) < 2 or fn.__name__ in sys.argv[1:]]
+    for fn in todo:
         fn()
         print('wrote', fn.__name__)
-    with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
+    with open(os.path.join(OUT, 'PROVENANCE.txt'), 'a' if len(sys.argv) > 1 else 'w') as f:
+        if len(sys.argv) > 1:
+            f.write(f'{" ".join(sys.argv[1:])}: ')
         f.write(f'generated by tools/make_golden.py from torchnmf {torchnmf.__version__} '
                 f'(reference mounted at {REF}), torch {torch.__version__}, CPU fp32, 1 thread\n')
