@@ -26,9 +26,11 @@ timed next to it (`bf16_mode`).  Printed JSON also carries
                 on a bounded sample of the same workload (rank 0, N = 1 only);
   parity        the same k iterations on the GPU and in the CPU reference from identical V, W0, H0: relative errors;
   beta_sweep    BASELINE configs[2]: beta in {2, 0.5, 0} at the same shape (iterations/s, kernel fraction at
-                12*N*C*R, parity k = 3);
+                12*N*C*R, parity at the headline's k);
   nmfd          BASELINE configs[3]: NMFD 1025 x 8192, rank 8, T = 400 (iterations/s, per-GEMM fractions, parity);
-  nmf2d         SURVEY 8 row f2 (no reference headline): NMF2D 1 x 64 x 256 x 512, rank 8, 8 x 16 kernel, fit()'s own mode.
+  nmf2d         SURVEY 8 row f2 (no reference headline): NMF2D 1 x 64 x 256 x 512, rank 8, 8 x 16 kernel, fit()'s own mode;
+  ref_notebook  the workload the reference publishes numbers for (benchmark.ipynb: 5168 x 1025, rank 88, five betas, fit());
+  roofline.ceiling_tflops / frac_of_ceiling   the zero-overhead MFMA + HBM-stream ceiling measured in this run (nmfmu_ubench_mfma_hbm).
 """
 import argparse
 import json
@@ -88,6 +90,8 @@ def parse():
     ap.add_argument('--force-dist', action='store_true', help='run the sharded (all-reduce) path even at world size 1')
     ap.add_argument('--gram', action='store_true', help="--beta 2 only: time fit()'s path without reconstruction (X @ panel + Gram "
                     'matrix) instead of the 12*N*C*R kernel')
+    ap.add_argument('--ref-notebook', action='store_true', help="add the ref_notebook sub-object (the reference's own published "
+                    'workload, 5168x1025 rank 88, five betas) to a run that is not the default one')
     ap.add_argument('--telemetry-s', type=float, default=0.8, help='seconds of back-to-back iterations (untimed, after the '
                     'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
                     'into roofline.clock_mhz / power_w (0 disables)')
@@ -97,25 +101,43 @@ def parse():
     return a
 
 
+# HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, separate
+# passes, MI355X_MICROARCH.md), which cannot run inside this process.  profiles/pmc_traffic.json holds the per-launch bytes
+# of the last passes TOGETHER WITH a hash of the kernel sources they measured; `traffic` is emitted only when that hash is
+# the hash of the sources this run was built from -- a record of another build reads null (the field must not
+# go stale silently).  tools/pmc_traffic_update.py rewrites a record from a fresh pmc_summary.txt.
+KERNEL_SOURCES = {'pp': ('nmfmu_pp.h', 'nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_pp.hip'),
+                  'fused': ('nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_r128.hip'),
+                  'xb': ('nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_r128.hip')}
+
+
+def kernel_source_sha(family):
+    import hashlib
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES[family]:
+        with open(os.path.join(ROOT, 'pytorch-nmf_amd', 'csrc', fn), 'rb') as f:
+            h.update(fn.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_key(key):
+    """(bytes per launch | None, note) for a record key '<rows>x<cols>_r<rank>_<precision>_<pp|fused|xb>'."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         e = d.get('records', {}).get(key)
-        return None if e is None else e.get('hbm_bytes_per_launch')
-    except Exception:
-        return None
+        if e is None:
+            return None, 'no PMC pass recorded for this workload (profiles/pmc_traffic.json)'
+        now = kernel_source_sha(key.rsplit('_', 1)[1])
+        if e.get('src_sha16') != now:
+            return None, (f"the recorded PMC pass ({e.get('source', '?')}) measured another build of this kernel "
+                          f"(sources {e.get('src_sha16', 'unrecorded')}, this run {now}); re-run tools/gpu_prof.sh ... pmc")
+        return e.get('hbm_bytes_per_launch'), f"{e.get('source', '')} -- same kernel sources as this run ({now})"
+    except Exception as ex:
+        return None, f'{type(ex).__name__}: {ex}'
 
 
 def pmc_traffic(N, C, R, precision, pp):
-    """HBM bytes per fused launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 gfx950
-    correction + WRITE_SIZE), keyed by shape / precision / kernel; None when this run's workload was not profiled."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        key = f'{N}x{C}_r{R}_{precision}_{"pp" if pp else "fused"}'
-        e = d.get('records', {}).get(key)
-        return None if e is None else e.get('hbm_bytes_per_launch')
-    except Exception:
-        return None
+    return pmc_traffic_key(f'{N}x{C}_r{R}_{precision}_{"pp" if pp else "fused"}')
 
 
 def usable_cores():
@@ -333,7 +355,7 @@ def cpu_baseline(V, W0, H0, beta, iters, betamu=False):
 
 def nmfd_line(a, sub=False):
     """BASELINE configs[3]: NMFD spectrogram 1025 x 8192, rank 8, T = 400, beta = 1 (replicas only: 1 GPU).  Returns the
-    JSON object; sub=True is the trimmed form embedded in the default run (precision f16 headline, k = 3 parity)."""
+    JSON object; sub=True is the trimmed form embedded in the default run (precision f16 headline)."""
     dev = torch.device('cuda', 0)
     from torchnmf_amd.nmfd_engine import ConvMU
     from torchnmf_amd.engine import KernelTimer
@@ -409,7 +431,7 @@ def nmfd_line(a, sub=False):
     peak = MFMA_BF16_PEAK_TFLOPS
     cpu = None
     parity = None
-    cpu_iters = min(a.cpu_iters, 3) if sub else a.cpu_iters
+    cpu_iters = a.cpu_iters            # (round 5: the embedded legs run the headline's k as well; was 3)
     if cpu_iters > 0:
         from oracle import aten_port
         torch.set_flush_denormal(True)
@@ -693,7 +715,8 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         pp = eng.step_h.block_rows == 256
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, precision, pp),
+                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, precision, pp)[0],
+                'traffic_source': pmc_traffic(N, C, R, precision, pp)[1],
                 'kernel': 'nmfmu::pp_kernel' if pp else 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
                 'avg_launch_ms': round(avg_ms, 5),
                 'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
@@ -715,11 +738,71 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
                 roof['peak_at_measured_clock'] = round(pk, 1)
                 roof['frac_of_peak_at_measured_clock'] = round(ach / pk, 4)
             roof['telemetry'] = tel
+        if telemetry and world == 1 and hasattr(eng.be, 'lib') and hasattr(eng.be.lib, 'nmfmu_ubench_mfma_hbm') and not betamu:
+            ceil = ceiling_leg(a, eng, dev)
+            if ceil is not None:
+                roof['ceiling'] = ceil
+                roof['ceiling_tflops'] = ceil['with_stream']['tflops']
+                roof['frac_of_ceiling'] = round(ach / ceil['with_stream']['tflops'], 4)
+                roof['ceiling_note'] = ('ceiling_tflops = what a loop with NO overhead (no LDS operand reads, no elementwise stage, '
+                                        'no barriers, fixed operands) sustains on this box in this run at the same MFMA count and '
+                                        'X bytes per launch; `frac` stays priced against the nominal dense peak')
         if 'ar' in spans:
             roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
             roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
                                       'second half\'s kernel' if 'h0' in spans else 'blocking, after the H half-step kernel')
         out['roofline'] = roof
+    return out
+
+
+def ceiling_leg(a, eng, dev):
+    """The zero-overhead ceiling of the fused MU step on THIS box, in THIS run: nmfmu_ubench_mfma_hbm
+    = 8 waves per CU issuing exactly one half-step's MFMAs (32 per wave and tile, fixed fragments read from the live W image:
+    the real operand distribution) next to an independent non-temporal stream of exactly one half-step's X bytes (the live
+    packed X), no LDS reads, no VALU, no barriers.  Timed like the kernels (hipEvents on the launching stream, after a pre-roll
+    that lets the clocks settle), with the same clock / power telemetry.  Also the MFMA loop alone (no stream)."""
+    import ctypes as C
+    from torchnmf_amd import _capi
+    lib = eng.be.lib
+    st = eng.step_h
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    f16 = int(eng.precision in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)))
+    img, xp = eng.fW.p1_hi, st.xp
+    kib = {128: 4, 256: 2, 64: 8}.get(eng.r_pad)
+    if kib is None or img.numel() < 65536:
+        return None
+    waves = 8
+    tiles = int(xp.numel() // (ncu * waves * kib * 1024))
+    if tiles < 8:
+        return None
+    sink = torch.empty(ncu * waves * 64, dtype=torch.float32, device=dev)
+    flops = float(ncu) * waves * tiles * 32 * 32768.0
+
+    def run(k):
+        _capi.check(lib.nmfmu_ubench_mfma_hbm(img.data_ptr(), img.numel(), f16, xp.data_ptr(), k, waves, tiles, ncu,
+                                              sink.data_ptr(), torch.cuda.current_stream().cuda_stream), 'nmfmu_ubench_mfma_hbm')
+    out = {'what': 'MFMA loop on the live W image fragments (32 per wave and tile, 8 waves per CU) beside an independent nt LDS-DMA '
+                   f'stream of the live packed X at {kib} KiB per wave and tile = the MU step\'s flop : byte ratio; no LDS reads, '
+                   'no VALU, no barriers (nmfmu_ubench_mfma_hbm)',
+           'grid': ncu, 'waves_per_workgroup': waves, 'tiles': tiles, 'flops_per_launch': flops,
+           'stream_bytes_per_launch': ncu * waves * tiles * kib * 1024}
+    for name, k in (('with_stream', kib), ('mfma_only', 0)):
+        preroll_steps(lambda: run(k), min(a.preroll_s, 0.3))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 200
+        ev[0].record()
+        for _ in range(reps):
+            run(k)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        ent = {'avg_launch_ms': round(ms, 5), 'tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
+        if k:
+            ent['stream_gbs'] = round(out['stream_bytes_per_launch'] / (ms * 1e-3) / 1e9, 1)
+        if a.telemetry_s > 0:
+            tel = SmiSampler(dev.index or 0).under_load(lambda: run(k), min(a.telemetry_s, 0.5))
+            ent['clock_mhz'], ent['power_w'] = tel.get('clock_mhz'), tel.get('power_w')
+        out[name] = ent
     return out
 
 
@@ -787,6 +870,75 @@ def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms, cls_name='NMF'):
             'loop_over_engine_step': round(loop / 200 / engine_ms, 4),
             'note': 'loop = 200 MU iterations + 20 loss evaluations with their host syncs (nmf.py:393-407); setup = packing V in '
                     'both orientations, validation flags, precision admission test, initial loss'}
+
+
+def ref_notebook_leg(a, dev, do_cpu):
+    """The ONE workload the reference publishes numbers for (examples/benchmarks/benchmark.ipynb cells 3-4): NMF.fit on a
+    5168 x 1025 magnitude spectrogram, 88 components, beta in {0, 0.5, 1, 1.5, 2}, max_iter = 60, tol = 1e-4, timed as the
+    notebook times it -- wall clock of the whole fit() call divided by the iterations it returns.  The notebook's audio file
+    is not available (no network): the target here is the magnitude of complex white noise of that shape (Rayleigh
+    distributed, what |STFT| of noise is), same init law as the reference (|N(0,1)|, nmf.py:221).  Reported per beta: what
+    precision='auto' picks and its s/iteration, the same fit forced to the 1x fp16 mode 'f16x' (what 'auto' would need the
+    F16_MIN_DIM rule relaxed for), both with their relative error against the reference's op sequence on the host after the
+    same number of iterations -- so the record says whether the 1x mode would be admissible at this shape.  The notebook's
+    own figures (RTX 3070 / i7-4790K, torchnmf 0.3.4) are quoted as context, not as a baseline (other hardware, real audio)."""
+    from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.engine import DenseMU
+    N, C, R = 5168, 1025, 88
+    g = torch.Generator(device=dev).manual_seed(5168)
+    V = torch.randn(2, N, C, device=dev, generator=g).pow_(2).sum(0).sqrt_()
+    W0 = torch.randn(C, R, device=dev, generator=g).abs_()
+    H0 = torch.randn(N, R, device=dev, generator=g).abs_()
+    notebook = {'0': (0.2972, 0.2081, 0.001958), '0.5': (0.4571, 0.2477, 0.002170), '1': (0.1713, 0.1546, 0.001306),
+                '1.5': (0.3474, 0.2535, 0.002192), '2': (0.03827, 0.08189, 0.001327)}
+    m = NMF(W=W0, H=H0).to(dev)
+
+    def run(beta, precision, max_iter=60, tol=1e-4):
+        m.W.data.copy_(W0)
+        m.H.data.copy_(H0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = m.fit(V, beta=beta, tol=tol, max_iter=max_iter, **({} if precision is None else {'precision': precision}))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / max(n, 1), n
+    out = {'workload': f'NMF.fit, {N}x{C} (frames x bins), rank {R}, max_iter=60, tol=1e-4, time / returned iterations '
+                       '(/root/reference/examples/benchmarks/benchmark.ipynb:108-130)',
+           'target': 'synthetic |complex white noise| (Rayleigh), fp32 -- the notebook\'s MAPS recording is not available',
+           'f16_min_dim_rule': f"'auto' admits the 1x fp16 modes from min(V.shape) >= {DenseMU.F16_MIN_DIM} (engine.py); here "
+                               f"min(V.shape) = {C}", 'betas': {}}
+    Vc = W0c = H0c = None
+    if do_cpu:
+        from oracle import aten_port
+        torch.set_flush_denormal(True)
+        Vc, W0c, H0c = V.cpu(), W0.cpu(), H0.cpu()
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    for beta in (0.0, 0.5, 1.0, 1.5, 2.0):
+        ent = {}
+        for tag, prec in (('auto', None), ('f16x_forced', 'f16x')):
+            run(beta, prec, 10)                        # warm (allocator, first launches of this beta's kernels)
+            s_it, n = min(run(beta, prec) for _ in range(3))
+            e = {'s_per_iter': float(f'{s_it:.4g}'), 'iters_per_s': round(1.0 / s_it, 1), 'n_iter': n,
+                 'precision': m.last_precision}
+            if do_cpu:
+                # parity over the iterations this fit ran (no early stop on either side: tol -> never)
+                k = 60
+                run(beta, prec, k, -1e9)
+                Wg, Hg = m.W.data.cpu(), m.H.data.cpu()
+                if 'ref' not in ent:
+                    t0 = time.perf_counter()
+                    ent['ref'] = aten_port.mu_iterations(Vc, W0c, H0c, beta, k)
+                    ent['cpu_port_s_per_iter'] = float(f'{(time.perf_counter() - t0) / k:.4g}')
+                Wr, Hr = ent['ref'][0], ent['ref'][1]
+                e['parity_k60'] = {'rel_W': float(f'{rel(Wg, Wr):.3e}'), 'rel_H': float(f'{rel(Hg, Hr):.3e}')}
+                e['parity_k60']['meets_1e-4'] = max(e['parity_k60']['rel_W'], e['parity_k60']['rel_H']) < 1e-4
+            ent[tag] = e
+        ent.pop('ref', None)
+        sk, tcpu, tcuda = notebook[f'{beta:g}']
+        ent['notebook_context_s_per_iter'] = {'sklearn_i7_4790K': sk, 'torchnmf_cpu_i7_4790K': tcpu, 'torchnmf_cuda_rtx3070': tcuda}
+        out['betas'][f'{beta:g}'] = ent
+    if do_cpu:
+        out['cpu_port_threads'] = torch.get_num_threads()
+    return out
 
 
 DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)', 'f16x': 'f16 operands, f32 target'}
@@ -906,7 +1058,7 @@ def main():
                       'bar': 1e-4, 'modes': {m: parity_leg(a, V, W0, H0, Vc, beta, m, Wr, Hr, a.cpu_iters, dev) for m in modes}}
 
     # ---- the other BASELINE configs the driver's default command should see (1 GPU, default workload only):
-    # configs[2] = the beta sweep at this shape, configs[3] = NMFD.  Each with its own in-run parity check (k = 3).
+    # configs[2] = the beta sweep at this shape, configs[3] = NMFD.  Each with its own in-run parity check (k = --cpu-iters, like the headline).
     beta_sweep = None
     nmfd = None
     nmf2d = None
@@ -942,12 +1094,13 @@ def main():
                     'kernel_avg_launch_ms_w_step': rf['avg_launch_ms_w_step'], 'kernel_avg_launch_ms_h_step': rf['avg_launch_ms_h_step'],
                     'roofline': {'bound': 'hbm', 'achieved': rf['hbm']['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': rf['hbm']['frac'], 'algorithmic_bytes_per_launch': rf['hbm']['algorithmic_bytes_per_launch'],
-                                 'traffic': pmc_traffic_key(f'{N}x{C}_r{R}_{a.precision}_xb')},
+                                 'traffic': pmc_traffic_key(f'{N}x{C}_r{R}_{a.precision}_xb')[0],
+                                 'traffic_source': pmc_traffic_key(f'{N}x{C}_r{R}_{a.precision}_xb')[1]},
                     'speedup_over_12NCR_kernel': round(ent['ms_per_step'] / gleg['ms_per_step'], 3),
                     'clock_mhz': rf.get('clock_mhz'), 'power_w': rf.get('power_w')}
                 del gleg
             if do_cpu:
-                k = 3
+                k = a.cpu_iters        # round 5: the sweep legs carry the same k as the headline (was 3)
                 Vbc = Vc.clamp(min=2.0 ** -7) if b <= 0 else Vc
                 Wr, Hr = aten_port.mu_iterations(Vbc, W0.cpu(), H0.cpu(), b, k)
                 ent['parity'] = dict(k=k, **parity_leg(a, Vb, W0, H0, Vbc, b, a.precision, Wr, Hr, k, dev))
@@ -994,7 +1147,7 @@ def main():
         del leg
         if do_cpu:
             from oracle import aten_port
-            k = 3
+            k = a.cpu_iters
             Vrc = Vr.cpu()
             Wr, Hr = aten_port.mu_iterations(Vrc, W0.cpu(), H0.cpu(), beta, k)
             real['parity'] = dict(k=k, **parity_leg(a, Vr, W0, H0, Vrc, beta, picks, Wr, Hr, k, dev))
@@ -1002,6 +1155,10 @@ def main():
         fitr = fit_leg(a, Vr, W0, H0, beta, None, dev, 1e3 / real['iters_per_s'])   # precision=None: fit()'s own default ('auto')
         real['fit'] = fitr
         del Vr
+
+    ref_nb = None
+    if default_run or a.ref_notebook:
+        ref_nb = ref_notebook_leg(a, dev, do_cpu)
 
     if rank == 0:
         ms_per_step = head['ms_per_step']
@@ -1027,6 +1184,7 @@ def main():
             'roofline': head.get('roofline'), 'cpu_baseline': cpu, 'parity': parity,
             ('bf16_mode' if other == 'bf16' else 'parity_mode'): second,
             'beta_sweep': beta_sweep, 'nmfd': nmfd, 'nmf2d': nmf2d, 'fit': fit_obj, 'real_data_mode': real,
+            'ref_notebook': ref_nb,
         }
         if betamu:
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \

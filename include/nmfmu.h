@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 7 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+#define NMFMU_ABI_VERSION 8 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
                                3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
@@ -42,7 +42,10 @@ extern "C" {
                                   the reconstruction); NMFMU_ERR_ALLOC;
                                7: nmfmu_gemm_desc.win_* / NMFMU_OPS_A_WIN (H numerator of NMFD / NMF2D / NMF3D without the unfolded Y),
                                   nmfmu_conv_pack_wk, nmfmu_conv_apply_h_rows; nmfmu_gemm_desc.t_koff, nmfmu_convnd_tables / _table_bytes / _koff (implicit
-                                  operands with several shift axes) */
+                                  operands with several shift axes);
+                               8: nmfmu_abi_check (load-time guard for bindings that are not the bundled Python host),
+                                  nmfmu_ubench_mfma_hbm (in-run ceiling of the MU step for bench.py); the NMFD GEMMs stage an implicit
+                                  operand as a sliding window of table entries where its tiles hold no padding (no interface change) */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -110,6 +113,13 @@ typedef struct nmfmu_step {
 
 /* ---- static queries (host only, no device work) ------------------------------------------------------------ */
 int nmfmu_abi_version(void);
+/* Load-time guard for bindings other than the bundled Python host: pass the NMFMU_ABI_VERSION the binding was
+ * COMPILED against; NMFMU_OK iff it is the library's, NMFMU_ERR_ARG otherwise.  Struct layouts are append-only, but the
+ * MEANING of a field may tighten between versions -- e.g. since ABI 6 a split panel (panel.p1_* and panel.p2_* images of
+ * different matrices) must say NMFMU_STAGE_DMA_SPLIT: with NMFMU_STAGE_DMA the single-plane kernels stage p1 only and
+ * derive the second GEMM's operand from it, so an ABI-5 caller's split panel would give wrong numerators without any
+ * error.  A binding that calls this once after dlopen cannot run into that silently. */
+int nmfmu_abi_check(int compiled_against);
 int nmfmu_pad_rows(int rows);             /* rows rounded up to a multiple of 256                                  */
 int nmfmu_pad_rank(int rank);             /* 32 / 64 / 128 / 256, or NMFMU_ERR_UNSUPPORTED                         */
 int nmfmu_beta_kind(float beta);          /* NMFMU_BETA_*                                                          */
@@ -148,6 +158,10 @@ int nmfmu_pack_factor_scaled(const nmfmu_factor* fac, int rank, int r_pad, int p
  * nmfmu_mu_partial: reconstruct + both backward passes of nmf.py:376-378 / 389-391, fused:
  *   slab_num[s] = sum over the s-th contraction chunk of  Gn(X, owner panel^T) @ panel      (nmf.py:77)
  *   slab_den[s] = likewise with Gp                                                    (nmf.py:82, beta != 1)
+ * st->stage: NMFMU_STAGE_DMA when panel.p1_* and panel.p2_* are the two images of ONE matrix (every NMF half-step; the
+ * single-plane kernels then read p1 only), NMFMU_STAGE_DMA_SPLIT when they are images of different matrices (PLCA's
+ * Z-scaled / unscaled pair; beta == 1, this entry only).  Passing a split panel with NMFMU_STAGE_DMA is not detectable
+ * here and yields the numerators of p1's matrix -- see nmfmu_abi_check.
  */
 int nmfmu_mu_partial(const nmfmu_step* st, void* stream);
 
@@ -157,7 +171,8 @@ int nmfmu_mu_partial(const nmfmu_step* st, void* stream);
  * st->xp == NULL and then evaluates beta_div against an all-zero target, i.e. sum (S + eps)^beta / beta. */
 int nmfmu_den_partial(const nmfmu_step* st, void* stream);
 
-/* nmfmu_mu_step: one complete single-device half-step = nmfmu_mu_partial + nmfmu_mu_apply.  When the contraction is
+/* nmfmu_mu_step: one complete single-device half-step = nmfmu_mu_partial + nmfmu_mu_apply (st->stage as there; a split
+ * panel is not meaningful for a complete MU half-step and NMFMU_STAGE_DMA_SPLIT is rejected).  When the contraction is
  * not split (nsplit == 1) and beta == 1 the apply runs inside the fused kernel's epilogue (no slab round trip).
  * kl_den: column sums of the panel (beta == 1), else ignored.  phase: 0 = everything, 1 = only the fused kernel,
  * 2 = only what follows it (lets a caller bracket the dominant kernel with events). */
@@ -582,6 +597,16 @@ int nmfmu_timer_destroy(void* timer);
 int nmfmu_probe_mfma(const uint16_t* a /*32x16 bf16 row-major*/, const uint16_t* b /*16x32*/, float* d /*32x32*/,
                      void* stream);
 int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords /* multiple of 1024 */, void* stream);
+/* The zero-overhead ceiling of the fused MU step, measured in the run that quotes it (bench.py: roofline.ceiling_tflops):
+ * every wave issues 32 MFMAs (32x32x16; f16 != 0: fp16, else bf16) per tile on fixed fragments read once from `operands`
+ * (a REAL 16-bit factor image of >= 64 KiB, so that the matrix pipe sees the MU step's value distribution -- the clock the
+ * power limit leaves follows the data) and streams kib_per_tile KiB (0, 1, 2, 4 or 8) per wave and tile from `stream_src`
+ * by non-temporal LDS-DMA, never read back, at most three tiles in flight; no LDS reads, no VALU, no barriers.
+ * kib_per_tile = 4 is the rank-128 MU step (256 flop per X byte).  grid workgroups of `waves` (4 or 8) waves, `tiles`
+ * tiles each: stream_src holds grid * waves * tiles * kib_per_tile KiB, out grid * waves * 64 floats (a sink).  Flops =
+ * grid * waves * tiles * 32 * 32768.  Asynchronous on `stream`; time it with events.  Not used by the product path. */
+int nmfmu_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
+                          int waves, int tiles, int grid, float* out, void* stream);
 /* Diagnostic hook of the ping-pong kernel (nmfmu_pp.h), live only in libraries built with -DNMFMU_DEBUG_HOOKS
  * (NMFMU_ERR_UNSUPPORTED otherwise): with a device buffer of >= (64 + 5 * workgroups) uint64 registered, every
  * workgroup records clock stamps at kernel entry, loop start, loop end and exit (tools/pp_timeline.py).  buf = NULL

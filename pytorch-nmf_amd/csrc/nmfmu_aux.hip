@@ -629,4 +629,86 @@ int launch_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, hipSt
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// (3) the zero-overhead ceiling of the fused MU step: an MFMA loop beside an
+// INDEPENDENT HBM stream at the MU step's flop-per-byte ratio.  Every wave issues 32 MFMAs (32x32x16, bf16 or fp16) per
+// "tile" on operand fragments that never change -- taken from a REAL factor image, so that the matrix pipe sees the value
+// distribution of the MU step's operands (its power draw, and with it the clock the socket's limit leaves, follow the data)
+// -- and streams NLOAD KiB per tile from HBM by LDS-DMA (non-temporal, never read back, at most three tiles in flight).
+// No LDS reads, no VALU work, no barriers, nothing depends on the stream.  NLOAD = 4 is the rank-128 MU step: 4 KiB of
+// 16-bit X per wave and 32 MFMAs = 256 flop per X byte; grid = CUs x 8 waves x 64 tiles = exactly the MFMA count and the
+// X bytes of one configs[1] half-step.  What this loop sustains is what a kernel with NO overhead at all could reach on
+// this part under its power limit; bench.py prices the shipped kernel against it next to the nominal 2.5 PFLOP/s.
+template <int NLOAD, bool F16>
+__global__ void __launch_bounds__(512) ubench_mfma_hbm_kernel(const char* __restrict__ operands, size_t operand_bytes,
+                                                              const char* __restrict__ src_all, int tiles, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nwaves = (int)blockDim.x >> 6;
+  // 2 x 8 fragments of 1 KiB per wave: A from the first half of the image, B from the second (16-byte chunks = 8 consecutive
+  // ranks of one factor row, the unit the fused kernels feed to the MFMA as well)
+  const size_t half = (operand_bytes / 2) & ~(size_t)16383;
+  const size_t woff = (((size_t)blockIdx.x * nwaves + wave) * 8192) % (half - 8192);
+  u32x4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = *reinterpret_cast<const u32x4*>(operands + woff + (size_t)i * 1024 + lane * 16);
+    b[i] = *reinterpret_cast<const u32x4*>(operands + half + woff + (size_t)i * 1024 + lane * 16);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const unsigned lds_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 8192u;
+  const char* src = src_all + ((size_t)blockIdx.x * nwaves + wave) * ((size_t)tiles * (NLOAD ? NLOAD : 1) * 1024) + lane * 16;
+  for (int t = 0; t < tiles; ++t) {
+    if constexpr (NLOAD > 0) {
+#pragma unroll
+      for (int p = 0; p < NLOAD; ++p) {
+        const unsigned la = lds_base + (unsigned)((p & 7) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :
+                     : "v"(src + (size_t)(t * NLOAD + p) * 1024), "s"(la)
+                     : "memory", "m0");
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLOAD > 63 ? 63 : 3 * NLOAD) : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[0] = mfma_op<F16 ? kOpF16 : kOpBf16>(a[i], b[i], acc[0]);
+      acc[1] = mfma_op<F16 ? kOpF16 : kOpBf16>(a[i], b[(i + 1) & 7], acc[1]);
+      acc[2] = mfma_op<F16 ? kOpF16 : kOpBf16>(a[(i + 2) & 7], b[i], acc[2]);
+      acc[3] = mfma_op<F16 ? kOpF16 : kOpBf16>(a[(i + 3) & 7], b[(i + 5) & 7], acc[3]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float tt = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tt += acc[i][e];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = tt;
+}
+
+int launch_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
+                           int waves, int tiles, int grid, float* out, hipStream_t s) {
+  auto go = [&](auto kern) {
+    static bool done[64] = {};
+    (void)done;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), (size_t)waves * 8192, s, (const char*)operands, operand_bytes,
+                       (const char*)stream_src, tiles, out);
+    return (int)hipGetLastError();
+  };
+#define UB(N) \
+  if (kib_per_tile == N) return f16 ? go(ubench_mfma_hbm_kernel<N, true>) : go(ubench_mfma_hbm_kernel<N, false>);
+  UB(0) UB(1) UB(2) UB(4) UB(8)
+#undef UB
+  return -2;
+}
+
 }  // namespace nmfmu

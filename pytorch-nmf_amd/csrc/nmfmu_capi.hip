@@ -148,6 +148,7 @@ struct Timer {
 extern "C" {
 
 int nmfmu_abi_version(void) { return NMFMU_ABI_VERSION; }
+int nmfmu_abi_check(int compiled_against) { return compiled_against == NMFMU_ABI_VERSION ? NMFMU_OK : NMFMU_ERR_ARG; }
 int nmfmu_pad_rows(int rows) { return rows <= 0 ? NMFMU_ERR_ARG : pad_rows(rows); }
 int nmfmu_pad_rank(int rank) {
   const int r = pad_rank(rank);
@@ -259,6 +260,9 @@ int nmfmu_den_partial(const nmfmu_step* st, void* stream) {
 int nmfmu_mu_step(const nmfmu_step* st, const float* kl_den, int phase, void* stream) {
   if (!st || phase < 0 || phase > 2) return NMFMU_ERR_ARG;
   if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  // (a split panel -- images of two different matrices -- belongs to nmfmu_mu_partial: PLCA's EM reads the slabs; a complete
+  // MU half-step of ONE panel matrix has nothing to split, and the fused-apply epilogue stages p1 only)
+  if (st->stage == NMFMU_STAGE_DMA_SPLIT) return NMFMU_ERR_ARG;
   const bool kl = nmfmu_beta_kind(st->beta) == NMFMU_BETA_KL;
   if (kl && !kl_den) return NMFMU_ERR_ARG;
   // apply in the fused kernel's epilogue when the workgroup owns whole rows: beta == 1 (closed-form denominators) on
@@ -469,6 +473,14 @@ int nmfmu_timer_destroy(void* timer) {
   for (auto& e : t->ev) hipEventDestroy(e);
   delete t;
   return NMFMU_OK;
+}
+
+int nmfmu_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
+                          int waves, int tiles, int grid, float* out, void* stream) {
+  if (!operands || operand_bytes < 65536 || !out || (waves != 4 && waves != 8) || tiles <= 0 || grid <= 0) return NMFMU_ERR_ARG;
+  if (kib_per_tile != 0 && !stream_src) return NMFMU_ERR_ARG;
+  const int rc = launch_ubench_mfma_hbm(operands, operand_bytes, f16, stream_src, kib_per_tile, waves, tiles, grid, out, S(stream));
+  return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 
 int nmfmu_debug_set_buffer(void* buf) {

@@ -229,15 +229,22 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       if constexpr (!C::LOSS) dma_img(p2src + (size_t)clampt(t + C::LEAD - 1) * IMG, C::P2_BASE + p2_issue_off);
     };
     // this wave's four 1-KiB pieces of X(t), one 16-byte chunk per lane each, loaded by asm so that hipcc neither
-    // counts nor waits for them; wait_x() is the counted wait that makes a buffer readable
+    // counts nor waits for them; wait_x() is the counted wait that makes a buffer readable.  Non-temporal: X is read once
+    // per launch (-DNMFMU_PP_X_DEFAULT_POLICY builds the default cache policy for the Infinity-Cache experiment of round 5,
+    // tools/mall_probe.py / profiles/r05_mall.md: no difference)
+#ifdef NMFMU_PP_X_DEFAULT_POLICY
+#define NMFMU_PP_XPOL ""
+#else
+#define NMFMU_PP_XPOL " nt"
+#endif
     auto load_x = [&](int t, u32x4(&x)[4]) {
       const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
       asm volatile(
           "s_nop 4\n\t"
-          "global_load_dwordx4 %0, %4, %5 nt\n\t"
-          "global_load_dwordx4 %1, %4, %5 offset:1024 nt\n\t"
-          "global_load_dwordx4 %2, %4, %5 offset:2048 nt\n\t"
-          "global_load_dwordx4 %3, %4, %5 offset:3072 nt"
+          "global_load_dwordx4 %0, %4, %5" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %1, %4, %5 offset:1024" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %2, %4, %5 offset:2048" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %3, %4, %5 offset:3072" NMFMU_PP_XPOL
           : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
           : "v"(lane16), "s"(src)
           : "memory");

@@ -57,13 +57,14 @@ class GemmDesc(C.Structure):
                 ('win_pitch', C.c_int32), ('win_fold', C.c_int32), ('t_koff', C.c_void_p)]
 
 
-ABI_VERSION = 7   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 8   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU, OPS_A_WIN = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); every symbol include/nmfmu.h declares
 SIGNATURES = {
     'nmfmu_abi_version': (C.c_int, []),
+    'nmfmu_abi_check': (C.c_int, [C.c_int]),
     'nmfmu_pad_rows': (C.c_int, [C.c_int]),
     'nmfmu_pad_rank': (C.c_int, [C.c_int]),
     'nmfmu_beta_kind': (C.c_int, [C.c_float]),
@@ -203,6 +204,8 @@ SIGNATURES = {
     'nmfmu_probe_mfma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_probe_lds_dma': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'nmfmu_debug_set_buffer': (C.c_int, [C.c_void_p]),
+    'nmfmu_ubench_mfma_hbm': (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

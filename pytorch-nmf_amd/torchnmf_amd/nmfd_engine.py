@@ -124,7 +124,17 @@ class ConvMU(AsyncLossMixin):
         f16_fold = (nd == 1 and T >= 128 and os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0' and
                     os.environ.get('TORCHNMF_AMD_NMFD_FUSED_SUMS', '1') != '0')
         f16_rows = ((nd > 1 or 1 < T < 128) and os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
-        f16_ok = own_loop and float(beta) == 1.0 and aligned and (f16_fold or f16_rows)
+        # ... and only where one of the two H-numerator paths built for fp16 planes will actually be taken ('auto'
+        # used to decide from f16_fold / f16_rows alone and could then fail the explicit-'f16' check further down -- ratio
+        # planes of 2 GiB or more, or TORCHNMF_AMD_NMFD_H_ROWS=0 where the fold-parts path does not apply -- instead of
+        # falling back to split bf16): the same two predicates that set self.fold_parts / self.h_rows below
+        pad_ = (lambda n: (n + 127) // 128 * 128)
+        fold_parts_will = (own_loop and nd == 1 and bool(self.lib.nmfmu_fold_parts_supported(B, R, Lh, T)) and
+                           os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0')
+        h_rows_will = (T > 1 and not fold_parts_will and 2 * pad_(B * L) * pad_(Cc) < 2 ** 31 and
+                       os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
+        f16_ok = (own_loop and float(beta) == 1.0 and aligned and (f16_fold or f16_rows) and
+                  (fold_parts_will or h_rows_will))
         # (fold path: Y elements contract over the channels alone; window-operand path: over channels x taps)
         long_enough = (min(Cc, B * L) >= self.F16_MIN_DIM and R * T >= self.F16_MIN_DIM) if f16_fold else \
             min(Cc * T, B * L, R * T) >= self.F16_MIN_DIM
@@ -146,7 +156,9 @@ class ConvMU(AsyncLossMixin):
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
         if precision == 'f16' and not f16_ok:
             raise ValueError("precision 'f16' is built for the convolutive models with beta == 1 and taps / frames (of the "
-                             "last shift axis) that are multiples of 8 (implicit Toeplitz operands); use 'bf16x3' or 'bf16'")
+                             "last shift axis) that are multiples of 8 (implicit Toeplitz operands), on shapes whose H "
+                             "numerator takes the fold-parts or the window-operand path (ratio planes below 2 GiB); use "
+                             "'bf16x3' or 'bf16'")
         self.precision_name = precision
         self.precision = _capi.PRECISIONS[precision]
         x3 = self.precision == _capi.PREC_BF16X3
@@ -230,8 +242,7 @@ class ConvMU(AsyncLossMixin):
         self.den_w = None if self.kl else torch.empty(cp * rpp, dtype=torch.float32, device=dev)
         # H numerator Y[(r,t)][(b,l)] before the col2im sum: with >= 128 taps the GEMM hands over per-tile diagonal sums
         # (NMFMU_EPI_FOLD, 4 KiB per tile) instead of storing Y (4 R T B L bytes, 105 MB at configs[3])
-        self.fold_parts = (own_loop and nd == 1 and bool(self.lib.nmfmu_fold_parts_supported(B, R, Lh, T)) and
-                           os.environ.get('TORCHNMF_AMD_NMFD_FOLD_PARTS', '1') != '0')
+        self.fold_parts = fold_parts_will
         # tail-round split of the H-numerator GEMM (fold epilogue): its (rp_pad / 128) x (bl_pad / 128) tiles run two per CU;
         # when they make N full rounds of the chip plus at most a quarter round that is whole tile rows (configs[3]: 1600
         # tiles on 512 slots = 3 rounds + the last row of 64), those rows are contraction-split so that the last round
@@ -245,11 +256,8 @@ class ConvMU(AsyncLossMixin):
         # A operand are shifted rows of the ratio planes the H half-step has just written, so nothing is unfolded or folded
         # (Y is 4 R T B L bytes: 537 MB for a 256 x 512 frame with 8 x 16 taps).  Any number of shift axes, no alignment
         # rules.  The fold-parts path above stays where it applies (1-D, >= 128 taps: it multiplies no padding of the rank).
-        self.h_rows = (T > 1 and not self.fold_parts and 2 * blp * cp < 2 ** 31 and
-                       os.environ.get('TORCHNMF_AMD_NMFD_H_ROWS', '1') != '0')
-        if self.precision == _capi.PREC_F16 and not (self.fold_parts or self.h_rows):
-            raise ValueError("precision 'f16': this shape takes neither the fold-parts nor the window-operand path for the H "
-                             "numerator (fp16 planes are built for those two); use 'bf16x3' or 'bf16'")
+        self.h_rows = h_rows_will
+        assert not (self.precision == _capi.PREC_F16 and not (self.fold_parts or self.h_rows))   # (f16_ok covers it)
         self.y = self.y_den = None
         if self.h_rows:
             self.wk_rows = 32 if R <= 32 else 64 if R <= 64 else pad(R)
