@@ -347,6 +347,12 @@ typedef struct nmfmu_gemm_desc {
    * nmfmu_convnd_koff(ops, ..., k_pad) -- one int per 8-wide k-chunk.  Needs taps and V extent of the LAST axis to be
    * multiples of 8.  NULL with win_nd <= 1: the one-axis form above (t_taps, t_lh). */
   const int32_t* t_koff;
+  /* (ABI 8, appended) How an implicit operand (ops B_HU / B_HUT / A_HU, one shift axis) reaches LDS: 0 = automatic -- as a
+   * sliding WINDOW of the distinct table entries a k-tile touches (128 + 56 entries = 2.9 KiB instead of the 16 KiB of a
+   * chunk-major tile, which holds most entries eight times: 19 instead of 32 LDS-DMA pieces per k-tile) wherever the
+   * implicit operand's tiles hold no padding (nmfmu_gemm_window_staged), chunk-major elsewhere; 1 = chunk-major always
+   * (the form of ABI <= 7; same results bit for bit -- the products and their order are unchanged). */
+  int32_t stage_mode;
 } nmfmu_gemm_desc;
 
 #define NMFMU_OPS_PLANES 0   /* A and B are bf16 planes                                                            */
@@ -385,6 +391,11 @@ int nmfmu_convnd_koff(int ops, int batch, int rank, int ndim, const int32_t* lh,
                       int32_t* koff_host);
 
 int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream);
+/* 1 when nmfmu_gemm(d, epilogue) stages its implicit operand as a window of table entries (stage_mode 0 and a shape whose
+ * implicit operand has no padding inside any tile: rows (b,l): (Lh + T - 1) % 128 == 0, T >= 64, n_pad resp. m_pad ==
+ * batch * (Lh + T - 1), k_len == rank * T (a multiple of 64); rows (r,t): n_pad == rank * T (a multiple of 128), T >= 128,
+ * (Lh + T - 1) % 64 == 0, k_len == batch * (Lh + T - 1)); 0 otherwise; < 0: the descriptor is invalid. */
+int nmfmu_gemm_window_staged(const nmfmu_gemm_desc* d, int epilogue);
 /* NMFMU_PREC_F16 in the GEMM engine: fp16 operand planes / window tables (nmfmu_conv_tables_f16,
  * nmfmu_conv_apply_pack_w_sums with precision F16) and fp16 ratio planes, one plane each, same MFMA rate as bf16 with
  * 11 significant bits; ratios saturate at 65504.  Built for the combinations of the beta == 1 NMFD iteration on implicit

@@ -95,24 +95,39 @@ using GemmN64 = GemmShape<4, 1, 1, 2>;
 using GemmM64 = GemmShape<1, 4, 2, 1>;
 // (256 x 128 and 128 x 256 with eight 64 x 64 waves were measured too: same time as two 128 x 128 workgroups per CU.)
 
-template <bool X3, class SH>
+// WS ("window staging", round 5): the implicit Toeplitz operand of a k-tile is not staged chunk-major (8 k-chunks x 128 rows
+// x 16 B = 16 KiB of table entries, most of them the SAME entries again: chunk q of row m is table entry base + m - 8 q) but
+// as the window of DISTINCT entries the tile touches: 128 + 56 consecutive entries = 2.9 KiB.  Slot s of a window region
+// holds table entry (region base) + s; the fragment of (row m, chunk q) is slot m + 56 - 8 q (rows (b,l), reversed windows)
+// resp. (n - 1 - m) + 8 q (rows (r,t), forward windows, n rows in the segment).  A tile that crosses a boundary of the
+// table's lines -- the next r inside a k-tile (rows (b,l)), the next r inside the tile's rows (rows (r,t)) -- uses a second
+// region for the part behind the boundary.  Two regions of WIN_REG = 192 slots: 6 KiB per plane and stage instead of 16,
+// 3 (or 6) LDS-DMA pieces per k-tile instead of 16, issued by waves 0-2.  The k loop of this kernel is bound by LDS-DMA issue
+// (DESIGN.md section 3.4): 19 instead of 32 pieces per k-tile.  Requires tiles without padding rows / dead k-chunks in the
+// implicit operand (nmfmu_gemm checks the shape; everything else keeps the chunk-major path, bit-identical results).
+template <bool X3, class SH, bool WS = false, int TOP = 1>
 struct GemmCfg {
   static constexpr int BM = SH::BM, BN = SH::BN, BK = 64;
-  static constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;   // bytes of one operand-plane tile
+  static constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;   // bytes of one explicit operand-plane tile
   static constexpr int NPL = X3 ? 2 : 1;
-  static constexpr int STAGE = NPL * (A_TILE + B_TILE);               // A planes then B planes
+  static constexpr int WIN_REG = 192, WIN_BYTES = 2 * WIN_REG * 16;   // window regions of an implicit operand (WS)
+  static constexpr int A_BYTES = (WS && TOP == 0) ? WIN_BYTES : A_TILE;   // what a stage holds per operand plane
+  static constexpr int B_BYTES = (WS && TOP == 1) ? WIN_BYTES : B_TILE;
+  static constexpr int STAGE = NPL * (A_BYTES + B_BYTES);             // A planes then B planes
   static constexpr int LDS_BYTES = 2 * STAGE;
   // ragged channels: 16 rows of the explicit operand per k-tile, one 2 KiB tile per plane and stage behind the stages
   static constexpr int RAG_TILE = 16 * BK * 2, RAG_BYTES = 2 * NPL * RAG_TILE;
   static constexpr int PA = BM * 8 / SH::THREADS, PB = BN * 8 / SH::THREADS;   // DMA passes per plane tile
   static_assert(PA * SH::THREADS == BM * 8 && PB * SH::THREADS == BN * 8, "whole DMA passes");
   static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
+  static_assert(!WS || (BM == 128 && BN == 128 && SH::THREADS == 256), "window staging: 128 x 128 tiles, four waves");
 };
 
-template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT, bool ND>
+template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT, bool ND, bool WS = false>
 __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
-  using C = GemmCfg<X3, SH>;
+  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1)>;
   static_assert(!(X3 && OPT == kOpF16), "fp16 operands are single-plane");
+  static_assert(!WS || (!ND && (OPS == kOpsBHu || OPS == kOpsBHuT || OPS == kOpsAHu)), "window staging: one shift axis, an implicit operand");
   // fp16: the ratio planes are converted with saturation (a ratio above 65504 becomes 65504, not inf)
   if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
   constexpr int MI = SH::MI, NI = SH::NI, THREADS = SH::THREADS;
@@ -231,7 +246,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       else kq[p] = (kc * 8) / tL, kr[p] = kc * 8 - kq[p] * tL;
     }
   }
-  auto toep_index = [&](int p) -> int {   // table chunk of (row, k-chunk p); 0 = the all-zero chunk
+  auto toep_index = [&](int p) __attribute__((always_inline)) -> int {   // table chunk of (row, k-chunk p); 0 = the all-zero chunk
     // scalar part first (k position), then one vector add / select for the lane's row
     int soff;
     bool live;
@@ -240,7 +255,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     else soff = 1 + kq[p] * a.tR * tJJ + kr[p], live = kq[p] < a.tB;
     return (live && trow >= 0) ? trow + soff : 0;
   };
-  auto toep_advance = [&]() {
+  auto toep_advance = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if constexpr (ND) {
@@ -255,8 +270,50 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       }
     }
   };
+  // ---- window staging (WS): per-thread constants.  A region holds WIN_REG slots, slot u <- table entry ws_tsl[region] + u +
+  // (the k-tile's scalar offset); waves 0-2 carry the 192 slots of a region (one 1-KiB piece each).
+  //   rows (b,l), k = (r,t)  [B_HU / A_HU; one b per tile: L % 128 == 0]:  entry(row m, chunk q) = trow(m) + soff(q), soff falling
+  //     by 8 per chunk -> slot m + 56 - 8 q.  Region 1 = the chunks behind an r boundary inside the k-tile (T >= 64: one at most).
+  //   rows (r,t), k = (b,l)  [B_HUT; one b per k-tile: L % 64 == 0]:  entries fall with t, rise by 8 per chunk -> slot
+  //     (n - 1 - m') + 8 q inside the row segment (n rows of one r).  Region 1 = the rows of the tile's second r (T >= 128: two at most).
+  int ws_tsl[2] = {0, 0};
+  int ws_q0 = 0, ws_r0 = 0;        // k position of chunk 0 of the next k-tile to issue (the meaning of kq / kr above)
+  int ws_qs0 = 8, ws_qs1 = 8;      // rows (b,l): first chunk behind the r boundary of the k-tile in staging buffer 0 / 1 (8: none)
+  bool ws_two = false;             // rows (r,t): the tile's rows span two r
+  int ws_nent = 1;
+  constexpr int WI = TOP == 0 ? MI : NI;
+  int ws_base[WI] = {};            // byte offset of this lane's fragment rows inside the window block (lane part of the address)
+  if constexpr (WS) {
+    static_assert(TROWS == 128, "window staging: 128 implicit rows per tile");
+    ws_nent = 1 + a.tB * a.tR * tJJ;
+    const int row0 = (TOP == 0 ? bm : bn) * TROWS;
+    const int u = tid;             // (tid < 192 issue)
+    if constexpr (kHuRows) {
+      const int b = row0 / tL, l0 = row0 - b * tL;
+      ws_tsl[0] = ws_tsl[1] = b * a.tR * tJJ + l0 + a.tT - 1 + (u - 56);
+      const int kc = kt0 * 8;
+      ws_q0 = kc / tT8, ws_r0 = kc - ws_q0 * tT8;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) ws_base[i] = ((TOP == 0 ? wm * MI : wn * NI) * 32 + i * 32 + j) * 16 + 128 - 128 * hl;
+    } else {
+      const int r0 = row0 / a.tT, t0 = row0 - r0 * a.tT;
+      const int n0 = min(128, a.tT - t0), n1 = 128 - n0;
+      ws_two = n1 > 0;
+      ws_tsl[0] = r0 * tJJ - t0 - n0 + a.tT + u;
+      ws_tsl[1] = (r0 + 1) * tJJ - n1 + a.tT + u;
+      const int k0 = kt0 * 64;
+      ws_q0 = k0 / tL, ws_r0 = k0 - ws_q0 * tL;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) {
+        const int row = (TOP == 0 ? wm * MI : wn * NI) * 32 + i * 32 + j;
+        const bool seg = row >= n0;
+        const int rl = seg ? row - n0 : row, ng = seg ? n1 : n0;
+        ws_base[i] = ((ng - 1 - rl) + (seg ? C::WIN_REG : 0) + 8 * hl) * 16;
+      }
+    }
+  }
   // LDS offset of plane pl of operand op inside a stage
-  auto tile_off = [](int op, int pl) { return op == 0 ? pl * C::A_TILE : C::NPL * C::A_TILE + pl * C::B_TILE; };
+  auto tile_off = [](int op, int pl) { return op == 0 ? pl * C::A_BYTES : C::NPL * C::A_BYTES + pl * C::B_BYTES; };
 
   // LDS-DMA by inline asm in the scalar-base form (global_load_lds_dwordx4 v_off, s[base:base+1]): the k-tile advance of
   // an explicit operand is a scalar add on its base, the pass offsets are four precomputed registers, the implicit
@@ -286,7 +343,7 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     wk_t1 = t01 % a.win_t[1];
     wk_off = ((t01 / a.win_t[1]) * a.win_l[1] + wk_t1) * a.win_l[2] + wk_t2 * a.win_tstep;
   }
-  auto win_advance = [&]() {
+  auto win_advance = [&]() __attribute__((always_inline)) {
     if (++wk_ck == a.win_ck) {
       wk_ck = 0, wk_off += a.win_tstep;
       if (++wk_t2 == a.win_t[2]) {
@@ -295,18 +352,46 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       }
     }
   };
-  auto dma1k = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
+  auto dma1k = [&](const char* sbase, unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory", "m0");
   };
-  auto stage_issue = [&](int kt, int buf) {
+  auto stage_issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    // window staging: scalar table offsets of this k-tile's one or two regions
+    int ws_soff[2] = {0, 0};
+    bool ws_need1 = false;
+    if constexpr (WS) {
+      if constexpr (kHuRows) {
+        const int qs = tT8 - ws_r0;                       // chunks left in the current r
+        ws_need1 = qs < 8;
+        ws_soff[0] = 1 + ws_q0 * tJJ - 8 * ws_r0;
+        ws_soff[1] = 1 + (ws_q0 + 1) * tJJ + 8 * qs;      // chunk q >= qs: entry = trow + 1 + (r + 1) JJ - 8 (q - qs)
+        if (buf) ws_qs1 = ws_need1 ? qs : 8;
+        else ws_qs0 = ws_need1 ? qs : 8;
+      } else {
+        ws_soff[0] = ws_soff[1] = 1 + ws_q0 * a.tR * tJJ + ws_r0;
+        ws_need1 = ws_two;
+      }
+    }
 #pragma unroll
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int pl = 0; pl < C::NPL; ++pl) {
         const bool implicit = kToep && op == TOP;
+        if constexpr (WS) {
+          if (implicit) {
+            // (entries outside the table can only sit in slots no fragment reads -- the unused head / tail of a region --
+            // but the address must stay inside the allocation: clamp)
+            if (wave < 3) {
+              const unsigned dst = lds_base + buf * C::STAGE + tile_off(op, pl) + wave * 1024;
+              dma1k(tab[pl], (unsigned)min(max(ws_tsl[0] + ws_soff[0], 0), ws_nent - 1) * 16u, dst);
+              if (ws_need1) dma1k(tab[pl], (unsigned)min(max(ws_tsl[1] + ws_soff[1], 0), ws_nent - 1) * 16u, dst + C::WIN_REG * 16);
+            }
+            continue;
+          }
+        }
         const char* s0 = (OPS == kOpsAWin && op == 0)
                              ? src[op * C::NPL + pl] + (size_t)wk_off * a.win_pitch + wk_ck * (C::BK * 2)
                              : src[op * C::NPL + pl] + (size_t)(kt0 + kt) * (C::BK * 2);     // scalar
@@ -330,7 +415,17 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
                 lds_base + 2 * C::STAGE + (buf * C::NPL + pl) * C::RAG_TILE + wave * 1024);
       }
     }
-    if constexpr (kToep) toep_advance();
+    if constexpr (WS) {
+      if constexpr (kHuRows) {
+        ws_r0 += 8;
+        if (ws_r0 >= tT8) ws_r0 -= tT8, ++ws_q0;
+      } else {
+        ws_r0 += 64;
+        if (ws_r0 >= tL) ws_r0 -= tL, ++ws_q0;
+      }
+    } else if constexpr (kToep) {
+      toep_advance();
+    }
     if constexpr (OPS == kOpsAWin) win_advance();
   };
   (void)TP; (void)KPP;
@@ -354,26 +449,39 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   __syncthreads();
   // one k-tile; the staging buffer index is a compile-time constant (the loop below is unrolled by two), so every LDS
   // address of the fragment reads and of the DMA destinations is a register base plus an immediate
-  auto k_tile = [&](int kt, auto bufc) {
+  auto k_body = [&](int kt, auto bufc, auto strc) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
+    constexpr bool STR = decltype(strc)::value;   // WS, rows (b,l): this k-tile crosses an r boundary (second window region)
+    const int qs_cur = buf ? ws_qs1 : ws_qs0;
     if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
     const char* sb = smem + buf * C::STAGE;
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
     u32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
-    auto load_frags = [&](int ks, int fb) {
+    auto load_frags = [&](int ks, int fb) __attribute__((always_inline)) {
       const int so = ((2 * ks + hl) << 4) ^ swz;          // row-major tile: 128-byte rows, XOR-swizzled 16-byte slots
+      // window staging: lane base + an immediate per k-step (two chunks = 256 bytes of slots), + the second region for the
+      // chunks behind the r boundary of a straddling k-tile
+      int wo = 0;
+      if constexpr (WS) {
+        wo = kHuRows ? (3 - ks) * 256 : ks * 256;
+        if constexpr (STR) wo += (2 * ks + hl >= qs_cur) ? C::WIN_REG * 16 : 0;
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
+        int ao;
+        if constexpr (WS && TOP == 0) ao = ws_base[i] + wo;
+        else ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
         ah[fb][i] = ld16(sb + ao);
-        if constexpr (X3) al[fb][i] = ld16(sb + C::A_TILE + ao);
+        if constexpr (X3) al[fb][i] = ld16(sb + C::A_BYTES + ao);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16
-                                                           : b_rowoff + i * 4096 + so;
-        bh[fb][i] = ld16(sb + C::NPL * C::A_TILE + bo);
-        if constexpr (X3) bl[fb][i] = ld16(sb + C::NPL * C::A_TILE + C::B_TILE + bo);
+        int bo;
+        if constexpr (WS && TOP == 1) bo = ws_base[i] + wo;
+        else bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16
+                                                      : b_rowoff + i * 4096 + so;
+        bh[fb][i] = ld16(sb + C::NPL * C::A_BYTES + bo);
+        if constexpr (X3) bl[fb][i] = ld16(sb + C::NPL * C::A_BYTES + C::B_BYTES + bo);
       }
     };
     load_frags(0, 0);
@@ -412,13 +520,14 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         // tiles' XOR swizzle, the implicit operand's tile is chunk-major (no swizzle)
         const int r16 = lane & 15, g4 = lane >> 4;
         const char* rt = smem + 2 * C::STAGE + buf * C::NPL * C::RAG_TILE;
-        const char* it = sb + (TOP == 0 ? 0 : C::NPL * C::A_TILE);
-        constexpr int IT_PLANE = TOP == 0 ? C::A_TILE : C::B_TILE;
+        const char* it = sb + (TOP == 0 ? 0 : C::NPL * C::A_BYTES);
+        constexpr int IT_PLANE = TOP == 0 ? C::A_BYTES : C::B_BYTES;
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const int q = 4 * ks2 + g4;
           const int eo = r16 * 128 + ((q ^ ((r16 >> 1) & 7)) << 4);
-          const int io = (q * TROWS + rag_sub0 + r16) * 16;
+          int io = (q * TROWS + rag_sub0 + r16) * 16;
+          if constexpr (WS) io = (rag_sub0 + r16 + 56 - 8 * q) * 16 + ((STR && q >= qs_cur) ? C::WIN_REG * 16 : 0);
           const u32x4 eh = ld16(rt + eo), ih = ld16(it + io);
           // D[m][n] = sum_k A[m][k] B[n][k]: B_HU -> the ragged rows are rows of A; A_HU -> rows of B
           if constexpr (X3) {
@@ -432,6 +541,15 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed (this wave's share of it)
     __syncthreads();
+  };
+  auto k_tile = [&](int kt, auto bufc) __attribute__((always_inline)) {
+    if constexpr (WS && kHuRows) {
+      if (__builtin_amdgcn_readfirstlane(decltype(bufc)::value ? ws_qs1 : ws_qs0) < 8) {
+        k_body(kt, bufc, std::true_type{});
+        return;
+      }
+    }
+    k_body(kt, bufc, std::false_type{});
   };
   {
     int kt = 0;
@@ -584,15 +702,15 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
   }
 }
 
-template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16, bool ND = false>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16, bool ND = false, bool WS = false>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
-  using C = GemmCfg<X3, SH>;
+  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1)>;
   constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
   constexpr bool kRag = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256;
   constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT, ND>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT, ND, WS>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -612,5 +730,19 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
 
 // f16 != 0: fp16 operand planes / window tables and fp16 ratio planes (single plane; the beta == 1 NMFD path)
 int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s);
+// the same combinations with the implicit operand staged as a window of table entries (WS; nmfmu_nmfd_ws.hip); the caller
+// (nmfmu_gemm) has checked gemm_window_stageable()
+int launch_gemm_ws(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s);
+// Shapes the window staging serves: one shift axis, 128 x 128 tiles, the implicit operand's rows and k extent exactly
+// the logical ones (no padding rows, no dead k-chunks inside any tile), and line lengths that keep a tile inside one
+// batch entry: rows (b,l): L % 128 == 0, T >= 64, k_len == R T;  rows (r,t): rows == R T (a multiple of 128), T >= 128,
+// L % 64 == 0, k_len == B L.
+inline bool gemm_window_stageable(int ops, const GemmArgs& a) {
+  if (a.koff || (ops != kOpsBHu && ops != kOpsBHuT && ops != kOpsAHu)) return false;
+  const int64_t L = (int64_t)a.tLh + a.tT - 1, bl = (int64_t)a.tB * L, rt = (int64_t)a.tR * a.tT;
+  const int rows = ops == kOpsAHu ? a.m_pad : a.n_pad;
+  if (ops == kOpsBHuT) return rows == rt && rt % 128 == 0 && a.tT >= 128 && L % 64 == 0 && a.k_len == bl;
+  return rows == bl && L % 128 == 0 && a.tT >= 64 && a.k_len == rt && rt % 64 == 0;
+}
 
 }  // namespace nmfmu

@@ -1000,7 +1000,8 @@ int nmfmu_gemm_f16_supported(float beta, int epilogue, int ops) {
   }
 }
 
-int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
+// descriptor -> kernel arguments (everything nmfmu_gemm validates); NMFMU_OK or the error nmfmu_gemm returns
+static int gemm_prepare(const nmfmu_gemm_desc* d, int epilogue, GemmArgs& a, int& x3, int& kind, int& f16) {
   if (!d || !d->a_hi || !d->b_hi) return NMFMU_ERR_ARG;
   // tiles are 128 x 128, except: the window-operand GEMM has narrow-N tiles (N = rank), and implicit operands with several
   // shift axes take a 64-row (B_HU / B_HUT) resp. 64-column (A_HU) tile when the channel side is exactly 64
@@ -1009,10 +1010,10 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   const int m_mult = (nd_ops && d->ops != NMFMU_OPS_A_HU && d->m_pad == 64) ? 64 : 128;
   if (d->m_pad <= 0 || d->n_pad <= 0 || d->k_pad <= 0 || d->m_pad % m_mult || d->n_pad % n_mult || d->k_pad % 128)
     return NMFMU_ERR_ARG;
-  const int x3 = d->precision == NMFMU_PREC_BF16X3, f16 = d->precision == NMFMU_PREC_F16;
+  x3 = d->precision == NMFMU_PREC_BF16X3, f16 = d->precision == NMFMU_PREC_F16;
   if (x3 && (!d->a_lo || !d->b_lo)) return NMFMU_ERR_ARG;
-  const int kind = nmfmu_beta_kind(d->beta);
-  GemmArgs a{};
+  kind = nmfmu_beta_kind(d->beta);
+  a = GemmArgs{};
   a.a_hi = (const uint16_t*)d->a_hi, a.a_lo = (const uint16_t*)d->a_lo;
   a.b_hi = (const uint16_t*)d->b_hi, a.b_lo = (const uint16_t*)d->b_lo;
   a.m_pad = d->m_pad, a.n_pad = d->n_pad, a.k_pad = d->k_pad;
@@ -1101,7 +1102,30 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   if (d->tile_rows != 0 && d->tile_rows != 128) return NMFMU_ERR_UNSUPPORTED;   // (the 256 x 256 tile of ABI 3 is gone)
   a.ldn = d->n_ld ? d->n_ld : d->n_pad;
   if (a.ldn < d->n_pad || (a.ldn != d->n_pad && epilogue == NMFMU_EPI_FOLD)) return NMFMU_ERR_ARG;
-  const int rc = launch_gemm(x3, epilogue, kind, d->ops, f16, a, S(stream));
+  if (d->stage_mode != 0 && d->stage_mode != 1) return NMFMU_ERR_ARG;
+  return NMFMU_OK;
+}
+
+// window staging of the implicit operand (nmfmu_gemm.h: WS): automatic where the shape allows it
+static bool gemm_takes_window(const nmfmu_gemm_desc* d, int epilogue, const GemmArgs& a) {
+  return d->stage_mode == 0 && epilogue != NMFMU_EPI_FOLD && d->ops != NMFMU_OPS_PLANES && d->ops != NMFMU_OPS_A_WIN &&
+         gemm_window_stageable(d->ops, a);
+}
+
+int nmfmu_gemm_window_staged(const nmfmu_gemm_desc* d, int epilogue) {
+  GemmArgs a;
+  int x3, kind, f16;
+  const int rc = gemm_prepare(d, epilogue, a, x3, kind, f16);
+  return rc ? rc : (gemm_takes_window(d, epilogue, a) ? 1 : 0);
+}
+
+int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
+  GemmArgs a;
+  int x3, kind, f16;
+  int rc = gemm_prepare(d, epilogue, a, x3, kind, f16);
+  if (rc) return rc;
+  rc = gemm_takes_window(d, epilogue, a) ? launch_gemm_ws(x3, epilogue, kind, d->ops, f16, a, S(stream))
+                                         : launch_gemm(x3, epilogue, kind, d->ops, f16, a, S(stream));
   return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 

@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
                 ('t_taps', C.c_int32), ('t_lh', C.c_int32), ('tile_rows', C.c_int32), ('n_ld', C.c_int32), ('k_len', C.c_int32), ('k_split', C.c_int32),
                 ('tail_rows', C.c_int32), ('rag_c0', C.c_int32), ('rag_channels', C.c_int32),
                 ('win_nd', C.c_int32), ('win_lh', C.c_int32 * 3), ('win_taps', C.c_int32 * 3), ('win_channels', C.c_int32),
-                ('win_pitch', C.c_int32), ('win_fold', C.c_int32), ('t_koff', C.c_void_p)]
+                ('win_pitch', C.c_int32), ('win_fold', C.c_int32), ('t_koff', C.c_void_p), ('stage_mode', C.c_int32)]
 
 
 ABI_VERSION = 8   # include/nmfmu.h: NMFMU_ABI_VERSION
@@ -105,6 +105,7 @@ SIGNATURES = {
     'nmfmu_reconstruct': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p]),
     'nmfmu_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    'nmfmu_gemm_window_staged': (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
     'nmfmu_pack2d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_convnd_unfold': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

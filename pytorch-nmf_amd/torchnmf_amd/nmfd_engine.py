@@ -98,6 +98,7 @@ class ConvMU(AsyncLossMixin):
         # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM): none of the paths that fuse this engine's
         # own update into a GEMM's neighbours (fold parts, fused sums, ragged channels), split bf16 unless told otherwise
         self.lib = _capi.load()
+        self.staged = {}          # tag of a GEMM launch -> nmfmu_gemm_window_staged() of its descriptor
         if not torch.cuda.is_available():
             raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
         # NMFD has one shift axis, NMF2D / NMF3D two / three (nmf.py:700-942); flattened they are the same problem
@@ -348,7 +349,12 @@ class ConvMU(AsyncLossMixin):
         if ops != _capi.OPS_PLANES and self.nd > 1:
             d.win_nd, d.win_lh, d.win_taps = self.nd, (C.c_int32 * 3)(*self.lhs), (C.c_int32 * 3)(*self.ts)
             d.t_koff = self.koff[ops].data_ptr()
+        # implicit operands are staged as a window of table entries wherever the library's shape test admits it (round 5);
+        # TORCHNMF_AMD_NMFD_WINSTAGE=0 keeps the chunk-major tiles of rounds 1-4 (A/B switch; bit-identical results)
+        d.stage_mode = 1 if os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1') == '0' else 0
         timer = getattr(self, 'timer', None) if tag else None
+        if tag and tag not in self.staged:       # which launches stage their implicit operand as a window (host-side query, once)
+            self.staged[tag] = int(self.lib.nmfmu_gemm_window_staged(C.byref(d), epi))
         if timer is not None:
             timer.mark(tag + '<')
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')

@@ -12,6 +12,8 @@ Tolerances (relative Frobenius error unless stated):
   * bf16 (operands carry 8 significant bits): factors are compared at 5e-3 .. 2e-2 and the objective (loss) at 2e-3;
     this mode is NOT claimed to meet 1e-4 on the factors and nothing selects it implicitly.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -2246,3 +2248,66 @@ def test_nmfd_cfg4_full_size(dev):
         ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
         print(f'configs[3] full size, {prec}: relW={ew:.2e} relH={eh:.2e}')
         assert ew < tol and eh < tol, (prec, ew, eh)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Round 5: window staging of the implicit Toeplitz operand (csrc/nmfmu_gemm.h, WS) -- the NMFD GEMMs move 19 instead of
+# 32 LDS-DMA pieces per k-tile.  The staged launches feed the MFMAs the same operands in the same order, so the whole
+# iteration must agree with the chunk-major path BIT FOR BIT; the oracle comparison rides on the existing NMFD tests
+# (configs[3] at full size takes the staged path: test_nmfd_cfg4_full_size).
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,Cc,L,R,T,staged', [
+    (2, 129, 384, 4, 160, dict(recon_w=1, num_w=1, recon_h=1)),     # rows (b,l) and rows (r,t) staged; T8 = 20: r boundaries mid k-tile
+    (1, 140, 256, 8, 64, dict(recon_w=1, num_w=0, recon_h=1)),      # T = 64: boundaries on k-tile edges; rows (r,t) need T >= 128
+    (1, 70, 256, 8, 136, dict(recon_w=1, num_w=0, recon_h=1)),      # T8 = 17 (odd): a boundary between the two halves of a k-step
+    (3, 33, 128, 16, 72, dict(recon_w=1, num_w=0, recon_h=1)),      # T8 = 9, three batch entries of one tile each
+    (1, 64, 320, 2, 192, dict(recon_w=0, num_w=1, recon_h=0)),      # L % 128 != 0: only the rows-(r,t) operand is staged; tiles spanning two r
+    (1, 1025, 1024, 2, 128, dict(recon_w=1, num_w=1, recon_h=1)),   # ragged 1025th channel inside the staged reconstruction GEMMs
+])
+@pytest.mark.parametrize('prec,beta', [('bf16x3', 1.0), ('f16', 1.0), ('bf16', 1.0), ('bf16x3', 0.5), ('bf16', 2.0)])
+def test_nmfd_window_staging_is_bit_identical(dev, B, Cc, L, R, T, staged, prec, beta):
+    from torchnmf_amd.nmfd_engine import ConvMU
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    V = (torch.rand(B, Cc, L, generator=g) + 1e-3).to(dev)
+    W0 = torch.randn(Cc, R, T, generator=g).abs()
+    H0 = torch.randn(B, R, L - T + 1, generator=g).abs()
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['TORCHNMF_AMD_NMFD_WINSTAGE'] = mode
+        try:
+            W, H = W0.clone().to(dev), H0.clone().to(dev)
+            try:
+                eng = ConvMU(V, W, H, beta, precision=prec)
+            except ValueError:
+                pytest.skip('fp16 planes are not built for this shape')
+            for _ in range(2):
+                eng.w_step()
+                eng.h_step()
+            loss = eng.divergence()
+            torch.cuda.synchronize()
+            res[mode] = (W.cpu(), H.cpu(), loss, dict(eng.staged))
+        finally:
+            os.environ.pop('TORCHNMF_AMD_NMFD_WINSTAGE', None)
+    got = {k: v for k, v in res['1'][3].items() if k in staged}
+    assert got == staged, got
+    assert all(v == 0 for v in res['0'][3].values())
+    assert torch.isfinite(res['1'][0]).all() and torch.isfinite(res['1'][1]).all()
+    assert torch.equal(res['1'][0], res['0'][0]) and torch.equal(res['1'][1], res['0'][1]) and res['1'][2] == res['0'][2]
+
+
+def test_nmfd_window_staging_against_oracle(dev):
+    """One staged shape end to end against the oracle (split bf16, three iterations): both operand forms, r boundaries
+    inside k-tiles and inside tile rows."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMFD
+    g = torch.Generator().manual_seed(55)
+    B, Cc, L, R, T = 2, 129, 384, 4, 160
+    V = torch.rand(B, Cc, L, generator=g) + 1e-3
+    W0, H0 = torch.randn(Cc, R, T, generator=g).abs(), torch.randn(B, R, L - T + 1, generator=g).abs()
+    m = NMFD(W=W0, H=H0).to(dev)
+    assert m.fit(V.to(dev), 1, NO_STOP, 3, precision='bf16x3') == 3
+    Wr, Hr = W0, H0
+    for _ in range(3):
+        Wr = O.nmfd_w_step(V, Wr, Hr, 1, 1.0)
+        Hr = O.nmfd_h_step(V, Wr, Hr, 1, 1.0)
+    assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL

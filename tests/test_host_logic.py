@@ -170,8 +170,35 @@ def test_static_queries_of_the_gemm_engine():
     assert lib.nmfmu_gemm_f16_supported(2.0, E.EPI_FOLD, O.OPS_PLANES) == 1         # beta-independent epilogues
     # descriptor layout: 12 pointers / 64-bit slots first, then int32 fields (header order)
     d = _capi.GemmDesc()
-    assert [f[0] for f in d._fields_][-14:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels',
-                                                'win_nd', 'win_lh', 'win_taps', 'win_channels', 'win_pitch', 'win_fold', 't_koff']
+    assert [f[0] for f in d._fields_][-15:] == ['tile_rows', 'n_ld', 'k_len', 'k_split', 'tail_rows', 'rag_c0', 'rag_channels',
+                                                'win_nd', 'win_lh', 'win_taps', 'win_channels', 'win_pitch', 'win_fold', 't_koff',
+                                                'stage_mode']
+    # window staging of an implicit operand (round 5, ABI 8): the library's shape test, host only.  configs[3] -- 1025 bins,
+    # 8192 frames, rank 8, 400 taps: both reconstructions (the GEMM runs over the 1024 whole channels), the loss and the W
+    # numerator qualify; stage_mode = 1 keeps the chunk-major tiles; padding inside the implicit operand's tiles disqualifies
+    import ctypes as C
+    one = C.c_char_p(b'x')       # any non-null pointers: nothing is dereferenced by the query
+
+    def desc(ops, m_pad, n_pad, k_pad, B, R, T, Lh, precision=_capi.PREC_BF16, **kw):
+        p = C.cast(one, C.c_void_p)
+        dd = _capi.GemmDesc(p, p, p, p, m_pad, n_pad, k_pad, precision, 1.0, p, p, p, p, p, p, 0, 0, ops, B, R, T, Lh, 128, 0, 0, 0, 0, 0, 0)
+        for k, v in kw.items():
+            setattr(dd, k, v)
+        return dd
+    q = lambda dd, epi: lib.nmfmu_gemm_window_staged(C.byref(dd), epi)
+    assert q(desc(O.OPS_B_HU, 1024, 8192, 3200, 1, 8, 400, 7793), E.EPI_RATIO) == 1
+    assert q(desc(O.OPS_A_HU, 8192, 1024, 3200, 1, 8, 400, 7793), E.EPI_RATIO) == 1
+    assert q(desc(O.OPS_B_HU, 1024, 8192, 3200, 1, 8, 400, 7793), E.EPI_LOSS) == 1
+    assert q(desc(O.OPS_B_HUT, 1152, 3200, 8192, 1, 8, 400, 7793, k_split=2), E.EPI_F32) == 1
+    assert q(desc(O.OPS_B_HU, 1024, 8192, 3200, 1, 8, 400, 7793, stage_mode=1), E.EPI_RATIO) == 0
+    assert q(desc(O.OPS_B_HU, 1024, 8192, 3200, 1, 8, 400, 7793, stage_mode=2), E.EPI_RATIO) == _capi.ERR_ARG
+    assert q(desc(O.OPS_B_HU, 128, 8320, 3200, 1, 8, 400, 7800 + 121), E.EPI_RATIO) == 1      # L = 8320 = 65 tiles
+    assert q(desc(O.OPS_B_HU, 128, 8064, 3200, 1, 8, 400, 7601), E.EPI_RATIO) == 0            # L = 8000: padding rows in the last tile
+    assert q(desc(O.OPS_B_HU, 128, 256, 512, 1, 8, 56, 201), E.EPI_RATIO) == 0                # fewer than 64 taps
+    assert q(desc(O.OPS_B_HU, 128, 256, 640, 1, 5, 104, 153), E.EPI_RATIO) == 0               # R T = 520: a dead k-chunk in the last k-tile
+    assert q(desc(O.OPS_B_HUT, 128, 640, 256, 1, 8, 72, 185), E.EPI_F32) == 0                 # rows (r,t) need >= 128 taps
+    assert q(desc(O.OPS_B_HUT, 128, 1152, 384, 1, 8, 136, 249), E.EPI_F32) == 0               # R T = 1088: padding rows
+    assert q(desc(O.OPS_PLANES, 128, 128, 128, 1, 8, 400, 7793), E.EPI_F32) == 0
     # ragged channels inside the GEMM grid: eight workgroups share out a tile's frames -> >= 8 tiles of the explicit operand
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_B_HU, 1024, 8192, 1) == 1           # configs[3], W half-step
     assert lib.nmfmu_gemm_ragged_supported(O.OPS_A_HU, 8192, 1024, 1) == 1           # ... H half-step

@@ -307,3 +307,143 @@ def test_h_update_blocks_rewrite_the_window_tables(B, R, T, Lh):
     assert (stored == 1).all()
     np.testing.assert_array_equal(rev, rev_want)
     np.testing.assert_array_equal(fwd, fwd_want)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Window staging of the implicit Toeplitz operand (round 5; csrc/nmfmu_gemm.h, template flag WS): a k-tile's implicit
+# operand reaches LDS as the window of DISTINCT table entries it touches (two regions of 192 slots) instead of a
+# chunk-major 8 x 128 tile.  The mirror below follows the kernel statement by statement -- per-thread slot entries ws_tsl,
+# the per-k-tile scalar offsets / region-1 rule of stage_issue, the lane bases ws_base and the k-step immediates of
+# load_frags -- and every fragment (row, chunk) of every k-tile must name the table entry whose window IS the operand:
+#   rows (b,l), k = (r,t): reversed window at j = l - t of line (b, r)   (Hu[(b,l)][(r,t..t+7)]  = H[b][r][l-t .. l-t-7])
+#   rows (r,t), k = (b,l): forward  window at j = l - t of line (b, r)   (HuT[(r,t)][(b,l..l+7)] = H[b][r][l-t .. l-t+7])
+# with the table layout of nmfmu_conv_tables: entry 1 + (b R + r) JJ + j + (T - 1), JJ = Lh + 2 T - 2.
+# ----------------------------------------------------------------------------------------------------------------------
+WIN_REG = 192
+
+
+def ws_stageable(ops, B, R, T, Lh, rows, k_len):
+    """gemm_window_stageable()."""
+    L = Lh + T - 1
+    if ops == 'B_HUT':
+        return rows == R * T and (R * T) % 128 == 0 and T >= 128 and L % 64 == 0 and k_len == B * L
+    return rows == B * L and L % 128 == 0 and T >= 64 and k_len == R * T and (R * T) % 64 == 0
+
+
+def ws_emulate_tile(ops, B, R, T, Lh, tile, kt0, ktiles):
+    """For tile `tile` of the implicit operand (128 rows) and k-tiles kt0 .. kt0 + ktiles - 1: yields (kt, row, q, entry) for
+    every fragment the MFMAs consume, `entry` = what sits in the LDS slot the lane reads (the kernel's arithmetic)."""
+    hu_rows = ops != 'B_HUT'
+    L, JJ, T8 = Lh + T - 1, Lh + 2 * T - 2, T // 8
+    nent = 1 + B * R * JJ
+    row0 = tile * 128
+    u = np.arange(256)                                   # tid; waves 0-2 (u < 192) issue
+    if hu_rows:
+        b, l0 = divmod(row0, L)
+        tsl = [b * R * JJ + l0 + T - 1 + (u - 56)] * 2
+        q0, r0 = divmod(kt0 * 8, T8)
+        two = False
+    else:
+        rr, t0 = divmod(row0, T)
+        n0 = min(128, T - t0)
+        n1 = 128 - n0
+        two = n1 > 0
+        tsl = [rr * JJ - t0 - n0 + T + u, (rr + 1) * JJ - n1 + T + u]
+        q0, r0 = divmod(kt0 * 64, L)
+    for kt in range(kt0, kt0 + ktiles):
+        # ---- stage_issue
+        lds = np.full(2 * WIN_REG, -1, dtype=np.int64)   # slot -> table entry (-1: never written in this stage)
+        if hu_rows:
+            qs = T8 - r0
+            need1 = qs < 8
+            soff = [1 + q0 * JJ - 8 * r0, 1 + (q0 + 1) * JJ + 8 * qs]
+            qs_cur = qs if need1 else 8
+        else:
+            soff = [1 + q0 * R * JJ + r0] * 2
+            need1, qs_cur = two, 8
+        lds[:WIN_REG] = np.clip(tsl[0][:WIN_REG] + soff[0], 0, nent - 1)
+        if need1:
+            lds[WIN_REG:] = np.clip(tsl[1][:WIN_REG] + soff[1], 0, nent - 1)
+        # ---- load_frags: every lane (j, hl) of every 32-row block, every k-step
+        for row in range(128):
+            for ks in range(4):
+                for hl in range(2):
+                    q = 2 * ks + hl
+                    if hu_rows:
+                        base = row * 16 + 128 - 128 * hl
+                        wo = (3 - ks) * 256 + (WIN_REG * 16 if q >= qs_cur else 0)
+                    else:
+                        seg = row >= n0
+                        rl, ng = (row - n0, n1) if seg else (row, n0)
+                        base = ((ng - 1 - rl) + (WIN_REG if seg else 0) + 8 * hl) * 16
+                        wo = ks * 256
+                    addr = base + wo
+                    assert addr % 16 == 0 and 0 <= addr < 2 * WIN_REG * 16
+                    yield kt, row, q, int(lds[addr // 16])
+        # ---- advance
+        if hu_rows:
+            r0 += 8
+            if r0 >= T8:
+                r0 -= T8
+                q0 += 1
+        else:
+            r0 += 64
+            if r0 >= L:
+                r0 -= L
+                q0 += 1
+
+
+@pytest.mark.parametrize('ops,B,R,T,Lh,kt0', [
+    ('B_HU', 1, 8, 400, 7793, 0),        # BASELINE configs[3]: L = 8192, R T = 3200; k-tiles straddle r at 384 + 16
+    ('B_HU', 1, 8, 400, 7793, 25),       # the second half of a contraction split in two
+    ('A_HU', 2, 3, 64, 193, 0),          # T = 64: every r boundary sits on a k-tile boundary, two batch entries
+    ('B_HU', 3, 8, 72, 57, 0),           # T8 = 9 (odd): boundaries inside a k-step (hl halves in different regions); L = 128
+    ('A_HU', 1, 16, 88, 297, 2),         # T8 = 11, L = 384, R T = 1408 = 22 k-tiles
+    ('B_HU', 1, 5, 104, 281, 3),         # T8 = 13, L = 384, R T = 520 is not a multiple of 64 -> not stageable (checked below)
+    ('B_HUT', 1, 8, 400, 7793, 0),       # configs[3] W numerator: rows (r,t) 3200 = 25 tiles, tiles 3, 6, .. span two r
+    ('B_HUT', 2, 3, 128, 65, 0),         # T = 128: one r per tile, L = 192: k-tiles stay inside a batch entry
+    ('B_HUT', 2, 2, 192, 129, 2),        # T = 192: every second tile spans two r; L = 320
+])
+def test_window_staging_index_algebra(ops, B, R, T, Lh, kt0):
+    L, JJ = Lh + T - 1, Lh + 2 * T - 2
+    hu_rows = ops != 'B_HUT'
+    rows, k_len = (B * L, R * T) if hu_rows else (R * T, B * L)
+    if not ws_stageable(ops, B, R, T, Lh, rows, k_len):
+        assert (R * T) % 64 != 0          # the one deliberately inadmissible case of the list
+        return
+    ktiles_all = k_len // 64
+    tiles = sorted({0, 1, rows // 128 // 2, rows // 128 - 1})
+    for tile in tiles:
+        n = 0
+        for kt, row, q, entry in ws_emulate_tile(ops, B, R, T, Lh, tile, kt0, min(ktiles_all - kt0, 9)):
+            m, k = tile * 128 + row, kt * 64 + 8 * q
+            if hu_rows:                                 # row (b,l), chunk (r, t .. t+7): reversed window at j = l - t
+                (b, l), (r, t) = divmod(m, L), divmod(k, T)
+            else:                                       # row (r,t), chunk (b, l .. l+7): forward window at j = l - t
+                (r, t), (b, l) = divmod(m, T), divmod(k, L)
+            assert b < B and r < R
+            assert entry == 1 + (b * R + r) * JJ + (l - t) + (T - 1), (ops, tile, kt, row, q)
+            n += 1
+        assert n == min(ktiles_all - kt0, 9) * 128 * 8
+
+
+def test_window_staging_matches_the_chunk_major_index():
+    """The same entries as toep_index() of the chunk-major path (trow + soff), i.e. the two staging forms feed the MFMAs
+    identical operands: bit-identical GEMM results."""
+    B, R, T, Lh = 1, 8, 400, 7793
+    L, JJ, T8 = Lh + T - 1, Lh + 2 * T - 2, T // 8
+    for ops in ('B_HU', 'B_HUT'):
+        for kt, row, q, entry in ws_emulate_tile(ops, B, R, T, Lh, 5, 4, 4):
+            m = 5 * 128 + row
+            kc = kt * 8 + q
+            if ops == 'B_HU':
+                b, l = divmod(m, L)
+                trow = b * R * JJ + l + T - 1
+                kq, kr = divmod(kc, T8)
+                soff = 1 + kq * JJ - 8 * kr
+            else:
+                r, t = divmod(m, T)
+                trow = r * JJ - t + T - 1
+                kq, kr = divmod(kc * 8, L)
+                soff = 1 + kq * R * JJ + kr
+            assert entry == trow + soff

@@ -32,3 +32,10 @@ if d.get('nmfd'):
 if d.get('nmf2d'):
     n = d['nmf2d']
     print(f"  nmf2d ({n['dtype']}): {n['iters_per_s']:.0f} it/s {n['ms_per_step']} ms; per gemm {n['roofline'].get('per_gemm')}; parity {(n.get('parity') or {}).get('modes')}; fit loop {(n.get('fit') or {}).get('iters_per_s_loop')} it/s")
+r = d.get('roofline') or {}
+if r.get('ceiling'):
+    c = r['ceiling']
+    print(f"  ceiling: with stream {c['with_stream']}, mfma only {c['mfma_only']}; frac_of_ceiling {r.get('frac_of_ceiling')}; traffic {r.get('traffic')} ({(r.get('traffic_source') or '')[:80]})")
+if d.get('ref_notebook'):
+    for b, e in d['ref_notebook']['betas'].items():
+        print(f"  ref_notebook beta={b}: auto {e['auto']} | f16x {e['f16x_forced']} | cpu port {e.get('cpu_port_s_per_iter')} s/it | notebook {e['notebook_context_s_per_iter']}")
