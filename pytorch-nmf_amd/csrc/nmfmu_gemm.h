@@ -453,10 +453,19 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
     constexpr int buf = decltype(bufc)::value;
     constexpr bool STR = decltype(strc)::value;   // WS, rows (b,l): this k-tile crosses an r boundary (second window region)
     const int qs_cur = buf ? ws_qs1 : ws_qs0;
+#ifdef NMFMU_GEMM_ABL_NODMA   // timing-only ablation (wrong results): no LDS-DMA in the loop, every k-tile multiplies stale LDS
+    (void)0;
+#else
     if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
+#endif
     const char* sb = smem + buf * C::STAGE;
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
     u32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+#ifdef NMFMU_GEMM_ABL_NOFRAG   // timing-only ablation (wrong results): no fragment reads, the MFMAs take whatever the registers hold
+    auto ldf = [&](const char*) __attribute__((always_inline)) { u32x4 r; asm volatile("" : "=v"(r)); return r; };
+#else
+    auto ldf = [&](const char* p_) __attribute__((always_inline)) { return ld16(p_); };
+#endif
     auto load_frags = [&](int ks, int fb) __attribute__((always_inline)) {
       const int so = ((2 * ks + hl) << 4) ^ swz;          // row-major tile: 128-byte rows, XOR-swizzled 16-byte slots
       // window staging: lane base + an immediate per k-step (two chunks = 256 bytes of slots), + the second region for the
@@ -471,8 +480,8 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         int ao;
         if constexpr (WS && TOP == 0) ao = ws_base[i] + wo;
         else ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
-        ah[fb][i] = ld16(sb + ao);
-        if constexpr (X3) al[fb][i] = ld16(sb + C::A_BYTES + ao);
+        ah[fb][i] = ldf(sb + ao);
+        if constexpr (X3) al[fb][i] = ldf(sb + C::A_BYTES + ao);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -480,8 +489,8 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
         if constexpr (WS && TOP == 1) bo = ws_base[i] + wo;
         else bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16
                                                       : b_rowoff + i * 4096 + so;
-        bh[fb][i] = ld16(sb + C::NPL * C::A_BYTES + bo);
-        if constexpr (X3) bl[fb][i] = ld16(sb + C::NPL * C::A_BYTES + C::B_BYTES + bo);
+        bh[fb][i] = ldf(sb + C::NPL * C::A_BYTES + bo);
+        if constexpr (X3) bl[fb][i] = ldf(sb + C::NPL * C::A_BYTES + C::B_BYTES + bo);
       }
     };
     load_frags(0, 0);
@@ -497,7 +506,11 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
             acc[mi][ni] = mfma_bf16(al[fb][mi], bh[fb][ni], acc[mi][ni]);
             acc[mi][ni] = mfma_bf16(ah[fb][mi], bl[fb][ni], acc[mi][ni]);
           }
+#ifdef NMFMU_GEMM_ABL_NOMFMA  // timing-only ablation: fragment reads kept alive, no matrix instructions
+          asm volatile("" ::"v"(ah[fb][mi]), "v"(bh[fb][ni]));
+#else
           acc[mi][ni] = mfma_op<OPT>(ah[fb][mi], bh[fb][ni], acc[mi][ni]);
+#endif
         }
     }
     {
@@ -540,7 +553,9 @@ __global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed (this wave's share of it)
+#ifndef NMFMU_GEMM_ABL_NOBAR   // (timing-only ablation: no barrier in the loop)
     __syncthreads();
+#endif
   };
   auto k_tile = [&](int kt, auto bufc) __attribute__((always_inline)) {
     if constexpr (WS && kHuRows) {

@@ -308,12 +308,14 @@ class ConvMU(AsyncLossMixin):
         # better; the apply kernel adds the partials (beta == 1 fused-sums path only)
         tiles = (cp // 128) * (rpp // 128)
         self.w_ksplit = 1
+        # (k-tiles of that GEMM's contraction as _gemm runs it: the logical B L rounded up to 64 on implicit operands)
+        kt_w = (-(-(B * L) // 64)) if (self.implicit and nd == 1) else blp // 64
         if os.environ.get('TORCHNMF_AMD_NMFD_KSPLIT', '1') != '0':
             if self.fused_sums:
-                self.w_ksplit = 2 if (tiles <= 256 and (blp // 64) % 2 == 0 and blp >= 2048) else 1
+                self.w_ksplit = 2 if (tiles <= 256 and kt_w % 2 == 0 and blp >= 2048) else 1
             else:
                 slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
-                self.w_ksplit = w_contraction_split(tiles, blp // 64, slots)
+                self.w_ksplit = w_contraction_split(tiles, kt_w, slots)
         self.num_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
         if self.den_w is not None:
             self.den_w = torch.empty(self.w_ksplit * cp * rpp, dtype=torch.float32, device=dev)
@@ -341,6 +343,11 @@ class ConvMU(AsyncLossMixin):
             ops = (_capi.OPS_A_HU if a is self.hu else _capi.OPS_B_HU if b is self.hu else
                    _capi.OPS_B_HUT if b is self.hut else _capi.OPS_PLANES)
         tile = 128
+        if not k_len and ops != _capi.OPS_PLANES and self.nd == 1:
+            # the contraction of an implicit operand runs over its logical extent rounded up to whole k-tiles, not over the
+            # 128-padded pitch of the explicit planes (whose tail is zero): one k-tile less for half of all shapes, and the form
+            # the library's window staging asks for (nmfmu_gemm_window_staged: k_len == the logical extent)
+            k_len = -(-(self.B * self.L if ops == _capi.OPS_B_HUT else self.R * self.T) // 64) * 64
         d = _capi.GemmDesc(_ptr(a.hi), _ptr(a.lo), _ptr(b.hi), _ptr(b.lo), m_pad, n_pad, a.cols_pad,
                            self.precision, self.beta, _ptr(x), _ptr(gn.hi) if gn else None,
                            _ptr(gn.lo) if gn else None, _ptr(gp.hi) if gp else None, _ptr(gp.lo) if gp else None,

@@ -1641,10 +1641,10 @@ def test_betamu_auto_takes_the_1x_modes(dev, exact, rank, beta, want):
     assert trainer.last_precision == want, trainer.last_precision
     ew, eh = rel_err(m.W.data.cpu(), Wn), rel_err(m.H.data.cpu(), Hn)
     assert ew < TOL and eh < TOL, (ew, eh)
-    # the gradient is a difference of two near-equal contractions: compare on the scale of its parts
-    for p, k in ((m.W, 'W'), (m.H, 'H')):
-        scale = float(grads[k].abs().mean()) + 1e-30
-        assert float((p.grad.cpu() - grads[k]).abs().mean()) / scale < 5e-2
+    # p.grad of the LAST parameter (the closure's zero_grad() clears the earlier ones, as in the reference); the gradient is
+    # a difference of two near-equal contractions: compare on the scale of its own magnitude
+    scale = float(grads['H'].abs().mean()) + 1e-30
+    assert float((m.H.grad.cpu() - grads['H']).abs().mean()) / scale < 5e-2
 
 
 def test_betamu_rejects_general_graphs_and_cpu_tensors(dev):
