@@ -51,8 +51,7 @@ legs = {
 }
 out = {'precision': prec, 'shape': f'NMFD 1x{Cc}x{L} rank {R} T {T}', 'winstage': os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1'), 'legs': {}}
 for name, (fn, kmax) in legs.items():
-    ks = [k for k in (kmax // 8, kmax // 4, kmax // 2, 3 * kmax // 4, kmax) if k % 128 == 0 or name == 'num_h']
-    ks = sorted({max(64, k // 128 * 128) for k in ks} | {kmax})
+    ks = sorted({max(128, (kmax * f // 5) // 128 * 128) for f in (1, 2, 3, 4)} | {kmax})
     if name == 'num_h':
         ks = [64, 320, 576, 832, 1088]
     us = [timed(lambda k=k: fn(k)) for k in ks]
