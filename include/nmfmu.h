@@ -347,20 +347,11 @@ typedef struct nmfmu_gemm_desc {
    * nmfmu_convnd_koff(ops, ..., k_pad) -- one int per 8-wide k-chunk.  Needs taps and V extent of the LAST axis to be
    * multiples of 8.  NULL with win_nd <= 1: the one-axis form above (t_taps, t_lh). */
   const int32_t* t_koff;
-  /* (ABI 8, appended) How the GEMMs with an implicit operand (ops B_HU / B_HUT / A_HU, one shift axis) run their k loop.
-   * Three independent choices, all with the same products per output element:
-   *   staging  chunk-major -- the 16 KiB tile of 8 k-chunks x 128 rows of table entries, most entries eight times (ABI <= 7) --
-   *            or WINDOW: the 128 + 56 distinct entries a k-tile touches, 2.9 KiB (19 instead of 32 LDS-DMA pieces per k-tile);
-   *            possible where the implicit operand's tiles hold no padding (nmfmu_gemm_window_staged), single plane or split;
-   *   waves    four 64 x 64 wave tiles, or EIGHT: two groups of four split the k-steps of every k-tile and exchange
-   *            accumulator halves behind the loop (single-plane precisions);
-   *   buffers  two staging buffers (the LDS-DMA of k-tile t + 1 flies while k-tile t is multiplied) or THREE (t + 2; one
-   *            counted wait per k-tile; single-plane precisions; chunk-major only on eight waves: 96 KiB of stages).
-   * 0 = automatic (window where possible, the measured-best of the others); 1 = chunk-major / four / two (the kernel of ABI <= 7);
-   * 2 = window / four / two; 3 = chunk-major / eight / two; 4 = window / eight / two; 5 = window / four / three;
-   * 6 = window / eight / three; 7 = chunk-major / eight / three.  A combination that is not built for the precision or shape
-   * falls back towards mode 1.  Modes 1, 2 and 5 give the same results bit for bit; the eight-wave tile adds each output
-   * element's two k-halves in another order (fp32 rounding, ~1e-7). */
+  /* (ABI 8, appended) How an implicit operand (ops B_HU / B_HUT / A_HU, one shift axis) reaches LDS: 0 = automatic -- as a
+   * sliding WINDOW of the distinct table entries a k-tile touches (128 + 56 entries = 2.9 KiB instead of the 16 KiB of a
+   * chunk-major tile, which holds most entries eight times: 19 instead of 32 LDS-DMA pieces per k-tile) wherever the
+   * implicit operand's tiles hold no padding (nmfmu_gemm_window_staged), chunk-major elsewhere; 1 = chunk-major always
+   * (the form of ABI <= 7; same results bit for bit -- the products and their order are unchanged). */
   int32_t stage_mode;
 } nmfmu_gemm_desc;
 

@@ -81,19 +81,12 @@ enum GemmOps : int { kOpsPlanes = 0, kOpsBHu = 1, kOpsBHuT = 2, kOpsAHu = 3, kOp
 // per MFMA, 52 instead of 27 % MFMA-busy per CU, but at configs[3] it pads 1025 channels to 1280 and leaves 160 / 416
 // workgroups for 256 CUs -- 2 210 instead of 2 650 it/s without a stream-K scheduler; removed in round 3, see the git
 // history of round 2.)
-// KW (round 5): KW groups of WM x WN waves share the tile, group kw multiplying k-steps [kw * 4 / KW, (kw + 1) * 4 / KW) of every
-// k-tile into its own full set of accumulators; the groups exchange halves through LDS behind the loop and each runs the
-// epilogue on its share of the rows.  Same operand bytes per MFMA as KW = 1, twice the waves per SIMD: the k loop of these
-// GEMMs is a chain of latencies (LDS-DMA landing, barrier skew, the first fragment reads of a k-tile) under which the matrix
-// pipe idles -- removing every MFMA from it does not make it faster (profiles/r05c_nmfd_ablations.json).
-template <int WM_, int WN_, int MI_, int NI_, int KW_ = 1>
+template <int WM_, int WN_, int MI_, int NI_>
 struct GemmShape {
-  static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, KW = KW_;
-  static constexpr int BM = WM * MI * 32, BN = WN * NI * 32, THREADS = 64 * WM * WN * KW;
-  static_assert(KW == 1 || (KW == 2 && MI % 2 == 0), "contraction split across two wave groups");
+  static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+  static constexpr int BM = WM * MI * 32, BN = WN * NI * 32, THREADS = 64 * WM * WN;
 };
 using GemmSmall = GemmShape<2, 2, 2, 2>;
-using GemmSmallK2 = GemmShape<2, 2, 2, 2, 2>;   // 128 x 128, eight waves: four 64 x 64 wave tiles x two k halves
 // narrow-N tiles (128 x 32, 128 x 64) for the window-operand GEMM, whose N is the rank
 using GemmN32 = GemmShape<4, 1, 1, 1>;
 using GemmN64 = GemmShape<4, 1, 1, 2>;
@@ -112,9 +105,8 @@ using GemmM64 = GemmShape<1, 4, 2, 1>;
 // 3 (or 6) LDS-DMA pieces per k-tile instead of 16, issued by waves 0-2.  The k loop of this kernel is bound by LDS-DMA issue
 // (DESIGN.md section 3.4): 19 instead of 32 pieces per k-tile.  Requires tiles without padding rows / dead k-chunks in the
 // implicit operand (nmfmu_gemm checks the shape; everything else keeps the chunk-major path, bit-identical results).
-template <bool X3, class SH, bool WS = false, int TOP = 1, int NST_ = 2>
+template <bool X3, class SH, bool WS = false, int TOP = 1>
 struct GemmCfg {
-  static constexpr int NST = NST_;   // staging buffers: the LDS-DMA of k-tile t + NST - 1 is in flight while k-tile t is multiplied
   static constexpr int BM = SH::BM, BN = SH::BN, BK = 64;
   static constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;   // bytes of one explicit operand-plane tile
   static constexpr int NPL = X3 ? 2 : 1;
@@ -122,29 +114,18 @@ struct GemmCfg {
   static constexpr int A_BYTES = (WS && TOP == 0) ? WIN_BYTES : A_TILE;   // what a stage holds per operand plane
   static constexpr int B_BYTES = (WS && TOP == 1) ? WIN_BYTES : B_TILE;
   static constexpr int STAGE = NPL * (A_BYTES + B_BYTES);             // A planes then B planes
-  static constexpr int LDS_BYTES = NST * STAGE;
+  static constexpr int LDS_BYTES = 2 * STAGE;
   // ragged channels: 16 rows of the explicit operand per k-tile, one 2 KiB tile per plane and stage behind the stages
-  static constexpr int RAG_TILE = 16 * BK * 2, RAG_BYTES = NST * NPL * RAG_TILE;
+  static constexpr int RAG_TILE = 16 * BK * 2, RAG_BYTES = 2 * NPL * RAG_TILE;
   static constexpr int PA = BM * 8 / SH::THREADS, PB = BN * 8 / SH::THREADS;   // DMA passes per plane tile
   static_assert(PA * SH::THREADS == BM * 8 && PB * SH::THREADS == BN * 8, "whole DMA passes");
   static_assert(PA <= 4 && PB <= 4, "k-position registers of the implicit operand");
-  static_assert(!WS || (BM == 128 && BN == 128 && SH::WM * SH::WN == 4), "window staging: 128 x 128 tiles, 2 x 2 wave tiles");
-  // LDS of the accumulator exchange behind the loop (KW = 2): every wave hands over half of its tile
-  static constexpr int MERGE_BYTES = SH::KW > 1 ? SH::WM * SH::WN * SH::KW * (SH::MI / 2) * SH::NI * 16 * 256 : 0;
+  static_assert(!WS || (BM == 128 && BN == 128 && SH::THREADS == 256), "window staging: 128 x 128 tiles, four waves");
 };
 
-// minimum waves per SIMD the launch asks registers for: two four-wave workgroups per CU (2), two eight-wave ones (4) unless
-// their LDS (three chunk-major stages: 96 KiB) admits only one (2); split bf16 one workgroup (1 resp. 2)
-template <bool X3, class SH, bool WS, int NST>
-constexpr int gemm_min_waves() {
-  if (SH::KW > 1) return (X3 || (NST > 2 && !WS)) ? 2 : 4;
-  return (X3 || SH::THREADS > 256) ? 1 : 2;
-}
-
-template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT, bool ND, bool WS = false, int NST = 2>
-__global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>())) nt_gemm_kernel(const GemmArgs a) {
-  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1), NST>;
-  static_assert(NST == 2 || NST == 3, "double or triple buffering");
+template <bool X3, int EPI, int BETA, int OPS, class SH, int OPT, bool ND, bool WS = false>
+__global__ void __launch_bounds__(SH::THREADS, ((X3 || SH::THREADS > 256) ? 1 : 2)) nt_gemm_kernel(const GemmArgs a) {
+  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1)>;
   static_assert(!(X3 && OPT == kOpF16), "fp16 operands are single-plane");
   static_assert(!WS || (!ND && (OPS == kOpsBHu || OPS == kOpsBHuT || OPS == kOpsAHu)), "window staging: one shift axis, an implicit operand");
   // fp16: the ratio planes are converted with saturation (a ratio above 65504 becomes 65504, not inf)
@@ -154,10 +135,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hl = lane >> 5;
-  constexpr int KW = SH::KW, KS = 4 / KW;                     // wave groups splitting the contraction, k-steps per group and k-tile
-  const int kw = wave / (SH::WM * SH::WN), wq = wave % (SH::WM * SH::WN);
-  const int wm = wq / SH::WN, wn = wq % SH::WN;
-  static_assert(KW == 1 || EPI != kEpiFold, "the fold epilogue runs on KW = 1 tiles");
+  const int wm = wave / SH::WN, wn = wave % SH::WN;
   int bm = blockIdx.y, zz = blockIdx.z, nsp = a.k_split;
   const int bn = blockIdx.x;
   if constexpr (EPI == kEpiFold) {
@@ -183,7 +161,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
   // own.  Wave 0 issues 2 (6 with split operands) small MFMAs and 4 (8) fragment reads per k-tile and runs the same
   // elementwise epilogue on its 16 x 16 block.  (A 16-frame direct-summation slice per workgroup after the tile was
   // measured first: +8.4 us per GEMM -- as much as the separate nmfmu_conv_ragged_rows launch it replaced.)
-  constexpr bool RAGK = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::WM * SH::WN == 4 && C::BM == 128 && C::BN == 128;
+  constexpr bool RAGK = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256 && C::BM == 128 && C::BN == 128;
   bool rag_on = false;
   int rag_sub0 = 0;
   const char* rag_src[C::NPL] = {};
@@ -300,7 +278,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
   //     (n - 1 - m') + 8 q inside the row segment (n rows of one r).  Region 1 = the rows of the tile's second r (T >= 128: two at most).
   int ws_tsl[2] = {0, 0};
   int ws_q0 = 0, ws_r0 = 0;        // k position of chunk 0 of the next k-tile to issue (the meaning of kq / kr above)
-  int ws_qs0 = 8, ws_qs1 = 8, ws_qs2 = 8;   // rows (b,l): first chunk behind the r boundary of the k-tile in staging buffer 0 / 1 / 2 (8: none)
+  int ws_qs0 = 8, ws_qs1 = 8;      // rows (b,l): first chunk behind the r boundary of the k-tile in staging buffer 0 / 1 (8: none)
   bool ws_two = false;             // rows (r,t): the tile's rows span two r
   int ws_nent = 1;
   constexpr int WI = TOP == 0 ? MI : NI;
@@ -316,8 +294,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       const int kc = kt0 * 8;
       ws_q0 = kc / tT8, ws_r0 = kc - ws_q0 * tT8;
 #pragma unroll
-      for (int i = 0; i < WI; ++i)   // (group kw starts KS k-steps = 2 KS chunks further down the window)
-        ws_base[i] = ((TOP == 0 ? wm * MI : wn * NI) * 32 + i * 32 + j) * 16 + 128 - 128 * hl - kw * KS * 256;
+      for (int i = 0; i < WI; ++i) ws_base[i] = ((TOP == 0 ? wm * MI : wn * NI) * 32 + i * 32 + j) * 16 + 128 - 128 * hl;
     } else {
       const int r0 = row0 / a.tT, t0 = row0 - r0 * a.tT;
       const int n0 = min(128, a.tT - t0), n1 = 128 - n0;
@@ -331,7 +308,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
         const int row = (TOP == 0 ? wm * MI : wn * NI) * 32 + i * 32 + j;
         const bool seg = row >= n0;
         const int rl = seg ? row - n0 : row, ng = seg ? n1 : n0;
-        ws_base[i] = ((ng - 1 - rl) + (seg ? C::WIN_REG : 0) + 8 * hl) * 16 + kw * KS * 256;
+        ws_base[i] = ((ng - 1 - rl) + (seg ? C::WIN_REG : 0) + 8 * hl) * 16;
       }
     }
   }
@@ -381,8 +358,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory", "m0");
   };
-  auto stage_issue = [&](int kt, int buf) __attribute__((always_inline)) -> int {
-    int npieces = 0;     // LDS-DMA instructions THIS wave issues for the stage (wave-uniform): what a counted wait leaves in flight
+  auto stage_issue = [&](int kt, int buf) __attribute__((always_inline)) {
     // window staging: scalar table offsets of this k-tile's one or two regions
     int ws_soff[2] = {0, 0};
     bool ws_need1 = false;
@@ -392,8 +368,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
         ws_need1 = qs < 8;
         ws_soff[0] = 1 + ws_q0 * tJJ - 8 * ws_r0;
         ws_soff[1] = 1 + (ws_q0 + 1) * tJJ + 8 * qs;      // chunk q >= qs: entry = trow + 1 + (r + 1) JJ - 8 (q - qs)
-        if (buf == 2) ws_qs2 = ws_need1 ? qs : 8;
-        else if (buf == 1) ws_qs1 = ws_need1 ? qs : 8;
+        if (buf) ws_qs1 = ws_need1 ? qs : 8;
         else ws_qs0 = ws_need1 ? qs : 8;
       } else {
         ws_soff[0] = ws_soff[1] = 1 + ws_q0 * a.tR * tJJ + ws_r0;
@@ -412,11 +387,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
             if (wave < 3) {
               const unsigned dst = lds_base + buf * C::STAGE + tile_off(op, pl) + wave * 1024;
               dma1k(tab[pl], (unsigned)min(max(ws_tsl[0] + ws_soff[0], 0), ws_nent - 1) * 16u, dst);
-              ++npieces;
-              if (ws_need1) {
-                dma1k(tab[pl], (unsigned)min(max(ws_tsl[1] + ws_soff[1], 0), ws_nent - 1) * 16u, dst + C::WIN_REG * 16);
-                ++npieces;
-              }
+              if (ws_need1) dma1k(tab[pl], (unsigned)min(max(ws_tsl[1] + ws_soff[1], 0), ws_nent - 1) * 16u, dst + C::WIN_REG * 16);
             }
             continue;
           }
@@ -431,7 +402,6 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
             const unsigned dst = lds_base + buf * C::STAGE + tile_off(op, pl) + p * (THREADS * 16) + wave * 1024;
             if (implicit) dma1k(tab[pl], (unsigned)toep_index(p) * 16u, dst);
             else dma1k(s0, (OPS == kOpsAWin && op == 0) ? voff_win[p] : voff_exp[p], dst);
-            ++npieces;
           }
         }
       }
@@ -440,9 +410,9 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       // swizzle as pass 0 of the tiles: row = tid >> 3)
       if (rag_on && wave < 2) {
 #pragma unroll
-        for (int pl = 0; pl < C::NPL; ++pl, ++npieces)
+        for (int pl = 0; pl < C::NPL; ++pl)
           dma1k(rag_src[pl] + (size_t)(kt0 + kt) * (C::BK * 2), voff_exp[0],
-                lds_base + C::NST * C::STAGE + (buf * C::NPL + pl) * C::RAG_TILE + wave * 1024);
+                lds_base + 2 * C::STAGE + (buf * C::NPL + pl) * C::RAG_TILE + wave * 1024);
       }
     }
     if constexpr (WS) {
@@ -457,7 +427,6 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       toep_advance();
     }
     if constexpr (OPS == kOpsAWin) win_advance();
-    return npieces;
   };
   (void)TP; (void)KPP;
   f32x4 racc = {0.f, 0.f, 0.f, 0.f};
@@ -469,57 +438,25 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)   // (the eps of S + eps rides in ONE group's accumulators: the groups' sums are added)
-        acc[mi][ni][e] = ((EPI == kEpiRatio || EPI == kEpiLoss) && BETA != kEuc && (KW == 1 || kw == 0)) ? kEps : 0.f;
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = ((EPI == kEpiRatio || EPI == kEpiLoss) && BETA != kEuc) ? kEps : 0.f;
 
   const int a_rowoff = (wm * MI * 32 + j) * 128;  // + mi * 4096
   const int b_rowoff = (wn * NI * 32 + j) * 128;
-  // (group kw reads k-steps kw KS ..: for KW = 2 that is bit 6 of the slot offset, disjoint from the (2 ks + hl) << 4 of its own
-  // two k-steps, so it folds into the lane's XOR mask; the chunk-major implicit tile takes a plain byte offset)
-  const int swz = (((j >> 1) & 7) << 4) ^ (kw * KS * 32);
-  const int imp_kw = kw * KS * 2 * TROWS * 16;
+  const int swz = ((j >> 1) & 7) << 4;
 
-  // counted wait: at most n of this wave's LDS-DMA instructions stay in flight (they retire in order)
-  auto vm_wait = [&](int n) __attribute__((always_inline)) {
-    n = __builtin_amdgcn_readfirstlane(n);
-    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  };
-  int np0 = 0, np1 = 0, np2 = 0;       // pieces this wave issued for the k-tile living in staging buffer 0 / 1 / 2
-  if (ktiles > 0) np0 = stage_issue(0, 0);   // (an empty contraction part -- split factor not dividing the k-tiles -- stores zeros)
-  if constexpr (NST == 3) {
-    // triple buffering (round 5): the k loop is bound by the LATENCY of the LDS-DMA (issue to landed ~0.7 us under this load: with
-    // one k-tile of lead the loop's period is that latency, whatever the MFMAs and the number of waves do --
-    // profiles/r05c_nmfd_ablations.json); two k-tiles of lead, one counted wait per k-tile
-    if (ktiles > 1) np1 = stage_issue(1, 1);
-    vm_wait(ktiles > 1 ? np1 : 0);
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  if (ktiles > 0) stage_issue(0, 0);   // (an empty contraction part -- split factor not dividing the k-tiles -- stores zeros)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // one k-tile; the staging buffer index is a compile-time constant (the loop below is unrolled by two), so every LDS
   // address of the fragment reads and of the DMA destinations is a register base plus an immediate
   auto k_body = [&](int kt, auto bufc, auto strc) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
     constexpr bool STR = decltype(strc)::value;   // WS, rows (b,l): this k-tile crosses an r boundary (second window region)
-    const int qs_cur = buf == 2 ? ws_qs2 : (buf == 1 ? ws_qs1 : ws_qs0);
-    constexpr int nbuf = (buf + NST - 1) % NST;     // where k-tile kt + NST - 1 goes: the buffer k-tile kt - 1 has just left
+    const int qs_cur = buf ? ws_qs1 : ws_qs0;
 #ifdef NMFMU_GEMM_ABL_NODMA   // timing-only ablation (wrong results): no LDS-DMA in the loop, every k-tile multiplies stale LDS
     (void)0;
 #else
-    if (kt + NST - 1 < ktiles) {
-      const int np = stage_issue(kt + NST - 1, nbuf);
-      if (nbuf == 2) np2 = np;
-      else if (nbuf == 1) np1 = np;
-      else np0 = np;
-    }
+    if (kt + 1 < ktiles) stage_issue(kt + 1, buf ^ 1);
 #endif
     const char* sb = smem + buf * C::STAGE;
     // operand fragments are fetched one 16-wide k-step ahead of the MFMAs that consume them (pinned below)
@@ -536,13 +473,13 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       int wo = 0;
       if constexpr (WS) {
         wo = kHuRows ? (3 - ks) * 256 : ks * 256;
-        if constexpr (STR) wo += (2 * (kw * KS + ks) + hl >= qs_cur) ? C::WIN_REG * 16 : 0;
+        if constexpr (STR) wo += (2 * ks + hl >= qs_cur) ? C::WIN_REG * 16 : 0;
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         int ao;
         if constexpr (WS && TOP == 0) ao = ws_base[i] + wo;
-        else ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 + imp_kw : a_rowoff + i * 4096 + so;
+        else ao = (OPS == kOpsAHu) ? (2 * ks + hl) * (C::BM * 16) + (wm * MI * 32 + i * 32 + j) * 16 : a_rowoff + i * 4096 + so;
         ah[fb][i] = ldf(sb + ao);
         if constexpr (X3) al[fb][i] = ldf(sb + C::A_BYTES + ao);
       }
@@ -550,7 +487,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       for (int i = 0; i < NI; ++i) {
         int bo;
         if constexpr (WS && TOP == 1) bo = ws_base[i] + wo;
-        else bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16 + imp_kw
+        else bo = (OPS == kOpsBHu || OPS == kOpsBHuT) ? (2 * ks + hl) * (C::BN * 16) + (wn * NI * 32 + i * 32 + j) * 16
                                                       : b_rowoff + i * 4096 + so;
         bh[fb][i] = ldf(sb + C::NPL * C::A_BYTES + bo);
         if constexpr (X3) bl[fb][i] = ldf(sb + C::NPL * C::A_BYTES + C::B_BYTES + bo);
@@ -558,9 +495,9 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
     };
     load_frags(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int fb = ks & 1;
-      if (ks + 1 < KS) load_frags(ks + 1, fb ^ 1);
+      if (ks + 1 < 4) load_frags(ks + 1, fb ^ 1);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -580,13 +517,13 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
       // pin the order: the first k-step's fragment reads, then per MFMA (group) its share of the next k-step's reads
       constexpr int RD = (MI + NI) * C::NPL, NM = MI * NI, MF = X3 ? 3 : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-      static_for<KS>([&](auto ksc) {
+      static_for<4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
         static_for<NM>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
           constexpr int nrd = (RD * (q + 1)) / NM - (RD * q) / NM;
-          if constexpr (ks + 1 < KS && nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+          if constexpr (ks + 1 < 4 && nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
         });
       });
     }
@@ -595,7 +532,7 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
         // 16 x 16 x 32 fragments: lane = (row r16, k-chunk g4 of the 32-wide step); the ragged tile is row-major with the
         // tiles' XOR swizzle, the implicit operand's tile is chunk-major (no swizzle)
         const int r16 = lane & 15, g4 = lane >> 4;
-        const char* rt = smem + C::NST * C::STAGE + buf * C::NPL * C::RAG_TILE;
+        const char* rt = smem + 2 * C::STAGE + buf * C::NPL * C::RAG_TILE;
         const char* it = sb + (TOP == 0 ? 0 : C::NPL * C::A_BYTES);
         constexpr int IT_PLANE = TOP == 0 ? C::A_BYTES : C::B_BYTES;
 #pragma unroll
@@ -615,40 +552,21 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
         }
       }
     }
-    // k-tile kt + 1 has landed (this wave's share of it); with three buffers k-tile kt + 2, issued above, stays in flight
-    if constexpr (NST == 3) vm_wait(kt + 2 < ktiles ? (nbuf == 2 ? np2 : (nbuf == 1 ? np1 : np0)) : 0);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed (this wave's share of it)
 #ifndef NMFMU_GEMM_ABL_NOBAR   // (timing-only ablation: no barrier in the loop)
     __syncthreads();
 #endif
   };
   auto k_tile = [&](int kt, auto bufc) __attribute__((always_inline)) {
-    if constexpr (WS && kHuRows && KW > 1) {
-      // eight waves: a wave has two k-steps per k-tile -- the region select is two compares, cheaper than a second copy of
-      // the loop body (which cost the four-wave instance 70 registers)
-      k_body(kt, bufc, std::true_type{});
-      return;
-    } else if constexpr (WS && kHuRows) {
-      constexpr int b_ = decltype(bufc)::value;
-      if (__builtin_amdgcn_readfirstlane(b_ == 2 ? ws_qs2 : (b_ == 1 ? ws_qs1 : ws_qs0)) < 8) {
+    if constexpr (WS && kHuRows) {
+      if (__builtin_amdgcn_readfirstlane(decltype(bufc)::value ? ws_qs1 : ws_qs0) < 8) {
         k_body(kt, bufc, std::true_type{});
         return;
       }
     }
     k_body(kt, bufc, std::false_type{});
   };
-  if constexpr (NST == 3) {
-    int kt = 0;
-    for (; kt + 3 <= ktiles; kt += 3) {
-      k_tile(kt, std::integral_constant<int, 0>{});
-      k_tile(kt + 1, std::integral_constant<int, 1>{});
-      k_tile(kt + 2, std::integral_constant<int, 2>{});
-    }
-    if (kt < ktiles) {
-      k_tile(kt, std::integral_constant<int, 0>{});
-      if (kt + 1 < ktiles) k_tile(kt + 1, std::integral_constant<int, 1>{});
-    }
-  } else {
+  {
     int kt = 0;
     for (; kt + 2 <= ktiles; kt += 2) {
       k_tile(kt, std::integral_constant<int, 0>{});
@@ -727,50 +645,17 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
     }
     return;
   }
-  // ---- KW = 2: the two wave groups hold partial sums of the same 64 x 64 wave tile.  Group 0 keeps MFMA row blocks
-  // [0, MI / 2) and hands the others to group 1, group 1 the reverse: one ds_write_b32 / ds_read_b32 per accumulator register
-  // handed over (lanes contiguous: conflict free), one barrier; afterwards every wave runs the epilogue on half a tile.
-  // (No accumulator array is indexed with the run-time group number: selects, so nothing is demoted to scratch.)
-  constexpr int MIE = MI / KW;
-  f32x16 res[MIE][NI];
-  if constexpr (KW == 1) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) res[mi][ni] = acc[mi][ni];
-  } else {
-    constexpr int REGS = MIE * NI * 16, WQ = SH::WM * SH::WN;
-    float* xb = reinterpret_cast<float*>(smem);
-    float* mine = xb + (size_t)((kw * WQ + wq) * REGS) * 64 + lane;
-    const float* theirs = xb + (size_t)(((1 - kw) * WQ + wq) * REGS) * 64 + lane;
-    const bool up = kw != 0;
-#pragma unroll
-    for (int ml = 0; ml < MIE; ++ml)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mine[((ml * NI + ni) * 16 + e) * 64] = up ? acc[ml][ni][e] : acc[MIE + ml][ni][e];
-    __syncthreads();
-#pragma unroll
-    for (int ml = 0; ml < MIE; ++ml)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          res[ml][ni][e] = (up ? acc[MIE + ml][ni][e] : acc[ml][ni][e]) + theirs[((ml * NI + ni) * 16 + e) * 64];
-    if constexpr (EPI == kEpiLoss) __syncthreads();   // (the loss reduction below re-uses the first words of this buffer)
-  }
   float lacc = 0.f;
 #pragma unroll
-  for (int mi = 0; mi < MIE; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = bn * C::BN + wn * NI * 32 + ni * 32 + j;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = bm * C::BM + wm * MI * 32 + (kw * MIE + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const int m = bm * C::BM + wm * MI * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
         const size_t idx = (size_t)m * a.ldn + n;
-        const float s = res[mi][ni][e];
+        const float s = acc[mi][ni][e];
         if constexpr (EPI == kEpiF32) {
           a.out[(size_t)zz * a.m_pad * a.ldn + idx] = s;
         } else if constexpr (EPI == kEpiLoss) {
@@ -832,17 +717,15 @@ __global__ void __launch_bounds__(SH::THREADS, (gemm_min_waves<X3, SH, WS, NST>(
   }
 }
 
-template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16, bool ND = false, bool WS = false,
-          int NST = 2>
+template <bool X3, int EPI, int BETA, int OPS = kOpsPlanes, class SH = GemmSmall, int OPT = kOpBf16, bool ND = false, bool WS = false>
 int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
-  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1), NST>;
+  using C = GemmCfg<X3, SH, WS, (OPS == kOpsAHu ? 0 : 1)>;
   constexpr int kFoldBytes = (SH::THREADS / 256) * 128 * kFoldLd * 4;
-  constexpr bool kRag = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::WM * SH::WN == 4;
-  constexpr int kLds0 = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
-  constexpr int kLds = kLds0 < C::MERGE_BYTES ? C::MERGE_BYTES : kLds0;
+  constexpr bool kRag = EPI == kEpiRatio && (OPS == kOpsBHu || OPS == kOpsAHu) && SH::THREADS == 256;
+  constexpr int kLds = (EPI == kEpiFold && C::LDS_BYTES < kFoldBytes) ? kFoldBytes : C::LDS_BYTES + (kRag ? C::RAG_BYTES : 0);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   if (a.m_pad % C::BM || a.n_pad % C::BN) return -3;
-  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT, ND, WS, NST>;
+  auto kern = nt_gemm_kernel<X3, EPI, BETA, OPS, SH, OPT, ND, WS>;
   static bool done[64] = {};   // per device (nmfmu_fused.h: attr_flag)
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -862,9 +745,9 @@ int launch_gemm_one(const GemmArgs& a, hipStream_t s) {
 
 // f16 != 0: fp16 operand planes / window tables and fp16 ratio planes (single plane; the beta == 1 NMFD path)
 int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s);
-// round-5 instances (nmfmu_nmfd_ws.hip): window staging (the caller has checked gemm_window_stageable()), the eight-wave tile,
-// three staging buffers; -2 = combination not instantiated
-int launch_gemm_r5(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s, bool ws, bool eight, int nst);
+// the same combinations with the implicit operand staged as a window of table entries (WS; nmfmu_nmfd_ws.hip); the caller
+// (nmfmu_gemm) has checked gemm_window_stageable()
+int launch_gemm_ws(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s);
 // Shapes the window staging serves: one shift axis, 128 x 128 tiles, the implicit operand's rows and k extent exactly
 // the logical ones (no padding rows, no dead k-chunks inside any tile), and line lengths that keep a tile inside one
 // batch entry: rows (b,l): L % 128 == 0, T >= 64, k_len == R T;  rows (r,t): rows == R T (a multiple of 128), T >= 128,

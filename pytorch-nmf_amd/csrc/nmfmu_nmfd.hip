@@ -14,14 +14,6 @@
 #include "../../include/nmfmu.h"
 #include "nmfmu_gemm.h"
 
-// what nmfmu_gemm_desc.stage_mode = 0 (automatic) runs on the round-5 instances (measured: profiles/r05*_nmfd_stage*.json)
-#ifndef NMFMU_GEMM_AUTO_EIGHT
-#define NMFMU_GEMM_AUTO_EIGHT 0
-#endif
-#ifndef NMFMU_GEMM_AUTO_NST
-#define NMFMU_GEMM_AUTO_NST 3
-#endif
-
 namespace nmfmu {
 
 int launch_gemm(int x3, int epi, int beta_kind, int ops, int f16, const GemmArgs& a, hipStream_t s) {
@@ -1110,34 +1102,14 @@ static int gemm_prepare(const nmfmu_gemm_desc* d, int epilogue, GemmArgs& a, int
   if (d->tile_rows != 0 && d->tile_rows != 128) return NMFMU_ERR_UNSUPPORTED;   // (the 256 x 256 tile of ABI 3 is gone)
   a.ldn = d->n_ld ? d->n_ld : d->n_pad;
   if (a.ldn < d->n_pad || (a.ldn != d->n_pad && epilogue == NMFMU_EPI_FOLD)) return NMFMU_ERR_ARG;
-  if (d->stage_mode < 0 || d->stage_mode > 7) return NMFMU_ERR_ARG;
+  if (d->stage_mode != 0 && d->stage_mode != 1) return NMFMU_ERR_ARG;
   return NMFMU_OK;
 }
 
-// nmfmu_gemm_desc.stage_mode -> (window staging wanted, eight-wave tile, staging buffers); see include/nmfmu.h
-struct StagePlan {
-  bool ws, eight;
-  int nst;
-};
-static StagePlan stage_plan(int mode) {
-  switch (mode) {
-    case 1: return {false, false, 2};
-    case 2: return {true, false, 2};
-    case 3: return {false, true, 2};
-    case 4: return {true, true, 2};
-    case 5: return {true, false, 3};
-    case 6: return {true, true, 3};
-    case 7: return {false, true, 3};
-    default: return {true, NMFMU_GEMM_AUTO_EIGHT != 0, NMFMU_GEMM_AUTO_NST};   // 0: automatic
-  }
-}
-static bool gemm_r5_candidate(const nmfmu_gemm_desc* d, int epilogue, const GemmArgs& a) {
-  return epilogue != NMFMU_EPI_FOLD && !a.koff &&
-         (d->ops == NMFMU_OPS_B_HU || d->ops == NMFMU_OPS_B_HUT || d->ops == NMFMU_OPS_A_HU);
-}
-// window staging of the implicit operand (nmfmu_gemm.h: WS): where the mode asks for it and the shape allows it
+// window staging of the implicit operand (nmfmu_gemm.h: WS): automatic where the shape allows it
 static bool gemm_takes_window(const nmfmu_gemm_desc* d, int epilogue, const GemmArgs& a) {
-  return stage_plan(d->stage_mode).ws && gemm_r5_candidate(d, epilogue, a) && gemm_window_stageable(d->ops, a);
+  return d->stage_mode == 0 && epilogue != NMFMU_EPI_FOLD && d->ops != NMFMU_OPS_PLANES && d->ops != NMFMU_OPS_A_WIN &&
+         gemm_window_stageable(d->ops, a);
 }
 
 int nmfmu_gemm_window_staged(const nmfmu_gemm_desc* d, int epilogue) {
@@ -1152,15 +1124,8 @@ int nmfmu_gemm(const nmfmu_gemm_desc* d, int epilogue, void* stream) {
   int x3, kind, f16;
   int rc = gemm_prepare(d, epilogue, a, x3, kind, f16);
   if (rc) return rc;
-  rc = -2;
-  if (gemm_r5_candidate(d, epilogue, a) && d->stage_mode != 1) {
-    const StagePlan pl = stage_plan(d->stage_mode);
-    const bool ws = gemm_takes_window(d, epilogue, a);
-    // (three stages of a chunk-major tile only fit the eight-wave form, one workgroup per CU; split bf16 keeps four waves, two stages)
-    rc = launch_gemm_r5(x3, epilogue, kind, d->ops, f16, a, S(stream), ws, pl.eight, pl.nst);
-    if (rc == -2 && ws) rc = launch_gemm_r5(x3, epilogue, kind, d->ops, f16, a, S(stream), true, false, 2);
-  }
-  if (rc == -2) rc = launch_gemm(x3, epilogue, kind, d->ops, f16, a, S(stream));
+  rc = gemm_takes_window(d, epilogue, a) ? launch_gemm_ws(x3, epilogue, kind, d->ops, f16, a, S(stream))
+                                         : launch_gemm(x3, epilogue, kind, d->ops, f16, a, S(stream));
   return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 

@@ -358,9 +358,7 @@ class ConvMU(AsyncLossMixin):
             d.t_koff = self.koff[ops].data_ptr()
         # implicit operands are staged as a window of table entries wherever the library's shape test admits it (round 5);
         # TORCHNMF_AMD_NMFD_WINSTAGE=0 keeps the chunk-major tiles of rounds 1-4 (A/B switch; bit-identical results)
-        # TORCHNMF_AMD_NMFD_STAGE=<0..3> passes nmfmu_gemm_desc.stage_mode through (0 automatic, 1 the rounds 1-4 kernel, 2 window
-        # on four waves, 3 chunk-major on eight waves)
-        d.stage_mode = int(os.environ.get('TORCHNMF_AMD_NMFD_STAGE', '1' if os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1') == '0' else '0'))
+        d.stage_mode = 1 if os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1') == '0' else 0
         timer = getattr(self, 'timer', None) if tag else None
         if tag and tag not in self.staged:       # which launches stage their implicit operand as a window (host-side query, once)
             self.staged[tag] = int(self.lib.nmfmu_gemm_window_staged(C.byref(d), epi))
