@@ -45,7 +45,8 @@ extern "C" {
                                   operands with several shift axes);
                                8: nmfmu_abi_check (load-time guard for bindings that are not the bundled Python host),
                                   nmfmu_ubench_mfma_hbm (in-run ceiling of the MU step for bench.py); the NMFD GEMMs stage an implicit
-                                  operand as a sliding window of table entries where its tiles hold no padding (no interface change) */
+                                  operand as a sliding window of table entries where its tiles hold no padding (nmfmu_gemm_desc.stage_mode,
+                                  nmfmu_gemm_window_staged); nmfmu_conv_apply_pack_w_wk / nmfmu_conv_apply_h_rows_sums / nmfmu_conv_h_rows_parts */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -563,6 +564,24 @@ int nmfmu_conv_pack_wk(const float* w, int channels, int rank, int taps, int tap
                        int precision, void* wk_hi, void* wk_lo, void* stream);
 int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
                             const float* den, const float* kl_den, int ld, float l1, float l2, float gamma, void* stream);
+/* (ABI 8) The same two with their neighbours riding along -- four launches less per iteration of NMF2D / NMF3D / NMFD with a
+ * short kernel (beta == 1, taps >= 64 in total, rank <= 256):
+ *   nmfmu_conv_apply_pack_w_wk    = nmfmu_conv_apply_pack_w_sums (update, Wm / WmT planes, kl_hpart in, wcol out) + the Wk planes
+ *                                   of nmfmu_conv_pack_wk from the same tile (their zero padding is NOT rewritten: run
+ *                                   nmfmu_conv_pack_wk once on these buffers first);
+ *   nmfmu_conv_apply_h_rows_sums  = nmfmu_conv_apply_h_rows for beta == 1 with sum_{c,t} W[c][r][t] finished in the kernel from
+ *                                   the tile sums kl_wcol [c_tiles][rp_pad / 64][2] (nmfmu_conv_apply_pack_w_sums / _wk), and
+ *                                   sum_{b,j} of the NEW h left as hsum_part[r][nmfmu_conv_h_rows_parts()] partials (fixed order)
+ *                                   -- what kl_hpart / n_hparts of the next W update take. */
+int nmfmu_conv_apply_pack_w_wk(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                               const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
+                               int c_pad, int rp_pad, float l1, float l2, float gamma, int update, int precision,
+                               void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, int taps_last, int fold, int wk_rows_pad,
+                               int wk_k_pad, void* wk_hi, void* wk_lo, void* stream);
+int nmfmu_conv_h_rows_parts(int batch, int rank, int lh_outer, int lh_last);
+int nmfmu_conv_apply_h_rows_sums(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
+                                 const float* kl_wcol, int c_tiles, int rp_pad, int taps, int ld, float l1, float l2, float gamma,
+                                 float* hsum_part, void* stream);
 /* ... and the sum alone: out (batch, rank, lh_outer, lh_last) = the folded numerator (shift-invariant PLCA's own update) */
 int nmfmu_conv_rows_fold(float* out, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num, int ld,
                          void* stream);

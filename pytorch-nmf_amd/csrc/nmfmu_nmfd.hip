@@ -382,6 +382,16 @@ __global__ void __launch_bounds__(256) conv_apply_w_kernel(float* __restrict__ W
   }
 }
 
+// Third layout of the same tile (round 5, the launch diet of NMF2D / NMF3D): the B operand of the window-operand H-numerator
+// GEMM, Wk[r F + d][((to TQ + q) CK + ck) 64 + c'] = W[c = 64 ck + c'][r][t = to T_last + F q + d] (conv_pack_wk_kernel's
+// layout).  A 64-channel tile is one ck, so a row of the transposed tile -- 64 channels of one (r, t) -- is one contiguous
+// 128-byte run of Wk: the WmT chunks go out a second time to another address.  hi == nullptr: off.
+struct WkOut {
+  uint16_t* hi = nullptr;
+  uint16_t* lo = nullptr;
+  int t_last = 1, fold = 1, ck = 1, k_pad = 0;
+};
+
 // conv_apply_w + both operand packings in one pass: a 64 (c) x 64 (k = (r,t)) tile of W is updated in place
 // (nmf.py:78-92), kept in LDS, and re-emitted as bf16 planes in both layouts the GEMMs read -- Wm [c_pad][rp_pad]
 // and WmT [rp_pad][c_pad] (zero in the padding).  Replaces conv_apply_w_kernel + two pack2d_kernel launches
@@ -395,7 +405,8 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
                                                                 uint16_t* wm_hi, uint16_t* wm_lo, uint16_t* wmt_hi,
                                                                 uint16_t* wmt_lo, const float* __restrict__ scale,
                                                                 const float* __restrict__ kl_hpart, int n_hparts,
-                                                                float* __restrict__ wcol, int num_slabs, int f16) {
+                                                                float* __restrict__ wcol, int num_slabs, int f16,
+                                                                WkOut wk = WkOut{}) {
   constexpr int LDT = 65;
   __shared__ float tile[64 * LDT];
   const int tid = threadIdx.x;
@@ -476,6 +487,13 @@ __global__ void __launch_bounds__(256) conv_apply_pack_w_kernel(float* __restric
     const size_t o = tr ? (size_t)(k0 + row) * c_pad + c0 + ch : (size_t)(c0 + row) * rp_pad + k0 + ch;
     *reinterpret_cast<u32x4*>((tr ? wmt_hi : wm_hi) + o) = hi;
     if constexpr (X3) *reinterpret_cast<u32x4*>((tr ? wmt_lo : wm_lo) + o) = lo;
+    if (tr && wk.hi && k0 + row < RT && c0 < wk.ck * 64) {
+      const int kk = k0 + row, r = kk / T, t = kk - r * T;
+      const int to = t / wk.t_last, tl = t - to * wk.t_last, q = tl / wk.fold, d = tl - q * wk.fold;
+      const size_t ow = (size_t)(r * wk.fold + d) * wk.k_pad + ((size_t)(to * (wk.t_last / wk.fold) + q) * wk.ck + c0 / 64) * 64 + ch;
+      *reinterpret_cast<u32x4*>(wk.hi + ow) = hi;
+      if constexpr (X3) *reinterpret_cast<u32x4*>(wk.lo + ow) = lo;
+    }
   }
 }
 
@@ -939,6 +957,56 @@ __global__ void __launch_bounds__(256) conv_apply_h_rows_kernel(float* __restric
   }
 }
 
+// The same update with the beta == 1 rank sums riding in it (round 5, launch diet): sum_{c,t} W[c][r][t] arrives as the tile
+// sums conv_apply_pack_w left behind (kl_wcol [c tile][k tile][2], as in the fold-parts kernels above) and is finished per
+// block for all ranks; sum_{b,j} H_new[b][r][j] leaves as one partial per block and rank (hsum_part[r][gridDim.x]) for the next
+// W half-step.  Thread layout: P = 256 / R positions per block step, r = tid % R is fixed per thread (any R <= 256; the
+// last 256 - P R threads idle), so the block's partial per rank is a fixed-order sum of P register sums: deterministic.
+__global__ void __launch_bounds__(256) conv_apply_h_rows_sums_kernel(float* __restrict__ H, int B, int R, int lh_outer, int lh_last,
+                                                                     int F, const float* __restrict__ num,
+                                                                     const float* __restrict__ kl_wcol, int c_tiles, int k_tiles,
+                                                                     int T, int ld, float l1, float l2, float gamma,
+                                                                     float* __restrict__ hsum_part) {
+  __shared__ float den_s[256];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, P = 256 / R;
+  if (tid < R) {
+    // the k tiles that hold taps of rank tid, slot = second rank of the tile (fixed order)
+    const int kt_lo = (tid * T) / 64, kt_n = (tid * T + T - 1) / 64 - kt_lo + 1;
+    float sacc = 0.f;
+    for (int ct = 0; ct < c_tiles; ++ct)
+      for (int kt = kt_lo; kt < kt_lo + kt_n; ++kt) sacc += kl_wcol[((size_t)ct * k_tiles + kt) * 2 + (tid > (kt * 64) / T ? 1 : 0)];
+    den_s[tid] = sacc;
+  }
+  __syncthreads();
+  const int r = tid % R, pl = tid / R;
+  const int64_t npos = (int64_t)B * lh_outer * lh_last;
+  const int lw = lh_last + F - 1;
+  float mine = 0.f;
+  if (pl < P) {
+    const float pos_ = den_s[r];
+    for (int64_t pos = (int64_t)blockIdx.x * P + pl; pos < npos; pos += (int64_t)gridDim.x * P) {
+      const int j = (int)(pos % lh_last);
+      const int64_t bo = pos / lh_last;                        // (b, jo)
+      const int b = (int)(bo / lh_outer), jo = (int)(bo - (int64_t)b * lh_outer);
+      const size_t row0 = ((size_t)bo * lw + j) * ld + (size_t)r * F;
+      float neg = 0.f;
+      for (int d = 0; d < F; ++d) neg += num[row0 + (size_t)d * (ld + 1)];
+      const size_t o = (((size_t)b * R + r) * lh_outer + jo) * lh_last + j;
+      const float hv = mu_update(H[o], neg, pos_, true, l1, l2, gamma);
+      H[o] = hv;
+      mine += hv;
+    }
+  }
+  red[tid] = mine;
+  __syncthreads();
+  if (tid < R) {
+    float tot = 0.f;
+    for (int p = 0; p < P; ++p) tot += red[p * R + tid];
+    hsum_part[(size_t)tid * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
 // the two rank-sum stages in one launch for small inputs: one block per rank, fixed order
 __global__ void __launch_bounds__(1024) rank_sums_one_kernel(const float* __restrict__ src, int outer, int R, int inner,
                                                              float* __restrict__ out) {
@@ -1207,7 +1275,7 @@ static int conv_pack_w(float* w, int channels, int rank, int taps, const float* 
                        const float* kl_den, int c_pad, int rp_pad, float l1, float l2, float gamma, int update,
                        void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, const float* scale, void* stream,
                        const float* kl_hpart = nullptr, int n_hparts = 0, float* wcol = nullptr, int num_slabs = 1,
-                       int f16 = 0) {
+                       int f16 = 0, WkOut wk = WkOut{}) {
   if (!w || !wm_hi || !wmt_hi || channels <= 0 || rank <= 0 || taps <= 0) return NMFMU_ERR_ARG;
   if (update && (!num || (!den && !kl_den && !kl_hpart))) return NMFMU_ERR_ARG;
   if ((kl_hpart && n_hparts <= 0) || (wcol && scale) || ((kl_hpart || wcol) && taps < 64)) return NMFMU_ERR_ARG;
@@ -1218,11 +1286,11 @@ static int conv_pack_w(float* w, int channels, int rank, int taps, const float* 
   if (wm_lo)
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<true>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, (uint16_t*)wm_lo,
-                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol, num_slabs, 0);
+                       (uint16_t*)wmt_hi, (uint16_t*)wmt_lo, scale, kl_hpart, n_hparts, wcol, num_slabs, 0, wk);
   else
     hipLaunchKernelGGL(conv_apply_pack_w_kernel<false>, grid, dim3(256), 0, S(stream), w, channels, rank * taps, taps, num,
                        den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, (uint16_t*)wm_hi, nullptr, (uint16_t*)wmt_hi,
-                       nullptr, scale, kl_hpart, n_hparts, wcol, num_slabs, f16);
+                       nullptr, scale, kl_hpart, n_hparts, wcol, num_slabs, f16, wk);
   return (int)hipGetLastError();
 }
 
@@ -1242,6 +1310,27 @@ int nmfmu_conv_apply_pack_w_sums(float* w, int channels, int rank, int taps, con
   if ((precision == NMFMU_PREC_BF16X3) != (wm_lo != nullptr)) return NMFMU_ERR_ARG;
   return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
                      wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol, num_slabs, precision == NMFMU_PREC_F16);
+}
+
+int nmfmu_conv_apply_pack_w_wk(float* w, int channels, int rank, int taps, const float* num, const float* den,
+                               const float* kl_den, const float* kl_hpart, int n_hparts, float* wcol, int num_slabs,
+                               int c_pad, int rp_pad, float l1, float l2, float gamma, int update, int precision,
+                               void* wm_hi, void* wm_lo, void* wmt_hi, void* wmt_lo, int taps_last, int fold, int wk_rows_pad,
+                               int wk_k_pad, void* wk_hi, void* wk_lo, void* stream) {
+  if (num_slabs < 1 || num_slabs > 64) return NMFMU_ERR_ARG;
+  if (precision != NMFMU_PREC_BF16 && precision != NMFMU_PREC_BF16X3 && precision != NMFMU_PREC_F16) return NMFMU_ERR_ARG;
+  if ((precision == NMFMU_PREC_BF16X3) != (wm_lo != nullptr)) return NMFMU_ERR_ARG;
+  // (the arguments nmfmu_conv_pack_wk checks)
+  if (!wk_hi || taps_last <= 0 || taps % taps_last || fold < 1 || taps_last % fold || wk_rows_pad < rank * fold || wk_k_pad % 8)
+    return NMFMU_ERR_ARG;
+  const int ck = (channels + 63) / 64;
+  if ((int64_t)wk_k_pad < (int64_t)(taps / fold) * ck * 64) return NMFMU_ERR_ARG;
+  if (precision == NMFMU_PREC_BF16X3 && !wk_lo) return NMFMU_ERR_ARG;
+  WkOut wk;
+  wk.hi = (uint16_t*)wk_hi, wk.lo = (uint16_t*)(precision == NMFMU_PREC_BF16X3 ? wk_lo : nullptr);
+  wk.t_last = taps_last, wk.fold = fold, wk.ck = ck, wk.k_pad = wk_k_pad;
+  return conv_pack_w(w, channels, rank, taps, num, den, kl_den, c_pad, rp_pad, l1, l2, gamma, update, wm_hi, wm_lo, wmt_hi,
+                     wmt_lo, nullptr, stream, kl_hpart, n_hparts, wcol, num_slabs, precision == NMFMU_PREC_F16, wk);
 }
 
 int nmfmu_conv_pack_w_scaled(float* w, int channels, int rank, int taps, const float* scale, int c_pad, int rp_pad,
@@ -1435,6 +1524,25 @@ int nmfmu_conv_apply_h_rows(float* h, int batch, int rank, int lh_outer, int lh_
   const int64_t n = (int64_t)batch * lh_outer * lh_last * rank;
   hipLaunchKernelGGL(conv_apply_h_rows_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), h, batch, rank, lh_outer, lh_last,
                      fold, num, den, kl_den, ld, l1, l2, gamma, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int nmfmu_conv_h_rows_parts(int batch, int rank, int lh_outer, int lh_last) {
+  if (batch <= 0 || rank <= 0 || rank > 256 || lh_outer <= 0 || lh_last <= 0) return 0;
+  const int64_t npos = (int64_t)batch * lh_outer * lh_last;
+  const int p = 256 / rank;
+  return (int)std::max<int64_t>(1, std::min<int64_t>((npos + p - 1) / p, 2048));
+}
+
+int nmfmu_conv_apply_h_rows_sums(float* h, int batch, int rank, int lh_outer, int lh_last, int fold, const float* num,
+                                 const float* kl_wcol, int c_tiles, int rp_pad, int taps, int ld, float l1, float l2, float gamma,
+                                 float* hsum_part, void* stream) {
+  if (!h || !num || !kl_wcol || !hsum_part || batch <= 0 || rank <= 0 || rank > 256 || lh_outer <= 0 || lh_last <= 0 || fold < 1 ||
+      ld < rank * fold || c_tiles <= 0 || taps < 64 || rp_pad % 64 || rp_pad < rank * taps)
+    return NMFMU_ERR_ARG;
+  const int grid = nmfmu_conv_h_rows_parts(batch, rank, lh_outer, lh_last);
+  hipLaunchKernelGGL(conv_apply_h_rows_sums_kernel, dim3(grid), dim3(256), 0, S(stream), h, batch, rank, lh_outer, lh_last, fold,
+                     num, kl_wcol, c_tiles, rp_pad / 64, taps, ld, l1, l2, gamma, hsum_part);
   return (int)hipGetLastError();
 }
 

@@ -137,6 +137,14 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_conv_apply_h_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'nmfmu_conv_apply_pack_w_wk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_conv_h_rows_parts': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nmfmu_conv_apply_h_rows_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                               C.c_void_p]),
     'nmfmu_convnd_table_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'nmfmu_convnd_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

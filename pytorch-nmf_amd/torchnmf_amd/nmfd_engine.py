@@ -303,6 +303,16 @@ class ConvMU(AsyncLossMixin):
             self.hpart = torch.zeros(R * self.n_hparts, dtype=torch.float32, device=dev)
             self.wcol = torch.zeros((cp // 64) * (rpp // 64) * 2, dtype=torch.float32, device=dev)
         self._h_parts_valid = False
+        # Launch diet of the window-operand path (round 5; NMF2D / NMF3D / NMFD below 128 taps, beta == 1, >= 64 taps in total,
+        # rank <= 256): the rank sums ride in the two apply kernels (tile sums of W out of / partial sums of H into the W
+        # update, the reverse for the H update) and the W update emits the Wk planes too -- four launches less per iteration
+        # (rank_sums x 3, conv_pack_wk).  '0' keeps the separate launches.
+        self.rows_fused = (own_loop and self.kl and self.h_rows and not self.fused_sums and T >= 64 and R <= 256 and
+                           os.environ.get('TORCHNMF_AMD_NMFD_ROWS_FUSED', '1') != '0')
+        if self.rows_fused:
+            self.n_hparts = self.lib.nmfmu_conv_h_rows_parts(B, R, Lh // self.lhs[-1], self.lhs[-1])
+            self.hpart = torch.zeros(R * self.n_hparts, dtype=torch.float32, device=dev)
+            self.wcol = torch.zeros((cp // 64) * (rpp // 64) * 2, dtype=torch.float32, device=dev)
         # W numerator GEMM: [C x B L] . [B L x R T] has few tiles and a long contraction (225 tiles x 128 k-steps at
         # configs[3]: one workgroup per CU, the second slot idle): split the contraction in two when that fills the chip
         # better; the apply kernel adds the partials (beta == 1 fused-sums path only)
@@ -323,7 +333,10 @@ class ConvMU(AsyncLossMixin):
         nrag = self.lib.nmfmu_conv_ragged_blocks(B, Lh, T) * (Cc - self.c_main) if self.ragged else 0
         self.loss_part = torch.zeros((cp // 128) * (blp // 128) + nrag, dtype=torch.float32, device=dev)  # not all written
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._wk_ready, self._wcol_valid = False, False
         self.refresh_images()
+        if self.rows_fused:                          # second pass: now through the fused kernel (tile sums of W for the first H update)
+            self._pack_w()
 
     # ------------------------------------------------------------------ helpers
     def _pack2d(self, src, rows, cols, rin, ros, ris, cin, cos, cis, rows_pad, cols_pad, dst_f32, planes, flags):
@@ -416,8 +429,10 @@ class ConvMU(AsyncLossMixin):
                 _ptr(self.wm.lo),
                 _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()), 'nmfmu_conv_apply_pack_w_sums')
             return
-        self._pack_w_planes(update)
+        if self._pack_w_planes(update):
+            return                                   # (rows_fused: the Wk planes came out of the same launch)
         if self.h_rows:
+            self._wk_ready = True                    # (the standalone kernel also writes the planes' zero padding: once)
             _capi.check(self.lib.nmfmu_conv_pack_wk(self.W.data_ptr(), self.C, self.R, self.T, self.ts[-1], self.wk_fold,
                                                     self.wk.rows_pad, self.wk.cols_pad, self.precision, _ptr(self.wk.hi),
                                                     _ptr(self.wk.lo), _stream()), 'nmfmu_conv_pack_wk')
@@ -432,6 +447,19 @@ class ConvMU(AsyncLossMixin):
                     _capi.check(self.lib.nmfmu_slab_sum(buf.data_ptr(), (self.c_rows or self.c_pad) * self.rp_pad, slabs,
                                                         _stream()), 'nmfmu_slab_sum')
             slabs = 1
+        if self.rows_fused and self._wk_ready:
+            # one launch: the update of nmf.py:78-92 with sum_{b,j} H taken from the H update's partial sums (or from the
+            # finished vector after an outside change of H), Wm / WmT / Wk planes, tile sums of the new W for the H update
+            parts = update and self._h_parts_valid
+            _capi.check(self.lib.nmfmu_conv_apply_pack_w_wk(
+                self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None, None,
+                self.sum_h.data_ptr() if (update and not parts) else None, self.hpart.data_ptr() if parts else None,
+                self.n_hparts, self.wcol.data_ptr(), slabs, self.c_pad, self.rp_pad, self.l1, self.l2, self.gamma, int(update),
+                self.precision, _ptr(self.wm.hi), _ptr(self.wm.lo), _ptr(self.wmt.hi), _ptr(self.wmt.lo), self.ts[-1],
+                self.wk_fold, self.wk.rows_pad, self.wk.cols_pad, _ptr(self.wk.hi), _ptr(self.wk.lo), _stream()),
+                'nmfmu_conv_apply_pack_w_wk')
+            self._wcol_valid = True
+            return True
         # (the _sums entry without its partial-sum operands: the one that adds the split-K slabs of num / den)
         _capi.check(self.lib.nmfmu_conv_apply_pack_w_sums(
             self.W.data_ptr(), self.C, self.R, self.T, _ptr(self.num_w) if update else None,
@@ -440,6 +468,7 @@ class ConvMU(AsyncLossMixin):
             _ptr(self.wm.hi), _ptr(self.wm.lo), _ptr(self.wmt.hi), _ptr(self.wmt.lo), _stream()),
             'nmfmu_conv_apply_pack_w_sums')
         self._rank_sums(self.W, self.C, self.T, self.sum_w)
+        return False
 
     def _pack_h(self, sums: bool = True):
         if self.implicit and self.nd > 1:
@@ -518,6 +547,14 @@ class ConvMU(AsyncLossMixin):
             self._gemm_win(self.gnt, self.hnum, tag='num_h')
             if not self.kl:
                 self._gemm_win(self.gpt, self.hden)
+            if self.rows_fused and self._wcol_valid:
+                _capi.check(self.lib.nmfmu_conv_apply_h_rows_sums(
+                    self.H.data_ptr(), self.B, self.R, self.Lh // self.lhs[-1], self.lhs[-1], self.wk_fold, self.hnum.data_ptr(),
+                    self.wcol.data_ptr(), self.c_pad // 64, self.rp_pad, self.T, self.wk_rows, self.l1, self.l2, self.gamma,
+                    self.hpart.data_ptr(), _stream()), 'nmfmu_conv_apply_h_rows_sums')
+                self._pack_h(sums=False)
+                self._h_parts_valid = True
+                return
             _capi.check(self.lib.nmfmu_conv_apply_h_rows(
                 self.H.data_ptr(), self.B, self.R, self.Lh // self.lhs[-1], self.lhs[-1], self.wk_fold, self.hnum.data_ptr(),
                 _ptr(self.hden),

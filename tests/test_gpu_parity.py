@@ -2314,3 +2314,56 @@ def test_nmfd_window_staging_against_oracle(dev):
         Wr = O.nmfd_w_step(V, Wr, Hr, 1, 1.0)
         Hr = O.nmfd_h_step(V, Wr, Hr, 1, 1.0)
     assert rel_err(m.W.data.cpu(), Wr) < TOL and rel_err(m.H.data.cpu(), Hr) < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Round 5: launch diet of the window-operand path (NMF2D / NMF3D / NMFD below 128 taps, beta == 1): the three rank-sum
+# launches and the Wk packing ride in the two apply kernels (nmfmu_conv_apply_pack_w_wk, nmfmu_conv_apply_h_rows_sums).
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cls,shape,rank,ks', [
+    ('NMF2D', (1, 20, 40, 72), 8, (8, 8)),        # 64 taps: every 64-wide k tile is one rank
+    ('NMF2D', (1, 70, 24, 80), 5, (4, 32)),       # 128 taps, rank 5: 51 positions per block step, idle lanes; two channel tiles
+    ('NMFD', (2, 33, 300), 16, (96,)),            # one shift axis below 128 taps (the short-kernel NMFD path), two batch entries
+    ('NMF3D', (2, 6, 9, 10, 24), 3, (2, 4, 8)),   # three shift axes, 64 taps
+])
+@pytest.mark.parametrize('prec', ['bf16x3', 'f16'])
+def test_rows_path_launch_diet(dev, cls, shape, rank, ks, prec):
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmfd_engine import ConvMU
+    g = torch.Generator().manual_seed(sum(shape) + rank)
+    V = torch.rand(*shape, generator=g) + 1e-3
+    W0 = torch.randn(shape[1], rank, *ks, generator=g).abs()
+    H0 = torch.randn(shape[0], rank, *[l - k + 1 for l, k in zip(shape[2:], ks)], generator=g).abs()
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['TORCHNMF_AMD_NMFD_ROWS_FUSED'] = mode
+        try:
+            W, H = W0.clone().to(dev), H0.clone().to(dev)
+            try:
+                eng = ConvMU(V.to(dev), W, H, 1.0, precision=prec)
+            except ValueError:
+                pytest.skip('fp16 planes are not built for this shape')
+            assert eng.h_rows and eng.rows_fused == (mode == '1')
+            for _ in range(3):
+                eng.w_step()
+                eng.h_step()
+            eng.refresh_images()                 # (an outside change of the factors: both forms must take it)
+            eng.w_step()
+            eng.h_step()
+            loss = eng.divergence()
+            torch.cuda.synchronize()
+            res[mode] = (W.cpu(), H.cpu(), loss)
+        finally:
+            os.environ.pop('TORCHNMF_AMD_NMFD_ROWS_FUSED', None)
+    # the rank sums are added in another order (tile / block partials instead of 128 chunks): fp32 rounding of the
+    # denominators; a single-plane mode then flips the odd operand rounding
+    tol = 1e-5 if prec == 'bf16x3' else 3e-4
+    assert rel_err(res['1'][0], res['0'][0]) < tol and rel_err(res['1'][1], res['0'][1]) < tol
+    assert abs(res['1'][2] - res['0'][2]) <= 1e-4 * abs(res['0'][2])
+    if prec == 'bf16x3':
+        Wr, Hr = W0, H0
+        w_step, h_step = (O.nmfd_w_step, O.nmfd_h_step) if len(ks) == 1 else (O.convnd_w_step, O.convnd_h_step)
+        for _ in range(4):
+            Wr = w_step(V, Wr, Hr, 1, 1.0)
+            Hr = h_step(V, Wr, Hr, 1, 1.0)
+        assert rel_err(res['1'][0], Wr) < TOL and rel_err(res['1'][1], Hr) < TOL
