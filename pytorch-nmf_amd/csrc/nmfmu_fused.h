@@ -619,6 +619,12 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       // by the fp16 half of the stored word (no separate conversion of x)
       constexpr bool MIX = C::F16 && !C::XF32 && BETA != kEuc;
       const float xa = MIX ? 1.f : x0, xb = MIX ? 1.f : x1;
+#ifdef NMFMU_FUSED_ABL_NOELEM
+      // timing-only ablation (wrong results; round 5): the transcendental / multiply chain of nmf.py:61-74 is
+      // gone, conversions and packing stay -- an UPPER bound of what hiding that chain behind the MFMAs could return, since the
+      // chain's own energy is removed as well (tools/gpu_r5g.sh, profiles/r05g_beta_lt1.md)
+      n0 = xa, n1 = xb, p0 = s0, p1 = s1;
+#else
       if constexpr (C::SCALE) {
         mu_elem_scaled<BETA>(s0, xa, a.beta, ki, n0, p0);
         mu_elem_scaled<BETA>(s1, xb, a.beta, ki, n1, p1);
@@ -626,6 +632,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         mu_elem<BETA>(s0, xa, a.beta, n0, p0);
         mu_elem<BETA>(s1, xb, a.beta, n1, p1);
       }
+#endif
       if constexpr (MIX) {
         const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
         float m0, m1;
