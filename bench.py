@@ -96,8 +96,8 @@ def parse():
                     'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
                     'into roofline.clock_mhz / power_w (0 disables)')
     a = ap.parse_args()
-    if a.precision == 'auto' and a.workload not in ('nmfd', 'nmf2d'):
-        ap.error("--precision auto: only for --workload nmfd / nmf2d (the dense workloads report 'auto' as real_data_mode)")
+    if a.precision == 'auto' and a.workload not in ('nmfd', 'nmf2d', 'betamu'):
+        ap.error("--precision auto: only for --workload nmfd / nmf2d / betamu (the dense workloads report 'auto' as real_data_mode)")
     return a
 
 
@@ -710,13 +710,13 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         all_ms = spans.get('w', []) + spans.get('h', [])
         avg_ms = sum(all_ms) / len(all_ms)
         flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
-        elt = 4 if precision in ('bf16x3', 'f16x') else 2
+        elt = 4 if eng.precision_name in ('bf16x3', 'f16x') else 2
         bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         pp = eng.step_h.block_rows == 256
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, precision, pp)[0],
-                'traffic_source': pmc_traffic(N, C, R, precision, pp)[1],
+                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, eng.precision_name, pp)[0],
+                'traffic_source': pmc_traffic(N, C, R, eng.precision_name, pp)[1],
                 'kernel': 'nmfmu::pp_kernel' if pp else 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
                 'avg_launch_ms': round(avg_ms, 5),
                 'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
@@ -959,7 +959,8 @@ def _spawned(local_rank, nprocs, port, argv):
 def main():
     a = parse()
     if a.precision is None:
-        a.precision = 'f16' if a.workload in ('nmf', 'nmfd') else 'bf16'
+        # (betamu: the optimizer's own default -- 'auto' resolves like NMF.fit's since round 5)
+        a.precision = 'f16' if a.workload in ('nmf', 'nmfd') else ('auto' if a.workload == 'betamu' else 'bf16')
     if a.workload == 'plca':
         assert int(os.environ.get('WORLD_SIZE', '1')) == 1, 'PLCA is not sharded'
         torch.cuda.set_device(0)
@@ -1031,6 +1032,9 @@ def main():
 
     head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu, telemetry=True,
                      gram=a.gram and beta == 2 and world == 1)
+    asked = a.precision
+    if a.precision == 'auto':            # betamu: report what the optimizer's 'auto' resolved to
+        a.precision = head['eng'].precision_name
     # secondary, clearly labelled object: the other single-plane operand type, timed in the same run
     other = {'f16': 'bf16', 'bf16': 'f16'}.get(a.precision)
     second = None
@@ -1187,6 +1191,7 @@ def main():
             'ref_notebook': ref_nb,
         }
         if betamu:
+            out['config']['precision_asked'] = asked
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \
                 'returns the layer (deferred reconstruction)'
         print(json.dumps(out))

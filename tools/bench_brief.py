@@ -2,7 +2,7 @@
 import json
 import sys
 
-d = json.load(open(sys.argv[1]))
+d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])   # (RCCL may print banner lines first)
 short = len(sys.argv) > 2
 
 
