@@ -739,7 +739,11 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
                 roof['frac_of_peak_at_measured_clock'] = round(ach / pk, 4)
             roof['telemetry'] = tel
         if telemetry and world == 1 and hasattr(eng.be, 'lib') and hasattr(eng.be.lib, 'nmfmu_ubench_mfma_hbm') and not betamu:
-            ceil = ceiling_leg(a, eng, dev)
+            try:
+                ceil = ceiling_leg(a, eng, dev)
+            except Exception as ex:          # a diagnostic leg must never take the bench line down with it
+                ceil = None
+                roof['ceiling_error'] = f'{type(ex).__name__}: {ex}'[:200]
             if ceil is not None:
                 roof['ceiling'] = ceil
                 roof['ceiling_tflops'] = ceil['with_stream']['tflops']
@@ -1162,7 +1166,10 @@ def main():
 
     ref_nb = None
     if default_run or a.ref_notebook:
-        ref_nb = ref_notebook_leg(a, dev, do_cpu)
+        try:
+            ref_nb = ref_notebook_leg(a, dev, do_cpu)
+        except Exception as ex:              # (context leg: report the failure instead of losing the whole line)
+            ref_nb = {'error': f'{type(ex).__name__}: {ex}'[:300]}
 
     if rank == 0:
         ms_per_step = head['ms_per_step']
