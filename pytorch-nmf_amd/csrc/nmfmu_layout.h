@@ -58,11 +58,12 @@ constexpr int kWaves = 4;
 // ds_read_b128 operand reads of the first GEMM (16 lanes = 16 rows, one logical slot) conflict free.  Its TOP bits come
 // from the LOWEST of those row bits: the transposing reads of the second GEMM (ds_read_b64_tr_b16, nmfmu_pp.h) fetch
 // four consecutive rows x 64 bytes per 32-lane pass, and four consecutive rows must land in four different bank
-// quarters.  (Padded rank 256 is not served by that path and keeps the plain row & 15.)
+// quarters.  Padded rank 256 (two bank lines per row) takes the rank-128 value: its rank-256 TR path (fused kernel,
+// beta = 1) measured SQ_LDS_BANK_CONFLICT at 60 % of SQ_LDS_IDX_ACTIVE with the plain row & 15 it had through round 4
+// (profiles/r05n_cfg5_rank256_sq_pmc_summary.txt): four consecutive rows XORed with 0..3 stay inside one quarter.
 NMFMU_HD int p1_swz(int row, int r_pad) {
   const int sp = r_pad / 8;                                              // 16-byte slots per row
-  if (sp >= 32) return row & 15;
-  if (sp == 16) return ((row & 3) << 2) | ((row >> 2) & 3);
+  if (sp >= 16) return ((row & 3) << 2) | ((row >> 2) & 3);
   if (sp == 8) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
   return (row >> 2) & 3;                                                 // sp == 4
 }

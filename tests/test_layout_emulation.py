@@ -16,9 +16,7 @@ EPS = np.float64(2.0 ** -23)
 # ---- layouts (mirror of csrc/nmfmu_layout.h) ---------------------------------------------------------------
 def p1_swz(row, r_pad):
     sp = r_pad // 8
-    if sp >= 32:
-        return row & 15
-    if sp == 16:
+    if sp >= 16:
         return ((row & 3) << 2) | ((row >> 2) & 3)
     if sp == 8:
         return (((row >> 1) & 1) << 2) | ((row >> 2) & 3)
@@ -224,7 +222,7 @@ def _tr_read(img, addr):
     return out
 
 
-@pytest.mark.parametrize('r_pad', [32, 64, 128])
+@pytest.mark.parametrize('r_pad', [32, 64, 128, 256])
 def test_transposing_reads_gather_the_g2_operand_conflict_free(r_pad):
     """For every (tt, m2, h, rt): the kernel's per-lane addresses make lane (j, hl) receive panel rows
     32 hl + 16 tt + 8 m2 + 4 h + (0..3) of rank 32 rt + j from the swizzled row-major tile, and each 32-lane pass touches
