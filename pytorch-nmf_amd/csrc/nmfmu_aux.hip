@@ -141,8 +141,16 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
         // not bandwidth, bounds a dependent chain), combined in a fixed order
         float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
         int s0 = 0;
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        for (; s0 + 16 <= a.nslab; s0 += 16) {   // (same order of additions as the rounds of eight)
+          f32x4_t v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(a.num + (size_t)(s0 + u) * plane + e));
+#pragma unroll
+          for (int u = 0; u < 16; ++u) n4.x += v[u].x, n4.y += v[u].y, n4.z += v[u].z, n4.w += v[u].w;
+        }
         for (; s0 + 8 <= a.nslab; s0 += 8) {
-          typedef float f32x4_t __attribute__((ext_vector_type(4)));
           f32x4_t v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u)

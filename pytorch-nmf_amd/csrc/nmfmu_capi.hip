@@ -130,6 +130,9 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     return launch_pp(st->r_pad, st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16, mode, a, grid, s);
   }
   const int kk = kernel_beta_kind(st->beta);
+#ifdef NMFMU_DEBUG_HOOKS
+  a.debug = mode == kModeXB ? g_pp_debug : nullptr;   // per-workgroup phase stamps of the streaming kernel (tools/xb_timeline.py)
+#endif
   switch (st->r_pad) {
     case 32: return launch_fused_r32(kk, st->precision, mode, a, grid, s);
     case 64: return launch_fused_r64(kk, st->precision, mode, a, grid, s);

@@ -185,7 +185,10 @@ struct FusedCfg {
   static constexpr bool G1_ASM = NMFMU_FUSED_G1_ASM && !X3 && MINW == 1;
   // kModeXB streams: four (fp32 target: three) ring stages, tiles t+1 .. t+3 in flight behind tile t (counted waits); at padded rank 128 the
   // ring is exactly as large as its epilogue's staging tile (4 waves x 32 rows x R_PAD floats)
-  static constexpr int NSTAGE = DEEP ? (XF32 ? 3 : 4) : 2;   // (fp32 X buffers are 32 registers each: three of them)
+#ifndef NMFMU_XB_NSTAGE
+#define NMFMU_XB_NSTAGE 4
+#endif
+  static constexpr int NSTAGE = DEEP ? (XF32 ? 3 : NMFMU_XB_NSTAGE) : 2;   // (fp32 X buffers are 32 registers each: three of them)
   // the fused-apply epilogue stages 4 waves x 32 rows x R_PAD floats in LDS (= two stages of two images; more than the
   // ring of the single-image instances)
   static constexpr int EPI_BYTES = (XB || TR) ? WAVES * 32 * R_PAD * 4 : 0;
@@ -346,7 +349,15 @@ __device__ __forceinline__ float loss_elem(float s, float x, float beta) {
 template <int NQ, int Q = 0>
 __device__ __forceinline__ void xb_load_x(const char* p, u32x4 (&x)[NQ]) {   // this lane's NQ 16-byte chunks of a tile, by asm
   if constexpr (Q < NQ) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(x[Q]) : "v"(p + Q * 1024) : "memory");
+#ifndef NMFMU_XB_XPOL
+#define NMFMU_XB_XPOL " nt"
+#endif
+#ifdef NMFMU_XB_ABL_NOX
+    x[Q] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // timing-only: no X stream
+    asm volatile("" : "+v"(x[Q]));
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off" NMFMU_XB_XPOL : "=&v"(x[Q]) : "v"(p + Q * 1024) : "memory");
+#endif
     xb_load_x<NQ, Q + 1>(p, x);
   }
 }
@@ -395,6 +406,25 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   const int m0 = mb * BM + wave * 32 + j;
 
   if constexpr (C::F16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: saturate
+  // Diagnostic builds (make EXTRA=-DNMFMU_DEBUG_HOOKS; tools/xb_timeline.py), kModeXB: wave 0 of every workgroup records the
+  // constant 100 MHz clock at kernel entry (slot 2), at the start (0) and the end (1) of the tile loop and at exit (3),
+  // and where it ran (slot 4: XCC_ID << 32 | HW_ID) -- the layout of the ping-pong kernel's stamps (nmfmu_pp.h)
+  auto stamp = [&](int slot) {
+#ifdef NMFMU_DEBUG_HOOKS
+    if constexpr (C::XB) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.debug);
+      if (!dbg || wave != 0) return;
+      const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) {
+        dbg[64 + 5 * blockIdx.x + slot] = r;
+        if (slot == 2)
+          dbg[64 + 5 * blockIdx.x + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                                         (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+      }
+    }
+#endif
+  };
+  stamp(2);
 
   // ---- fp16 operands, beta < 1: scale 2^ki of Gn / Gp from the typical S = sum_r colsum_A[r] colsum_B[r] / (M K)
   // (every workgroup computes the same value in the same order; ki ends up in a scalar register)
@@ -417,7 +447,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
   // ---- owner fragments (B operand of GEMM1): row m, rank slice 16*kk + 8*hl .. +7
   u32x4 qh[KS];
   u32x4 ql[X3 ? KS : 1];
-  {
+  auto load_owner_frags = [&]() {
     const int sw = P1Swz<R_PAD>::of(m0) << 4;
     const char* rowh = reinterpret_cast<const char*>(a.a1_hi) + (size_t)m0 * ROWB;
     const char* rowl = reinterpret_cast<const char*>(a.a1_lo) + (size_t)m0 * ROWB;
@@ -427,7 +457,10 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       qh[kk] = ld16(rowh + off);
       if constexpr (X3) ql[kk] = ld16(rowl + off);
     }
-  }
+  };
+  // (kModeXB has no first GEMM: its denominator product reads them in the epilogue and fetches them there -- 4 * KS
+  // registers less across the stream loop, and nothing queued in front of the first X tile)
+  if constexpr (!C::XB) load_owner_frags();
 
   // ---- per-lane LDS offsets
   // GEMM1 A operand: MFMA row i = j of S^T tile tt reads panel row pi_tt(j); with this
@@ -760,13 +793,36 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     // both NSTAGE - 1 tiles ahead, every load issued from inline asm with ONE counted wait per tile (tile t has landed when
     // at most the loads of tiles t+1 .. t+NSTAGE-2 are outstanding; tile t+NSTAGE-1 is issued right behind that wait's
     // barrier, into the stage / registers tile t-1 has just vacated).
+    stamp(0);
     if (t0 < t1) {
       const int nt = t1 - t0;
       constexpr int NST = C::NSTAGE;
-      constexpr int OPS = C::NIMG * C::PASSES + NQ;   // vm operations per tile and thread (LDS-DMA pieces + X chunks)
+      // (timing-only ablations NMFMU_XB_ABL_{NOX,NODMA,NOGEMM}: tools/gpu_r5q.sh, profiles/r05q_beta2_stream.md)
+#ifdef NMFMU_XB_ABL_NOX
+      constexpr int OPS_X = 0;
+#else
+      constexpr int OPS_X = NQ;
+#endif
+#ifdef NMFMU_XB_ABL_NODMA
+      constexpr int OPS_P = 0;
+#else
+      constexpr int OPS_P = C::NIMG * C::PASSES;
+#endif
+      constexpr int OPS = OPS_P + OPS_X;   // vm operations per tile and thread (LDS-DMA pieces + X chunks)
       static_assert((NST - 2) * OPS <= 63, "vmcnt range");
       u32x4 xr[NST][NQ];
+#ifdef NMFMU_XB_ABL_NODMA
+      auto stage_issue = [&](int, int) {};
+#endif
+#ifdef NMFMU_XB_ABL_TILEMAJOR
+      // timing-only (wrong results): the same bytes in tile-major order -- at step t the workgroups read ADJACENT 16 KiB
+      // blocks instead of blocks ktiles * 16 KiB apart (is the stream's rate a matter of DRAM channel / page locality?)
+      const char* xtm = reinterpret_cast<const char*>(a.xp) + ((size_t)mb * 4 + wave) * (NQ * 1024) + lane * 16;
+      const size_t xtm_stride = (size_t)(gridDim.x / a.nsplit) * (4 * NQ * 1024);
+      auto load_x_asm = [&](int t, u32x4(&x)[NQ]) { xb_load_x<NQ>(xtm + (size_t)t * xtm_stride, x); };
+#else
       auto load_x_asm = [&](int t, u32x4(&x)[NQ]) { xb_load_x<NQ>(xbase + (size_t)t * (4 * NQ * 1024), x); };
+#endif
       auto landed = [&](int later, u32x4(&x)[NQ]) {   // `later` tiles issued after this one may still be in flight
         if (later >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPS) : "memory");
         else if (later == 1 && NST > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
@@ -784,7 +840,12 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         }
         GOps g;
         to_ops(xr[b], g);
+#ifdef NMFMU_XB_ABL_NOGEMM
+#pragma unroll
+        for (int d = 0; d < 8; ++d) asm volatile("" ::"v"(g.gnh[0][d]), "v"(g.gnh[1][d]));   // timing-only: no MFMA, no LDS reads
+#else
         gemm2(smem + b * C::STAGE_BYTES, g);
+#endif
       };
       static_for<NST - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
@@ -801,6 +862,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       });
       __syncthreads();   // the epilogue re-uses the ring as its staging tile
     }
+    stamp(1);
   } else if (t0 < t1) {
     // ---------------- main loop: LDS double buffer for the panel, X in ONE register buffer that is refilled with the
     // next tile right after its last use; one drain + barrier per tile.
@@ -841,24 +903,92 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     if constexpr (C::XB && !X3) {
       // fused apply (unsplit contraction), or -- split contraction -- the ks == 0 workgroup of every row block leaves the
       // denominator as ONE slab next to the nsplit numerator slabs (a.slab_den; the apply kernel then has nothing to form)
-      const bool den_here = (a.fuse_apply && R_PAD <= 128) || (!a.fuse_apply && ks == 0 && a.slab_den && a.gram_hi);
-      if (den_here) {
+      // (round 5) split contraction: the rank tiles of the denominator are shared out over the first min(nsplit, RT)
+      // workgroups of the row block (tile rt belongs to ks == rt % nd) instead of all landing on ks == 0, whose epilogue was
+      // the launch's straggler (28 us against 2-5 us, tools/xb_timeline.py)
+      const int nd = a.nsplit < RT ? a.nsplit : RT;
+      const bool den_fused = a.fuse_apply && R_PAD <= 128;
+      const bool den_split = !a.fuse_apply && ks < nd && a.slab_den && a.gram_hi;
+      if (den_fused || den_split) {
         // denominator of kModeXB: den[m][r] = sum_q owner[m][q] G[q][r] as MFMA(owner fragments, Gram image rows r): the
         // same (row from the register index, column from the lane) layout as the numerator accumulators.  The image row r
         // carries 2^-exp[r]; hi + lo planes make the matrix itself exact to 2^-22, what is left is the owner's own rounding.
+        // (round 5) At padded rank 64 / 128 the image rows come through LDS: the ring is free by now, one LDS-DMA pass
+        // fetches 4 KiB and all passes are in flight together, where the 2 * KS * RT dependent 16-byte global loads per
+        // lane were a chain of L2 latencies.  LDS slot s of row r holds image slot s ^ gswz(r), so that the 16 lanes of a
+        // ds_read_b128 group (16 consecutive rows, one image slot) touch 16 different bank groups.
+        constexpr bool GLDS = R_PAD == 64 || R_PAD == 128;
+        constexpr int GSP = R_PAD / 8, GRPL = GSP >= 16 ? 1 : 16 / GSP;   // slots per row, rows per 256-byte bank line
+        constexpr int GPLANE = R_PAD * ROWB;                              // bytes of one image
+        load_owner_frags();
+        // the fused apply's master rows are TOUCHED here (one dword per 128-byte line of the wave's 32 rows) so that their
+        // HBM latency overlaps the Gram staging and its MFMAs; the apply's own loads then hit L2.  (Holding the 64 values
+        // themselves across the product was tried: 43 registers spilled.)
+        constexpr int NTOUCH = 32 * R_PAD * 4 / 128 / 64;   // lines of the wave's rows per lane
+        uint32_t touch[NTOUCH > 0 ? NTOUCH : 1];
+        const bool touched = den_fused && NTOUCH > 0 && a.rank == R_PAD && mb * BM + wave * 32 + 32 <= a.M;
+        if (touched) {
+#pragma unroll
+          for (int k = 0; k < NTOUCH; ++k) {
+            const char* tp = reinterpret_cast<const char*>(a.f) + ((size_t)(mb * BM + wave * 32) * R_PAD * 4) + (size_t)(k * 64 + lane) * 128;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(touch[k]) : "v"(tp) : "memory");
+          }
+        }
+        if constexpr (GLDS) {
+          constexpr int GP = 32 * ROWB / 4096;                            // passes per rank tile and plane
+          static_for<RT>([&](auto rtc) {
+            constexpr int rt = decltype(rtc)::value;
+            if (den_fused || rt % nd == ks) {
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) {
+                const char* gsrc = reinterpret_cast<const char*>(pl ? a.gram_lo : a.gram_hi);
+#pragma unroll
+                for (int p = 0; p < GP; ++p) {
+                  const int o = rt * 32 * ROWB + p * 4096 + tid * 16, r = o / ROWB, sl = (o % ROWB) >> 4;
+                  const char* src = gsrc + r * ROWB + ((sl ^ ((r / GRPL) & (GSP - 1))) << 4);
+                  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+                      lds_base + (unsigned)(pl * GPLANE + rt * 32 * ROWB + p * 4096) + wave_lds);
+                  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                               :
+                               : "v"(src), "s"(lds_addr)
+                               : "memory", "m0");
+                }
+              }
+            }
+          });
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+        if (touched) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < NTOUCH; ++k) asm volatile("" ::"v"(touch[k]));   // (their registers were reserved until here)
+        }
         static_for<RT>([&](auto rtc) {   // (compile-time indices: op / qh must stay in registers)
           constexpr int rt = decltype(rtc)::value;
-          const char* grow = reinterpret_cast<const char*>(a.gram_hi) + (size_t)(rt * 32 + j) * ROWB + hl * 16;
-          const char* grow_lo = reinterpret_cast<const char*>(a.gram_lo) + (size_t)(rt * 32 + j) * ROWB + hl * 16;
-          static_for<KS>([&](auto kc) {
-            constexpr int kk = decltype(kc)::value;
-            op[rt] = mfma_op<OPT>(qh[kk], ld16(grow + kk * 32), op[rt]);
-            op[rt] = mfma_op<OPT>(qh[kk], ld16(grow_lo + kk * 32), op[rt]);
-          });
-          const float gs = a.gram_scale[rt * 32 + j];
+          if (den_fused || rt % nd == ks) {
+            const int gr = rt * 32 + j;
+            const char* grow = reinterpret_cast<const char*>(a.gram_hi) + (size_t)gr * ROWB + hl * 16;
+            const char* grow_lo = reinterpret_cast<const char*>(a.gram_lo) + (size_t)gr * ROWB + hl * 16;
+            const char* lrow = smem + gr * ROWB;
+            const int gsw = (gr / GRPL) & (GSP - 1);
+            static_for<KS>([&](auto kc) {
+              constexpr int kk = decltype(kc)::value;
+              if constexpr (GLDS) {
+                const int off = ((2 * kk + hl) ^ gsw) << 4;
+                op[rt] = mfma_op<OPT>(qh[kk], ld16(lrow + off), op[rt]);
+                op[rt] = mfma_op<OPT>(qh[kk], ld16(lrow + GPLANE + off), op[rt]);
+              } else {
+                op[rt] = mfma_op<OPT>(qh[kk], ld16(grow + kk * 32), op[rt]);
+                op[rt] = mfma_op<OPT>(qh[kk], ld16(grow_lo + kk * 32), op[rt]);
+              }
+            });
+            const float gs = a.gram_scale[rt * 32 + j];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) op[rt][e] *= gs;
+            for (int e = 0; e < 16; ++e) op[rt][e] *= gs;
+          }
         });
+        if constexpr (GLDS) __syncthreads();   // the fused apply re-uses the same LDS as its staging tile
       }
     }
     if constexpr (BETA == kKL || (C::TWO_ACC && !X3 && R_PAD <= 128)) {   // (rank pad 256 x two sets: no registers left)
@@ -1006,13 +1136,21 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
           const size_t idx = slab + (size_t)row * R_PAD + rt * 32 + j;
           a.slab_num[idx] = C::SCALE ? on[rt][e] * unsc : on[rt][e];
           if constexpr (C::TWO_ACC && !C::XB) a.slab_den[idx] = C::SCALE ? op[rt][e] * unsc : op[rt][e];
-          if constexpr (C::XB) {
-            if (ks == 0 && a.slab_den && a.gram_hi) a.slab_den[idx] = op[rt][e];   // (idx: slab 0 when ks == 0)
+          if constexpr (C::XB) {   // this workgroup's share of the ONE denominator slab (see den_split above)
+            const int nd = a.nsplit < RT ? a.nsplit : RT;
+            if (ks < nd && rt % nd == ks && a.slab_den && a.gram_hi)
+              a.slab_den[((size_t)mb * BM + wave * 32 + row) * R_PAD + rt * 32 + j] = op[rt][e];
           }
         }
       });
     }
   }
+#ifdef NMFMU_DEBUG_HOOKS
+  if constexpr (C::XB) {
+    if (a.debug) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
+    stamp(3);
+  }
+#endif
 }
 
 // Host-side launcher, one per (R_PAD) translation unit.  prec = NMFMU_PREC_*, beta_kind = BetaKind.

@@ -39,6 +39,44 @@ __global__ void __launch_bounds__(256) gram_partial_kernel(const char* __restric
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   // byte offset of this lane's slot for k-step kk inside rank row r of a tile: r * 128 + ((2 kk + hl) ^ ((r >> 1) & 7)) * 16
   auto slot = [&](int r, int kk) { return r * 128 + (((2 * kk + hl) ^ ((r >> 1) & 7)) << 4); };
+  if constexpr (R_PAD <= 128) {
+    // (round 5) one tile-row per wave (NTR == 1): the 4 * (RT + 1) fragment loads of a tile are issued together and the
+    // next tile's go out before this tile's MFMAs (two register sets) -- a chunk of four tiles was four HBM latencies in
+    // a row (10 us per launch, twice per beta = 2 iteration); the MFMA order per accumulator is unchanged
+    static_assert(NTR == 1, "one tile row per wave");
+    u32x4 fa[2][4], fb[2][4][RT];
+    const bool live = wave < RT;
+    auto ld = [&](int t, auto bc) {
+      constexpr int b = decltype(bc)::value;
+      const char* tile = p2 + (size_t)t * (R_PAD * 128);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        fa[b][kk] = ld16(tile + slot(32 * (live ? wave : 0) + j, kk));
+#pragma unroll
+        for (int q = 0; q < RT; ++q) fb[b][kk][q] = ld16(tile + slot(32 * q + j, kk));
+      }
+    };
+    auto mm = [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int q = 0; q < RT; ++q) acc[0][q] = mfma_op<OPT>(fa[b][kk], fb[b][kk][q], acc[0][q]);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    if (live && t0 < t1) {
+      ld(t0, B0{});
+      int t = t0;
+      for (; t + 2 <= t1; t += 2) {
+        ld(t + 1, B1{});
+        mm(B0{});
+        if (t + 2 < t1) ld(t + 2, B0{});
+        mm(B1{});
+      }
+      if (t < t1) mm(B0{});
+    }
+  } else
   for (int t = t0; t < t1; ++t) {
     const char* tile = p2 + (size_t)t * (R_PAD * 128);
 #pragma unroll
@@ -91,6 +129,13 @@ __global__ void __launch_bounds__(256) gram_finalize_kernel(const float* __restr
     const float4* src = reinterpret_cast<const float4*>(part + (size_t)r * r_pad) + c4;
     const size_t cstride = (size_t)r_pad * r_pad / 4;
     int ch = grp;
+    for (; ch + 15 * ngrp < nchunk; ch += 16 * ngrp) {   // (same order of additions as the rounds of eight below)
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(ch + u * ngrp) * cstride];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
+    }
     for (; ch + 7 * ngrp < nchunk; ch += 8 * ngrp) {
       float4 v[8];
 #pragma unroll
@@ -170,7 +215,9 @@ int nmfmu_gram_panel(const nmfmu_factor* panel, int r_pad, int precision, void* 
   if (precision != NMFMU_PREC_BF16 && precision != NMFMU_PREC_F16 && precision != NMFMU_PREC_F16X) return NMFMU_ERR_UNSUPPORTED;
   const int f16 = precision != NMFMU_PREC_BF16;
   const int ktiles = panel->rows_pad / 64;
-  int nchunk = (ktiles + kGramTilesPerChunk - 1) / kGramTilesPerChunk;
+  // one tile per chunk while that stays within kGramMaxChunks (a 4096-row factor: 64 workgroups and one HBM latency
+  // instead of 16 workgroups and four), four tiles per chunk at 65536 rows
+  int nchunk = ktiles <= kGramMaxChunks ? ktiles : (ktiles + kGramTilesPerChunk - 1) / kGramTilesPerChunk;
   if (nchunk > kGramMaxChunks) nchunk = kGramMaxChunks;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const char* p2 = static_cast<const char*>(panel->p2_hi);
