@@ -106,7 +106,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
     if (kind != kEuc || x3 || st->block_rows != 128) return NMFMU_ERR_UNSUPPORTED;
     if (!a.p2_hi || (!fuse_apply && !a.slab_num)) return NMFMU_ERR_ARG;
     if (fuse_apply && (!gm || st->r_pad > 128)) return NMFMU_ERR_ARG;
-    if (gm) {   // denominator in the kernel: fused apply, or ONE denominator slab written by the ks == 0 workgroups
+    if (gm) {   // denominator in the kernel: fused apply, or ONE denominator slab, its rank tiles shared out over the row block's first workgroups
       if (!gm->hi || !gm->lo || !gm->scale || (!fuse_apply && !a.slab_den)) return NMFMU_ERR_ARG;
       a.gram_hi = static_cast<const uint16_t*>(gm->hi), a.gram_lo = static_cast<const uint16_t*>(gm->lo);
       a.gram_scale = gm->scale;
@@ -365,7 +365,7 @@ int nmfmu_xb_step(const nmfmu_step* st, const void* g_hi, const void* g_lo, cons
   if (!nmfmu_xb_supported(st->r_pad, st->precision, st->beta)) return NMFMU_ERR_UNSUPPORTED;
   // the workgroup owns whole rows (unsplit contraction): numerator, denominator (owner fragments x Gram image) and
   // nmf.py:78-92 in the kernel's epilogue; otherwise nsplit numerator slabs + ONE denominator slab (written by the first
-  // workgroup of every row block, the same MFMA product) + the apply kernel
+  // min(nsplit, r_pad / 32) workgroups of every row block, one 32-rank tile each, the same MFMA product) + the apply kernel
   const bool fuse = st->nsplit == 1 && st->owner.f && st->owner.p2_hi && st->owner.colsum && st->owner.colsum_part &&
                     st->r_pad <= 128;
   if (!fuse && !st->slab_den) return NMFMU_ERR_ARG;

@@ -901,8 +901,8 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
     // accumulator register e of lane (j, hl): row (e&3) + 8*(e>>2) + 4*hl, column 32*rt + j
     bool fused_done = false;
     if constexpr (C::XB && !X3) {
-      // fused apply (unsplit contraction), or -- split contraction -- the ks == 0 workgroup of every row block leaves the
-      // denominator as ONE slab next to the nsplit numerator slabs (a.slab_den; the apply kernel then has nothing to form)
+      // fused apply (unsplit contraction), or -- split contraction -- the denominator is left as ONE slab next to the
+      // nsplit numerator slabs (a.slab_den; the apply kernel then has nothing to form).
       // (round 5) split contraction: the rank tiles of the denominator are shared out over the first min(nsplit, RT)
       // workgroups of the row block (tile rt belongs to ks == rt % nd) instead of all landing on ks == 0, whose epilogue was
       // the launch's straggler (28 us against 2-5 us, tools/xb_timeline.py)

@@ -207,6 +207,51 @@ def test_lds_reads_are_bank_conflict_free(r_pad):
                 assert len(slots) == 16, ('P2', tt, m2)
 
 
+@pytest.mark.parametrize('r_pad', [64, 128])
+def test_gram_images_through_lds(r_pad):
+    """Round 5, kModeXB epilogue (nmfmu_fused.h): the Gram images reach the MFMAs through LDS.  One LDS-DMA pass writes
+    4 KiB linearly (thread tid -> byte tid * 16 of the pass); the SOURCE address carries the swizzle, so that LDS slot s of row
+    r holds image slot s ^ gswz(r).  The reader of (row r, image slot q = 2 kk + hl) then looks at slot q ^ gswz(r): it must
+    get image slot q, and the 16 lanes of every ds_read_b128 service group must touch 16 different 16-byte bank groups."""
+    rowb = 2 * r_pad
+    gsp = r_pad // 8
+    grpl = 1 if gsp >= 16 else 16 // gsp
+    gswz = lambda r: (r // grpl) & (gsp - 1)
+    passes = 32 * rowb // 4096                       # per rank tile and plane
+    lds = {}                                         # LDS byte offset of a 16-byte slot -> (image row, image slot)
+    for rt in range(r_pad // 32):
+        for p in range(passes):
+            for tid in range(256):
+                o = rt * 32 * rowb + p * 4096 + tid * 16
+                r, sl = o // rowb, (o % rowb) >> 4
+                src = r * rowb + ((sl ^ gswz(r)) << 4)               # byte offset in the image
+                assert o not in lds
+                lds[o] = (src // rowb, (src % rowb) >> 4)
+    assert len(lds) == r_pad * gsp                                    # the whole image, every slot once
+    assert sorted(lds.values()) == [(r, q) for r in range(r_pad) for q in range(gsp)]
+    for rt in range(r_pad // 32):
+        for kk in range(r_pad // 16):
+            for grp in _b128_groups():
+                banks = set()
+                for ln in grp:
+                    j, hl = ln & 31, ln >> 5
+                    r = rt * 32 + j
+                    off = r * rowb + (((2 * kk + hl) ^ gswz(r)) << 4)
+                    assert lds[off] == (r, 2 * kk + hl)
+                    banks.add((off % 256) // 16)
+                assert len(banks) == 16, (r_pad, rt, kk)
+
+
+def test_denominator_slab_is_shared_out_completely():
+    """Round 5: with a split contraction the rank tiles of the ONE denominator slab are computed by the first
+    nd = min(nsplit, RT) workgroups of a row block, tile rt by ks == rt % nd -- every tile exactly once for every split."""
+    for rt_n in (1, 2, 4, 8):
+        for nsplit in (1, 2, 3, 4, 5, 8, 16, 33):
+            nd = min(nsplit, rt_n)
+            owners = [[ks for ks in range(nsplit) if ks < nd and rt % nd == ks] for rt in range(rt_n)]
+            assert all(len(o) == 1 for o in owners), (rt_n, nsplit, owners)
+
+
 # ---- single panel image: the second GEMM's operands by ds_read_b64_tr_b16 (nmfmu_pp.h, PPCfg::TR) --------------------
 def _tr_read(img, addr):
     """ds_read_b64_tr_b16 as probed on gfx950 (tools/ubench/tr_probe.hip): within each group of 16 lanes, lane 4a+b
