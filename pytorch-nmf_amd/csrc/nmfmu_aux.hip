@@ -93,8 +93,14 @@ int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose
 // apply: nmf.py:78-92 on a 64-row stripe of the owner factor, then re-emit that stripe's bf16 images (P1 rows,
 // one whole P2 tile) and its partial column sums.  PACK_ONLY skips the update (initial packing of W0 / H0).
 // ------------------------------------------------------------------------------------------------------------
-template <int R_PAD, bool X3, bool PACK_ONLY, int ROWS>
-__global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
+// (round 5) NT threads per block: 512 when the update phase has at least 512 (row, four-rank) items, so that every thread
+// has ONE item and all of a block's slab / master loads are in flight together -- with 256 threads the short-factor
+// instance (16 rows x 128 ranks) ran two items per thread one after the other, i.e. two HBM round trips per launch.
+template <int ROWS, int R_PAD>
+constexpr int apply_threads() { return ROWS * (R_PAD / 4) >= 512 ? 512 : 256; }
+
+template <int R_PAD, bool X3, bool PACK_ONLY, int ROWS, int NT>
+__global__ void __launch_bounds__(NT) apply_kernel(ApplyArgs a) {
   // ROWS = 64 (one whole P2 tile per block) for tall factors, 16 for short ones so that the grid still fills the chip.
   constexpr int LDT = R_PAD + 1;  // odd leading dimension: the P2 column reads below stay <= 2-way bank conflicted
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -109,13 +115,13 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   float* rowsum = tile + ROWS * LDT;  // [ROWS]
   if constexpr (!PACK_ONLY) {
     if (a.trainer && a.ortho > 0.f) {
-      for (int idx = tid; idx < ROWS * R_PAD; idx += 256) {
+      for (int idx = tid; idx < ROWS * R_PAD; idx += NT) {
         const int rl = idx / R_PAD, r = idx - rl * R_PAD;
         const int row = row0 + rl;
         tile[rl * LDT + r] = (row < a.rows && r < a.rank) ? a.f[(size_t)row * a.rank + r] : 0.f;
       }
       __syncthreads();
-      for (int rl = tid; rl < ROWS; rl += 256) {
+      for (int rl = tid; rl < ROWS; rl += NT) {
         float s = 0.f;
         for (int r = 0; r < a.rank; ++r) s += tile[rl * LDT + r];
         rowsum[rl] = s;
@@ -123,7 +129,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
       __syncthreads();
     }
   }
-  for (int idx = tid; idx < ROWS * R4; idx += 256) {
+  for (int idx = tid; idx < ROWS * R4; idx += NT) {
     const int rl = idx / R4, r = (idx - rl * R4) * 4;
     const int row = row0 + rl;
     float f[4] = {0.f, 0.f, 0.f, 0.f};
@@ -207,7 +213,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   // P1: ROWS rows x (R_PAD/8) sixteen-byte slots, swizzled inside each row
   constexpr int SP = R_PAD / 8;
   bool clamped = false;   // fp16 images: a factor value above 65504 is stored as 65504 -- tell the caller (status word)
-  for (int idx = tid; idx < ROWS * SP; idx += 256) {
+  for (int idx = tid; idx < ROWS * SP; idx += NT) {
     const int rl = idx / SP, slot = idx - rl * SP;
     const float* src = tile + rl * LDT + slot * 8;
     u32x4 hi, lo;
@@ -226,7 +232,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
   if (a.f16 && a.status && __any(clamped) && (tid & 63) == 0) atomicOr(a.status, 1u);
   // P2: [R_PAD][64] tiles; this block owns ROWS/8 of the 8 slots (8 consecutive factor rows each) of every rank row
   constexpr int NS = ROWS / 8;
-  for (int idx = tid; idx < R_PAD * NS; idx += 256) {
+  for (int idx = tid; idx < R_PAD * NS; idx += NT) {
     const int r = idx / NS, sl = idx - r * NS;
     u32x4 hi, lo;
 #pragma unroll
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(256) apply_kernel(ApplyArgs a) {
     if constexpr (X3) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p2_lo) + off) = lo;
   }
   // partial column sums of this stripe (fixed order -> deterministic)
-  for (int r = tid; r < R_PAD; r += 256) {
+  for (int r = tid; r < R_PAD; r += NT) {
     float s = 0.f;
 #pragma unroll 8
     for (int rl = 0; rl < ROWS; ++rl) s += tile[rl * LDT + r];
@@ -288,15 +294,16 @@ template <int R_PAD, int ROWS>
 int launch_apply_rr(const ApplyArgs& a, bool x3, bool pack_only, hipStream_t s) {
   const int grid = a.rows_pad / ROWS;
   const size_t lds = (size_t)ROWS * (R_PAD + 1) * sizeof(float) + ROWS * sizeof(float);   // tile + row sums
+  constexpr int NT = apply_threads<ROWS, R_PAD>();
 #define L(X, P)                                                                                                      \
   {                                                                                                                  \
-    auto k = apply_kernel<R_PAD, X, P, ROWS>;                                                                        \
+    auto k = apply_kernel<R_PAD, X, P, ROWS, NT>;                                                                      \
     if (lds > 64 * 1024) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds);                                                                  \
       if (e != hipSuccess) return (int)e;                                                                            \
     }                                                                                                                \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, s, a);                                                          \
   }
   if (x3 && pack_only) L(true, true)
   else if (x3) L(true, false)
