@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NMFMU_ABI_VERSION 8 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
+#define NMFMU_ABI_VERSION 9 /* 2: nmfmu_gemm_desc grew the implicit-operand fields; trainer / convnd / tables entries;
                                3: nmfmu_gemm_desc.tile_rows, NMFMU_EPI_FOLD, NMFMU_PREC_F16;
                                4: NMFMU_PREC_F16 for every beta and padded rank 256 (four-wave kernel); nmfmu_mu_step_parts /
                                   nmfmu_parts_supported / nmfmu_gemm_tile256_supported removed (measured neutral / not faster);
@@ -46,7 +46,9 @@ extern "C" {
                                8: nmfmu_abi_check (load-time guard for bindings that are not the bundled Python host),
                                   nmfmu_ubench_mfma_hbm (in-run ceiling of the MU step for bench.py); the NMFD GEMMs stage an implicit
                                   operand as a sliding window of table entries where its tiles hold no padding (nmfmu_gemm_desc.stage_mode,
-                                  nmfmu_gemm_window_staged); nmfmu_conv_apply_pack_w_wk / nmfmu_conv_apply_h_rows_sums / nmfmu_conv_h_rows_parts */
+                                  nmfmu_gemm_window_staged); nmfmu_conv_apply_pack_w_wk / nmfmu_conv_apply_h_rows_sums / nmfmu_conv_h_rows_parts;
+                               9: nmfmu_kernel_family / nmfmu_choose_nsplit_for (round 6: beta == 1 at padded rank 256 with fp16 operands runs the
+                                  software-pipelined one-wave-per-SIMD kernel, ONE workgroup per CU -- the split must know the kernel) */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -127,6 +129,13 @@ int nmfmu_beta_kind(float beta);          /* NMFMU_BETA_*                       
 int nmfmu_supported(int r_pad, int precision);
 int nmfmu_block_rows(int r_pad, int precision, float beta); /* 128 or 256: owner rows per workgroup tile          */
 int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, int num_cu);
+/* which fused kernel a half-step of this (padded rank, precision, beta) runs on, and the split that fills the chip with ITS
+ * workgroups per CU (the ping-pong and the software-pipelined kernel: one; the four-wave kernel: two where its registers allow) */
+#define NMFMU_KERNEL_FUSED 0 /* nmfmu::fused_kernel, four waves, 128-row tiles (nmfmu_fused.h)                         */
+#define NMFMU_KERNEL_PP 1    /* nmfmu::pp_kernel, eight waves in two half-phases, 256-row tiles (nmfmu_pp.h)            */
+#define NMFMU_KERNEL_SP 2    /* nmfmu::sp_kernel, four waves, software-pipelined across tiles, 128-row tiles (nmfmu_sp.h) */
+int nmfmu_kernel_family(int r_pad, int precision, float beta);
+int nmfmu_choose_nsplit_for(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int block_rows, int num_cu);
 /* tile height for ONE half-step of this shape (128 where the owner axis alone fills the chip, else nmfmu_block_rows) */
 int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu);
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision);

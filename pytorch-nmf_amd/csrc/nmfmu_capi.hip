@@ -11,7 +11,11 @@
 #include "nmfmu_aux.h"
 #include "nmfmu_fused.h"
 #include "nmfmu_pp.h"
+#include "nmfmu_sp.h"
 
+#ifndef NMFMU_SP
+#define NMFMU_SP 1   // (A/B switch of round 6; 0 = padded rank 256, beta == 1, fp16 stays on the four-wave kernel)
+#endif
 #ifndef NMFMU_FUSE_APPLY_TWO_ACC
 #define NMFMU_FUSE_APPLY_TWO_ACC 1   // (A/B switch of round 3; 0 = beta != 1 always goes through slabs + the apply kernel)
 #endif
@@ -38,6 +42,11 @@ static void* g_pp_debug = nullptr;
 static bool pp_eligible(int r_pad, int precision, float beta) {
   return nmfmu_beta_kind(beta) == NMFMU_BETA_KL && r_pad <= 128 &&
          (precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_BF16);
+}
+// which half-steps the software-pipelined one-wave-per-SIMD kernel serves (nmfmu_sp.h): beta == 1, fp16 operands and target,
+// padded rank 256 -- the kernel of configs[4]'s shard
+static bool sp_eligible(int r_pad, int precision, float beta) {
+  return NMFMU_SP && nmfmu_beta_kind(beta) == NMFMU_BETA_KL && r_pad == 256 && precision == NMFMU_PREC_F16;
 }
 // beta -> kernel branch (nmfmu_fused.h: BetaKind): the public kinds plus the two rsqrt special cases of the generic one
 static int kernel_beta_kind(float beta) {
@@ -129,6 +138,10 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
 #endif
     return launch_pp(st->r_pad, st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16, mode, a, grid, s);
   }
+  if (mode == kModeMU && sp_eligible(st->r_pad, st->precision, st->beta)) {
+    a.tiles_per_split = (a.tiles_per_split + 3) & ~3;   // its tile loop runs in groups of four (ring slot = tile & 3)
+    return launch_sp(st->r_pad, kOpF16, a, grid, s);
+  }
   const int kk = kernel_beta_kind(st->beta);
 #ifdef NMFMU_DEBUG_HOOKS
   a.debug = mode == kModeXB ? g_pp_debug : nullptr;   // per-workgroup phase stamps of the streaming kernel (tools/xb_timeline.py)
@@ -192,6 +205,25 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
   if (ns > 8) ns = (ns + 7) / 8 * 8;           // same-chunk workgroups then share an XCD (block b runs on XCD b % 8)
   ns = std::min(ns, std::max(1, ktiles / 4));  // at least 4 tiles per workgroup to amortise prologue/epilogue
   return std::max(ns, 1);
+}
+
+int nmfmu_kernel_family(int r_pad, int precision, float beta) {
+  if (pp_eligible(r_pad, precision, beta)) return NMFMU_KERNEL_PP;
+  if (sp_eligible(r_pad, precision, beta)) return NMFMU_KERNEL_SP;
+  return NMFMU_KERNEL_FUSED;
+}
+
+int nmfmu_choose_nsplit_for(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int block_rows, int num_cu) {
+  if (owner_rows_pad <= 0 || panel_rows_pad <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
+  if (block_rows == 128 && sp_eligible(r_pad, precision, beta)) {
+    // one 512-register workgroup per CU: as many splits as fill the chip ONCE (whole rounds when the row blocks alone
+    // exceed it), each a multiple of four tiles
+    const int mblocks = owner_rows_pad / 128, ktiles = panel_rows_pad / kBK;
+    int ns = (std::max(num_cu, 1) + mblocks - 1) / mblocks;
+    ns = std::min(ns, std::max(1, ktiles / 8));
+    return std::max(ns, 1);
+  }
+  return nmfmu_choose_nsplit(owner_rows_pad, panel_rows_pad, block_rows, num_cu);
 }
 
 int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int num_cu) {

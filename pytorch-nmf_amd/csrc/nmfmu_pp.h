@@ -54,6 +54,15 @@
 #ifndef NMFMU_PP_EPI_PLAIN
 #define NMFMU_PP_EPI_PLAIN 1  // fused apply: branch-free form for the unregularised full-tile case
 #endif
+// Joule budget by result-preserving DUPLICATION (round 6; tools/gpu_r6a.sh, profiles/r06_joule_budget.md):
+// -DNMFMU_PP_DUP=<bits> executes one component of the tile loop TWICE with identical results (every earlier energy
+// experiment was a deletion, which corrupts the factors -- and the clock follows the data).  1: every panel ds_read_b128;
+// 2: every v_rcp_f32 / v_fma_mix_f32 of the ratio stage (second copy into a dead register); 4: every X global_load (second
+// copy of the SAME address into dead registers); 8: every LDS-DMA panel piece (same source, same LDS bytes); 16: every
+// barrier; 32: X duplicate from the MIRRORED row block instead (a second, real HBM stream of the same size).
+#ifndef NMFMU_PP_DUP
+#define NMFMU_PP_DUP 0
+#endif
 
 namespace nmfmu {
 
@@ -203,6 +212,9 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     auto clampt = [&](int t) { return t < nt ? t : nt - 1; };   // tail prefetches re-read the last tile (never used)
     auto dma1k = [&](const char* src, unsigned voff, unsigned lds_addr) {
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+#if NMFMU_PP_DUP & 8
+                   "\n\tglobal_load_lds_dwordx4 %0, %1"
+#endif
                    :
                    : "v"(voff), "s"(src), "s"(lds_addr)
                    : "memory", "m0");
@@ -237,8 +249,35 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #else
 #define NMFMU_PP_XPOL " nt"
 #endif
+    u32x4 xA[4], xB[4];   // X(even tiles) / X(odd tiles)
+#if NMFMU_PP_DUP & (4 | 32)
+    // dead landing registers of the duplicated X loads, one set per X buffer: a duplicate stays in flight exactly as long
+    // as its original, so it is tied at the SAME counted wait (one set tied a tile early let hipcc reuse registers that
+    // loads were still landing in: memory access faults)
+    u32x4 xdupA[4], xdupB[4];
+#if NMFMU_PP_DUP & 32
+    const long long xmirror = (long long)((int)(gridDim.x / a.nsplit) - 1 - 2 * mb) * (long long)a.ktiles * (long long)C::XTILE;
+#else
+    const long long xmirror = 0;
+#endif
+#endif
+#if NMFMU_PP_DUP & (4 | 32)
+#define NMFMU_PP_XDUP(x) ((&(x)[0] == &xA[0]) ? xdupA : xdupB)
+#endif
     auto load_x = [&](int t, u32x4(&x)[4]) {
       const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
+#if NMFMU_PP_DUP & (4 | 32)
+      u32x4(&xdup)[4] = NMFMU_PP_XDUP(x);
+      asm volatile(
+          "s_nop 4\n\t"
+          "global_load_dwordx4 %0, %4, %5" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %1, %4, %5 offset:1024" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %2, %4, %5 offset:2048" NMFMU_PP_XPOL "\n\t"
+          "global_load_dwordx4 %3, %4, %5 offset:3072" NMFMU_PP_XPOL
+          : "=&v"(xdup[0]), "=&v"(xdup[1]), "=&v"(xdup[2]), "=&v"(xdup[3])
+          : "v"(lane16), "s"(src + xmirror)
+          : "memory");
+#endif
       asm volatile(
           "s_nop 4\n\t"
           "global_load_dwordx4 %0, %4, %5" NMFMU_PP_XPOL "\n\t"
@@ -250,11 +289,19 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           : "memory");
     };
     auto wait_x = [&](u32x4(&x)[4]) {
+#if NMFMU_PP_DUP & (4 | 32)
+      u32x4(&xdup)[4] = NMFMU_PP_XDUP(x);
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(xdup[0]), "+v"(xdup[1]), "+v"(xdup[2]), "+v"(xdup[3])::"memory");
+#else
       asm volatile("s_waitcnt vmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+#endif
     };
     auto barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+#if NMFMU_PP_DUP & 16
+      __builtin_amdgcn_s_barrier();
+#endif
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -295,7 +342,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     // lives in ring[e % PF]; LDS returns in order, so "entry e has landed" = at most min(PF-1, NS-1-e) younger reads
     // outstanding.
     auto rd = [&](u32x4& dst, int addr, auto offc) {
+#if NMFMU_PP_DUP & 1
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\tds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+#else
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+#endif
     };
     auto opnd = [&](u32x4& dst, auto ec, auto g1c) {   // issue the LDS read of stream entry e
       constexpr int e0 = decltype(ec)::value;
@@ -358,7 +409,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       static_for<NS>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         constexpr int younger = (NS - 1 - e) < (PF - 1) ? (NS - 1 - e) : (PF - 1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((NMFMU_PP_DUP & 1) ? 2 * younger : younger));
         u32x4& op = ring[e % PF];
         if constexpr (e < N1) {
           constexpr int tt = e & 1, kk = e >> 1;
@@ -429,6 +480,30 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
             const uint32_t w0 = x[2 * tt + (d >> 2)][d & 3], w1 = x[2 * tt + (d >> 2)][(d & 3) + 1];
             float r0, r1, r2, r3;
             uint32_t g0, g1;
+#if NMFMU_PP_DUP & 2
+            float dd0, dd1;   // dead results of the duplicated reciprocals / mixed multiplies
+            asm("v_rcp_f32 %2, %8\n\t"
+                "v_rcp_f32 %6, %8\n\t"
+                "v_rcp_f32 %3, %9\n\t"
+                "v_rcp_f32 %7, %9\n\t"
+                "v_rcp_f32 %4, %10\n\t"
+                "v_rcp_f32 %6, %10\n\t"
+                "v_rcp_f32 %5, %11\n\t"
+                "v_rcp_f32 %7, %11\n\t"
+                "v_fma_mix_f32 %6, %12, %2, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %2, %12, %2, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %7, %12, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %3, %12, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %6, %13, %4, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %4, %13, %4, 0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %7, %13, %5, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %5, %13, %5, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                "v_cvt_pk_f16_f32 %1, %4, %5"
+                : "=&v"(g0), "=&v"(g1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(dd0), "=&v"(dd1)
+                : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(w0),
+                  "v"(w1));
+#else
             asm("v_rcp_f32 %2, %6\n\t"
                 "v_rcp_f32 %3, %7\n\t"
                 "v_rcp_f32 %4, %8\n\t"
@@ -442,6 +517,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
                 : "=&v"(g0), "=&v"(g1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                 : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(w0),
                   "v"(w1));
+#endif
             gn[tt][d] = g0;
             gn[tt][d + 1] = g1;
           }
@@ -470,12 +546,14 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         for (int i = 0; i < C::LEAD - 1; ++i) dma_img(p2src + (size_t)clampt(i) * IMG, C::P2_BASE + i * IMG);
       }
     }
-    u32x4 xA[4], xB[4];   // X(even tiles) / X(odd tiles)
     load_x(0, xA);
     load_x(1, xB);
     load_owner();
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
+#if NMFMU_PP_DUP & (4 | 32)
+    asm volatile("" : "+v"(xdupA[0]), "+v"(xdupA[1]), "+v"(xdupA[2]), "+v"(xdupA[3]), "+v"(xdupB[0]), "+v"(xdupB[1]), "+v"(xdupB[2]), "+v"(xdupB[3]));
+#endif
     scale_owner();
     barrier();
     prefetch(std::true_type{});
@@ -491,8 +569,12 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       elementwise_segment(t, std::true_type{}, xc, tailc);
       barrier();
       matrix_segment(std::true_type{}, std::true_type{});
-      if constexpr (tail)   // nothing younger than X(t+1) except tail panel pieces: drain
+      if constexpr (tail) {  // nothing younger than X(t+1) except tail panel pieces: drain
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+#if NMFMU_PP_DUP & (4 | 32)
+        asm volatile("" : "+v"(xdupA[0]), "+v"(xdupA[1]), "+v"(xdupA[2]), "+v"(xdupA[3]), "+v"(xdupB[0]), "+v"(xdupB[1]), "+v"(xdupB[2]), "+v"(xdupB[3]));
+#endif
+      }
       else
         wait_x(xn);
     };

@@ -21,6 +21,7 @@ ERR_ALLOC = -4
 PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16X = 0, 1, 2, 3
 STAGE_REG, STAGE_DMA, STAGE_DMA_SPLIT = 0, 1, 2
 BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
+KERNEL_FUSED, KERNEL_PP, KERNEL_SP = 0, 1, 2
 
 PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16, 'f16x': PREC_F16X}
 
@@ -57,7 +58,7 @@ class GemmDesc(C.Structure):
                 ('win_pitch', C.c_int32), ('win_fold', C.c_int32), ('t_koff', C.c_void_p), ('stage_mode', C.c_int32)]
 
 
-ABI_VERSION = 8   # include/nmfmu.h: NMFMU_ABI_VERSION
+ABI_VERSION = 9   # include/nmfmu.h: NMFMU_ABI_VERSION
 EPI_RATIO, EPI_F32, EPI_LOSS, EPI_FOLD = 0, 1, 2, 3
 OPS_PLANES, OPS_B_HU, OPS_B_HUT, OPS_A_HU, OPS_A_WIN = 0, 1, 2, 3, 4
 
@@ -72,6 +73,8 @@ SIGNATURES = {
     'nmfmu_block_rows': (C.c_int, [C.c_int, C.c_int, C.c_float]),
     'nmfmu_step_block_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     'nmfmu_choose_nsplit': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nmfmu_kernel_family': (C.c_int, [C.c_int, C.c_int, C.c_float]),
+    'nmfmu_choose_nsplit_for': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
     'nmfmu_xp_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_image_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'nmfmu_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -58,9 +58,19 @@ class HipBackend:
             _capi.check(br if br < 0 else _capi.ERR_ARG, 'nmfmu_step_block_rows')
         return br
 
-    def choose_nsplit(self, m_pad: int, k_pad: int, block_rows: int, device) -> int:
+    def choose_nsplit(self, m_pad: int, k_pad: int, block_rows: int, device, r_pad=None, precision=None, beta=None) -> int:
+        """Contraction split of one half-step.  With (r_pad, precision, beta) the library sizes it for the kernel that will
+        run (the software-pipelined rank-256 kernel holds ONE workgroup per CU, the four-wave kernel two)."""
         ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        forced = os.environ.get('TORCHNMF_AMD_NSPLIT')        # experiment hook (tools/gpu_r6*.sh)
+        if forced:
+            return max(1, min(int(forced), k_pad // 64 // 4))
+        if r_pad is not None:
+            return self.lib.nmfmu_choose_nsplit_for(m_pad, k_pad, r_pad, precision, beta, block_rows, ncu)
         return self.lib.nmfmu_choose_nsplit(m_pad, k_pad, block_rows, ncu)
+
+    def kernel_family(self, r_pad: int, precision: int, beta: float) -> int:
+        return self.lib.nmfmu_kernel_family(r_pad, precision, beta)
 
     @staticmethod
     def stream() -> int:
@@ -290,7 +300,12 @@ class StepRows:
     @staticmethod
     def nsplit_for(st: StepBuf, n: int, backend, k_pad: int, dev) -> int:
         """Its own contraction split: half the row blocks want twice the workgroups per block to fill the chip."""
-        return max(st.nsplit, backend.choose_nsplit(n, k_pad, st.block_rows, dev))
+        s0 = st.struct
+        try:
+            ns = backend.choose_nsplit(n, k_pad, st.block_rows, dev, s0.r_pad, s0.precision, s0.beta)
+        except TypeError:           # (the oracle-backed stand-in of the CPU tests: the plain rule)
+            ns = backend.choose_nsplit(n, k_pad, st.block_rows, dev)
+        return max(st.nsplit, ns)
 
 
 # Factory of the compute backend.  It is HipBackend in the product; the CPU test-suite swaps in an oracle-backed
@@ -484,7 +499,7 @@ class DenseMU(AsyncLossMixin):
         self.block_rows = br
         # H half-step and loss: owner axis N, contraction over C
         xp_h = self.be.pack_x(V, False, self.precision, br, n_pad, c_pad, self.flags)
-        ns_h = self.be.choose_nsplit(n_pad, c_pad, br, dev)
+        ns_h = self._nsplit(n_pad, c_pad, br, dev)
         need_den = False if self.kl else ('one' if self.gram_path else True)   # no slab | one slab | nsplit slabs
         self.step_h = StepBuf(xp_h, self.fH, self.fW, R, self.r_pad, ns_h, self.precision, stage, br, self.beta, gamma,
                               l1, l2, need_den=need_den, status=self.status)
@@ -492,7 +507,7 @@ class DenseMU(AsyncLossMixin):
         if update_W:
             brw = tile_rows(c_pad, n_pad)
             xp_w = self.be.pack_x(V, True, self.precision, brw, c_pad, n_pad, None)
-            ns_w = self.be.choose_nsplit(c_pad, n_pad, brw, dev)
+            ns_w = self._nsplit(c_pad, n_pad, brw, dev)
             self.step_w = StepBuf(xp_w, self.fW, self.fH, R, self.r_pad, ns_w, self.precision, stage, brw, self.beta,
                                   gamma, l1, l2, need_den=need_den, status=self.status)
         self.gm = self.be.gram_alloc(self.r_pad, dev) if self.gram_path else None
@@ -564,6 +579,14 @@ class DenseMU(AsyncLossMixin):
         if self.step_w is not None:
             sw = self.step_w
             self.be.pack_x(V, True, self.precision, sw.block_rows, sw.owner.rows_pad, sw.panel.rows_pad, None, out=sw.xp)
+
+    def _nsplit(self, m_pad, k_pad, block_rows, dev):
+        """Contraction split of a half-step, sized for the kernel it runs on where the backend can tell (the oracle-backed
+        stand-in of the CPU tests has the plain rule only)."""
+        try:
+            return self.be.choose_nsplit(m_pad, k_pad, block_rows, dev, self.r_pad, self.precision, self.beta)
+        except TypeError:
+            return self.be.choose_nsplit(m_pad, k_pad, block_rows, dev)
 
     def refresh_images(self):
         """Re-derive bf16 images / column sums from the fp32 masters (after external edits of W / H)."""

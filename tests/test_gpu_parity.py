@@ -2141,6 +2141,47 @@ def test_cfg5_shard_slice_rank256(dev, prec, tol):
     assert ew < tol and eh < tol, (ew, eh)
 
 
+@pytest.mark.parametrize('N,C,nsplit,regs', [(300, 200, None, (0.0, 0.0)),      # 4 tiles: the last group alone; ragged rows
+                                              (130, 500, None, (0.0, 0.0)),      # 8 tiles: one pass of the loop + the last group
+                                              (600, 1000, 1, (0.0, 0.0)),        # 16 tiles unsplit: H half-step with the fused apply
+                                              (600, 1000, 2, (0.1, 0.5)),        # 8 + 8 tiles, regularised (general epilogue)
+                                              (400, 1300, 3, (0.0, 0.0)),        # 24 tiles in splits of 8
+                                              (260, 2100, 5, (0.0, 0.0)),        # 36 tiles in splits of 8: the last split holds 4
+                                              (1100, 300, 8, (0.3, 0.0))])       # more splits than groups: empty workgroups
+def test_rank256_software_pipelined_kernel(dev, monkeypatch, N, C, nsplit, regs):
+    """nmfmu::sp_kernel (round 6: padded rank 256, beta = 1, fp16 -- the kernel of configs[4]'s shard) over its control
+    flow: one / several four-tile groups, the last group's shorter final iteration, contraction splits that leave short and
+    empty workgroups (tiles_per_split is rounded to a multiple of four), ragged rows and ranks, both epilogues (fused apply,
+    plain and regularised; slab stores).  Two iterations against the oracle, so that the images the fused apply wrote are
+    what the next half-steps read.  The tolerance is what fp16 operands give on contractions this short (64 .. 2100 terms;
+    DESIGN.md section 4) -- the parity bar itself is held at configs[4]'s own lengths by test_cfg5_shard_slice_rank256."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import DenseMU
+    R = 200 if N != 600 else 256
+    g = torch.Generator().manual_seed(N + C)
+    V = torch.rand(N, C, generator=g).bfloat16().float()
+    W0 = torch.randn(C, R, generator=g).abs()
+    H0 = torch.randn(N, R, generator=g).abs()
+    if nsplit is not None:
+        monkeypatch.setenv('TORCHNMF_AMD_NSPLIT', str(nsplit))
+    alpha, l1r = regs
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = DenseMU(V.to(dev), W, H, 1.0, alpha * l1r, alpha * (1 - l1r), precision='f16')
+    assert eng.r_pad == 256 and eng.be.kernel_family(256, _capi.PREC_F16, 1.0) == _capi.KERNEL_SP
+    Wr, Hr = W0, H0
+    for _ in range(2):
+        eng.w_step()
+        eng.h_step()
+        Wr = O.nmf_w_step(V, Wr, Hr, 1, 1.0, alpha * l1r, alpha * (1 - l1r))
+        Hr = O.nmf_h_step(V, Wr, Hr, 1, 1.0, alpha * l1r, alpha * (1 - l1r))
+    torch.cuda.synchronize()
+    ew, eh = rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr)
+    record('rank256_sp_kernel', N=N, C=C, nsplit=(eng.step_w.nsplit, eng.step_h.nsplit), regs=regs, relW=ew, relH=eh)
+    assert ew < 4e-4 and eh < 4e-4, (ew, eh)
+    assert eng.divergence() == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, 1)), rel=1e-3)
+
+
 def test_auto_precision_policy(dev, monkeypatch):
     """'auto' = the fastest mode that meets the 1e-4 bar, never plain bf16: fp16 operands where both dimensions are
     >= 4096, the target is exactly representable in fp16 and the data sit inside fp16's range; split bf16 otherwise

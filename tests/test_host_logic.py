@@ -118,8 +118,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_static_queries():
     lib = _capi.load()
-    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 8
-    assert lib.nmfmu_abi_check(8) == 0 and lib.nmfmu_abi_check(7) == _capi.ERR_ARG     # load-time guard of foreign bindings
+    assert lib.nmfmu_abi_version() == _capi.ABI_VERSION == 9
+    assert lib.nmfmu_abi_check(9) == 0 and lib.nmfmu_abi_check(8) == _capi.ERR_ARG     # load-time guard of foreign bindings
     assert [lib.nmfmu_pad_rows(r) for r in (1, 256, 257, 4096)] == [256, 256, 512, 4096]
     assert [lib.nmfmu_pad_rank(r) for r in (1, 32, 33, 88, 128, 129, 256)] == [32, 32, 64, 128, 128, 256, 256]
     assert lib.nmfmu_pad_rank(257) == _capi.ERR_UNSUPPORTED

@@ -332,3 +332,80 @@ def test_fused_apply_epilogue_slot_map(r_pad):
         for m in masks:
             group |= {x ^ m for x in group}
         assert group == {x for x in range(64) if x % SP == lane % SP}
+
+
+# ---- the software-pipelined rank-256 kernel (csrc/nmfmu_sp.h): its address registers and its operand stream ------------
+def test_sp_kernel_address_registers_reproduce_the_fused_kernel_addresses():
+    """nmfmu::sp_kernel reaches every LDS operand as  register + 16-bit immediate: 8 GEMM1 bases ga[kk & 7] and 16 GEMM2
+    bases gb[2 m2 + h][rt & 3], with tt, kk >> 3, rt >> 2 and the ring slot's parity as immediates and the slot's 64 KiB half as
+    bit 16 of the registers.  Mirror of that algebra: for every lane and every operand the sum must be the four-wave kernel's
+    address (nmfmu_fused.h: a_row / a_sw for GEMM1, t_base ^ 64 rt for the transposing reads) inside the tile's ring slot."""
+    r_pad, rowb, img = 256, 512, 64 * 512
+    for lane in range(64):
+        j, hl = lane & 31, lane >> 5
+        row0 = 32 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3)
+        sw0 = p1_swz(row0, r_pad)
+        ga = [row0 * rowb + (((2 * v + hl) ^ sw0) << 4) for v in range(8)]
+        grp, s16 = lane >> 4, lane & 15
+        cslot, lr = 2 * (grp & 1) + ((s16 & 3) >> 1), (s16 >> 2) & 3
+        gb = [[(32 * (grp >> 1) + (s16 >> 2)) * rowb + (((cslot ^ c) | ((lr ^ p) << 2)) << 4) + 8 * (s16 & 1) for p in range(4)]
+              for c in range(4)]
+        for slot in range(4):
+            half, par = slot >> 1, slot & 1
+            for tt in range(2):
+                for kk in range(16):       # GEMM1
+                    imm = tt * 16 * rowb + (kk >> 3) * 256 + par * img
+                    assert 0 <= imm < 65536
+                    got = (ga[kk & 7] ^ (half << 16)) + imm
+                    row = 32 * ((j >> 2) & 1) + 16 * tt + (j & 3) + 4 * (j >> 3)
+                    want = slot * img + row * rowb + ((kk * 32 + hl * 16) ^ (p1_swz(row, r_pad) << 4))
+                    assert got == want, (lane, slot, tt, kk)
+                for m2 in range(2):        # GEMM2
+                    for h in range(2):
+                        for rt in range(8):
+                            imm = (16 * tt + 8 * m2 + 4 * h) * rowb + (rt >> 2) * 256 + par * img
+                            assert 0 <= imm < 65536
+                            got = (gb[2 * m2 + h][rt & 3] ^ (half << 16)) + imm
+                            row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2)
+                            base = row * rowb + ((cslot ^ p1_swz(row, r_pad)) << 4) + 8 * (s16 & 1)
+                            assert got == slot * img + (base ^ (rt * 64)), (lane, slot, tt, m2, h, rt)
+
+
+def test_sp_kernel_stream_tables():
+    """The compile-time tables of nmfmu_sp.h (sp_entry / sp_younger), restated: a four-tile group is 4 x (32 GEMM1 entries of
+    the NEXT tile + 32 GEMM2 entries of this tile), the workgroup's last group ends without a GEMM1; the counted lgkmcnt in
+    front of MFMA n must equal the LDS read instructions issued after entry n's own (ring depth 4: entries n+1 .. n+3, one
+    ds_read_b128 per GEMM1 entry, two ds_read_b64_tr_b16 per GEMM2 entry) and fit the 4-bit counter; the slot / buffer / half
+    bookkeeping of an iteration (ring slot = it, S and X buffer = it & 1, GEMM1 registers flipped in even iterations, GEMM2
+    registers in odd ones) must leave every register set in the half its next reads need."""
+    N1 = N2 = 32
+    PF = 4
+
+    def entry(n, last):
+        it, l = divmod(n, N1 + N2)
+        if last and it == 3:
+            return (3, False, l)
+        return (it, l < N1, l if l < N1 else l - N1)
+
+    for last in (False, True):
+        length = 3 * (N1 + N2) + (N2 if last else N1 + N2)
+        in_flight = []
+        for n in range(length + PF):
+            if n >= PF:                                    # MFMA n - PF: everything older than its own reads has landed
+                m = n - PF
+                own = 1 if entry(m, last)[1] else 2
+                younger = sum(1 if entry(k, last)[1] else 2 for k in range(m + 1, min(m + PF, length)))
+                assert len(in_flight) == own + younger and younger <= 15
+                del in_flight[:own]
+            if n < length:
+                in_flight += [n] * (1 if entry(n, last)[1] else 2)
+        assert not in_flight
+    # halves: G1 registers serve tile it+1 (slot (it+1) & 3), G2 registers tile it (slot it); flips after even / odd iterations
+    g1_half, g2_half = 0, 0
+    for rep in range(3):
+        for it in range(4):
+            assert g1_half == ((it + 1) & 3) >> 1 and g2_half == it >> 1, (rep, it)
+            if it % 2 == 0:
+                g1_half ^= 1
+            else:
+                g2_half ^= 1
