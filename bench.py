@@ -95,6 +95,11 @@ def parse():
     ap.add_argument('--telemetry-s', type=float, default=0.8, help='seconds of back-to-back iterations (untimed, after the '
                     'timed blocks) during which a side thread samples core clock and socket power through amdsmi; the means go '
                     'into roofline.clock_mhz / power_w (0 disables)')
+    ap.add_argument('--standin', action='store_true',
+                    help='TEST ONLY (tests/test_distributed_gloo.py): run the control flow of this script -- rank spawn, rendezvous, '
+                         'barrier-bracketed blocks, MAX over ranks, the one JSON line of rank 0 -- on CPU tensors over gloo with the '
+                         "oracle-backed stand-in backend of the CPU test-suite (tests/cpu_backend.py).  The numbers of such a run "
+                         'measure nothing and the line says so (`data`).')
     a = ap.parse_args()
     if a.precision == 'auto' and a.workload not in ('nmfd', 'nmf2d', 'betamu'):
         ap.error("--precision auto: only for --workload nmfd / nmf2d / betamu (the dense workloads report 'auto' as real_data_mode)")
@@ -108,7 +113,8 @@ def parse():
 # go stale silently).  tools/pmc_traffic_update.py rewrites a record from a fresh pmc_summary.txt.
 KERNEL_SOURCES = {'pp': ('nmfmu_pp.h', 'nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_pp.hip'),
                   'fused': ('nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_r128.hip'),
-                  'xb': ('nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_r128.hip')}
+                  'xb': ('nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_r128.hip'),
+                  'sp': ('nmfmu_sp.h', 'nmfmu_fused.h', 'nmfmu_layout.h', 'nmfmu_inst_sp.hip')}
 
 
 def kernel_source_sha(family):
@@ -136,8 +142,8 @@ def pmc_traffic_key(key):
         return None, f'{type(ex).__name__}: {ex}'
 
 
-def pmc_traffic(N, C, R, precision, pp):
-    return pmc_traffic_key(f'{N}x{C}_r{R}_{precision}_{"pp" if pp else "fused"}')
+def pmc_traffic(N, C, R, precision, family):
+    return pmc_traffic_key(f'{N}x{C}_r{R}_{precision}_{family}')
 
 
 def usable_cores():
@@ -297,16 +303,46 @@ class SmiSampler:
         return out
 
 
+STANDIN = False   # --standin: CPU tensors, gloo, the test-suite's oracle-backed backend (no measurement)
+
+
+def dev_sync():
+    if not STANDIN:
+        torch.cuda.synchronize()
+
+
+class HostTimer:
+    """--standin only: the KernelTimer interface on the host clock (there are no device events on CPU tensors)."""
+
+    def __init__(self, n_events):
+        self.t, self.tags = [], []
+
+    def mark(self, tag):
+        self.t.append(time.perf_counter())
+        self.tags.append(tag)
+
+    def spans(self):
+        out = {}
+        for i in range(len(self.tags) - 1):
+            a, b = self.tags[i], self.tags[i + 1]
+            if a.endswith('<') and b == a[:-1] + '>':
+                out.setdefault(a[:-1], []).append(1e3 * (self.t[i + 1] - self.t[i]))
+        return out
+
+    def close(self):
+        pass
+
+
 def preroll_steps(step, seconds):
     """Untimed iterations until `seconds` of GPU work have passed: under this load the chip takes a few tenths of a second
     to settle its clocks (the first blocks of a cold run were up to 18 % slower than the settled ones)."""
     n = 0
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
             step()
-        torch.cuda.synchronize()
+        dev_sync()
         n += 20
     return n
 
@@ -315,7 +351,7 @@ def timed_blocks(run, steps, min_repeats, max_repeats, barrier=None, reduce_max=
     """Blocks of exactly `steps` steps, each bracketed by barrier + synchronize (MAX over ranks); at least `min_repeats`,
     then more until two consecutive blocks agree within 2 % (or `max_repeats`).  Returns (median ms/step, all blocks)."""
     def sync():
-        torch.cuda.synchronize()
+        dev_sync()
         if barrier is not None:
             barrier()
     blocks = []
@@ -663,7 +699,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         def step():
             eng.w_step()
             eng.h_step()
-    torch.cuda.synchronize()
+    dev_sync()
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -671,7 +707,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         preroll = 60
         for _ in range(preroll):
             step()
-        torch.cuda.synchronize()
+        dev_sync()
     else:
         preroll = preroll_steps(step, a.preroll_s)
 
@@ -679,7 +715,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
 
     def reduce_max(elapsed):
         if world == 1:
@@ -698,10 +734,10 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
     # span; these spans agree with the rocprofv3 kernel-trace durations)
     if want_roofline:
         nst = max(a.steps, 40)
-        eng.timer = KernelTimer(8 * nst + 8)
+        eng.timer = (HostTimer if STANDIN else KernelTimer)(8 * nst + 8)
         for _ in range(nst):
             step()
-        torch.cuda.synchronize()
+        dev_sync()
         spans = eng.timer.spans()
         eng.timer.close()
         eng.timer = None
@@ -713,11 +749,16 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         elt = 4 if eng.precision_name in ('bf16x3', 'f16x') else 2
         bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        pp = eng.step_h.block_rows == 256
+        # which kernel ran (include/nmfmu.h: NMFMU_KERNEL_*): the ping-pong kernel, the software-pipelined rank-256 kernel
+        # (round 6) or the four-wave kernel
+        fam = 1 if eng.step_h.block_rows == 256 else 0
+        if fam == 0 and hasattr(eng.be, 'kernel_family') and not (gram and beta == 2):
+            fam = eng.be.kernel_family(eng.r_pad, eng.precision, float(beta))
+        family = {0: 'fused', 1: 'pp', 2: 'sp'}[fam]
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, eng.precision_name, pp)[0],
-                'traffic_source': pmc_traffic(N, C, R, eng.precision_name, pp)[1],
-                'kernel': 'nmfmu::pp_kernel' if pp else 'nmfmu::fused_kernel', 'launches_timed': len(all_ms),
+                'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(N, C, R, eng.precision_name, family)[0],
+                'traffic_source': pmc_traffic(N, C, R, eng.precision_name, family)[1],
+                'kernel': f'nmfmu::{family}_kernel', 'launches_timed': len(all_ms),
                 'avg_launch_ms': round(avg_ms, 5),
                 'avg_launch_ms_w_step': round(sum(spans['w']) / len(spans['w']), 5),
                 'avg_launch_ms_h_step': round(sum(spans['h']) / len(spans['h']), 5),
@@ -738,7 +779,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
                 roof['peak_at_measured_clock'] = round(pk, 1)
                 roof['frac_of_peak_at_measured_clock'] = round(ach / pk, 4)
             roof['telemetry'] = tel
-        if telemetry and world == 1 and hasattr(eng.be, 'lib') and hasattr(eng.be.lib, 'nmfmu_ubench_mfma_hbm') and not betamu:
+        if telemetry and world == 1 and hasattr(eng.be, 'lib') and hasattr(eng.be.lib, 'nmfmu_ubench_mfma_hbm2') and not betamu:
             try:
                 ceil = ceiling_leg(a, eng, dev)
             except Exception as ex:          # a diagnostic leg must never take the bench line down with it
@@ -749,8 +790,19 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
                 roof['ceiling_tflops'] = ceil['with_stream']['tflops']
                 roof['frac_of_ceiling'] = round(ach / ceil['with_stream']['tflops'], 4)
                 roof['ceiling_note'] = ('ceiling_tflops = what a loop with NO overhead (no LDS operand reads, no elementwise stage, '
-                                        'no barriers, fixed operands) sustains on this box in this run at the same MFMA count and '
-                                        'X bytes per launch; `frac` stays priced against the nominal dense peak')
+                                        'no barriers, fixed operands) sustains on this box in this run at the MU step\'s X bytes per '
+                                        'MFMA, over a loop long enough that launch ramp and drain are < 2 % (ceiling.*.mfma_busy_frac '
+                                        'is its matrix pipe\'s busy fraction from in-kernel stamps); `frac` stays priced against the '
+                                        'nominal dense peak')
+        if telemetry and world == 1 and not STANDIN and family in ('pp', 'sp') and not betamu:
+            try:
+                ik = in_kernel_leg(eng, step, dev, family)
+                if ik is not None:
+                    roof['in_kernel'] = ik
+                    if roof.get('ceiling'):
+                        roof['ceiling']['shipped_kernel'] = ik
+            except Exception as ex:
+                roof['in_kernel_error'] = f'{type(ex).__name__}: {ex}'[:200]
         if 'ar' in spans:
             roof['avg_allreduce_ms'] = round(sum(spans['ar']) / len(spans['ar']), 5)
             roof['allreduce_note'] = ('exposed part: the first row half of the H numerators is reduced behind the '
@@ -759,13 +811,51 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
     return out
 
 
+def in_kernel_leg(eng, step, dev, family):
+    """The shipped kernel's own clocks (nmfmu_step.stamps): workgroup 0 stamps shader cycles and the
+    constant 100 MHz clock at the start and the end of its tile loop -- cycles per tile, the core clock INSIDE the kernel
+    and the matrix pipe's busy fraction = 32 cycles x MFMAs per SIMD and tile / cycles per tile.  H half-step (the plain
+    tile loop + slab stores); a few iterations after the timed legs, median."""
+    import numpy as np
+    st = eng.step_h
+    nwg = (st.owner.rows_pad // st.block_rows) * st.nsplit
+    buf = torch.zeros(64 + 5 * nwg, dtype=torch.int64, device=dev)
+    mfma_per_tile_simd = (2 if family == 'pp' else 1) * (eng.r_pad // 4)
+    res = []
+    try:
+        st.struct.stamps = buf.data_ptr()
+        for _ in range(7):
+            for _ in range(25):          # back to back: the clock the sustained loop runs at (a lone launch clocks higher)
+                step()
+            torch.cuda.synchronize()
+            v = buf[:8].cpu().numpy().reshape(2, 4)          # slots 0 (loop start) and 1 (loop end): cycles, 100 MHz ticks, tiles
+            nt = int(v[0, 2])
+            cyc, ticks = int(v[1, 0] - v[0, 0]), int(v[1, 1] - v[0, 1])
+            if nt > 0 and cyc > 0 and ticks > 0:
+                res.append((cyc / nt, cyc / ticks * 100.0))
+    finally:
+        st.struct.stamps = None
+    if not res:
+        return None
+    r = np.array(res)
+    cpt, clk = float(np.median(r[:, 0])), float(np.median(r[:, 1]))
+    return {'what': 'clock stamps of workgroup 0 around its tile loop (nmfmu_step.stamps; H half-step; the last launch of %d bursts of 25 back-to-back iterations, median)' % len(res),
+            'kernel': f'nmfmu::{family}_kernel', 'tiles_per_workgroup': nt, 'cycles_per_tile': round(cpt, 1),
+            'mfma_cycles_per_tile_and_simd': 32 * mfma_per_tile_simd,
+            'mfma_busy_frac': round(32 * mfma_per_tile_simd / cpt, 4), 'clock_mhz_in_kernel': round(clk, 1),
+            'ns_per_tile': round(cpt / clk * 1e3, 1)}
+
+
 def ceiling_leg(a, eng, dev):
-    """The zero-overhead ceiling of the fused MU step on THIS box, in THIS run: nmfmu_ubench_mfma_hbm
-    = 8 waves per CU issuing exactly one half-step's MFMAs (32 per wave and tile, fixed fragments read from the live W image:
-    the real operand distribution) next to an independent non-temporal stream of exactly one half-step's X bytes (the live
-    packed X), no LDS reads, no VALU, no barriers.  Timed like the kernels (hipEvents on the launching stream, after a pre-roll
-    that lets the clocks settle), with the same clock / power telemetry.  Also the MFMA loop alone (no stream)."""
+    """The zero-overhead ceiling of the fused MU step on THIS box, in THIS run: nmfmu_ubench_mfma_hbm2
+    = 8 waves per CU issuing 32 MFMAs per wave and tile on fixed fragments read from the live W image (the real operand
+    distribution) next to an independent non-temporal stream of the live packed X at the MU step's bytes per MFMA; no LDS
+    reads, no VALU, no barriers.  Round 6: the loops run LONG (1 024 tiles without the stream, 512 with it,
+    wrapping over X) so that ramp, operand fetch and drain are < 2 % of a launch, and every workgroup stamps its loop: the
+    matrix pipe's busy fraction (32 cycles x MFMAs per SIMD / loop cycles) and the in-kernel clock are reported per arm.
+    Timed like the kernels (hipEvents on the launching stream, after a pre-roll), with the same clock / power telemetry."""
     import ctypes as C
+    import numpy as np
     from torchnmf_amd import _capi
     lib = eng.be.lib
     st = eng.step_h
@@ -776,35 +866,46 @@ def ceiling_leg(a, eng, dev):
     if kib is None or img.numel() < 65536:
         return None
     waves = 8
-    tiles = int(xp.numel() // (ncu * waves * kib * 1024))
-    if tiles < 8:
+    wrap = int(xp.numel() // (ncu * waves * kib * 1024))     # tiles per wave that one pass over the packed X holds
+    if wrap < 8:
         return None
     sink = torch.empty(ncu * waves * 64, dtype=torch.float32, device=dev)
-    flops = float(ncu) * waves * tiles * 32 * 32768.0
+    stamps = torch.zeros(4 * ncu * waves, dtype=torch.int64, device=dev)
 
-    def run(k):
-        _capi.check(lib.nmfmu_ubench_mfma_hbm(img.data_ptr(), img.numel(), f16, xp.data_ptr(), k, waves, tiles, ncu,
-                                              sink.data_ptr(), torch.cuda.current_stream().cuda_stream), 'nmfmu_ubench_mfma_hbm')
+    def run(k, tiles):
+        _capi.check(lib.nmfmu_ubench_mfma_hbm2(img.data_ptr(), img.numel(), f16, xp.data_ptr(), k, waves, tiles, wrap, ncu,
+                                               sink.data_ptr(), stamps.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                    'nmfmu_ubench_mfma_hbm2')
     out = {'what': 'MFMA loop on the live W image fragments (32 per wave and tile, 8 waves per CU) beside an independent nt LDS-DMA '
                    f'stream of the live packed X at {kib} KiB per wave and tile = the MU step\'s flop : byte ratio; no LDS reads, '
-                   'no VALU, no barriers (nmfmu_ubench_mfma_hbm)',
-           'grid': ncu, 'waves_per_workgroup': waves, 'tiles': tiles, 'flops_per_launch': flops,
-           'stream_bytes_per_launch': ncu * waves * tiles * kib * 1024}
-    for name, k in (('with_stream', kib), ('mfma_only', 0)):
-        preroll_steps(lambda: run(k), min(a.preroll_s, 0.3))
+                   'no VALU, no barriers (nmfmu_ubench_mfma_hbm2); long loops, in-kernel stamps',
+           'grid': ncu, 'waves_per_workgroup': waves, 'one_pass_over_x_tiles': wrap}
+    for name, k, tiles in (('with_stream', kib, max(wrap, 512)), ('mfma_only', 0, 1024)):
+        flops = float(ncu) * waves * tiles * 32 * 32768.0
+        preroll_steps(lambda: run(k, tiles), min(a.preroll_s, 0.3))
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reps = 200
+        reps = 60
         ev[0].record()
         for _ in range(reps):
-            run(k)
+            run(k, tiles)
         ev[1].record()
         torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1]) / reps
-        ent = {'avg_launch_ms': round(ms, 5), 'tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
+        sv = stamps.cpu().numpy().reshape(ncu, waves, 4).astype(np.float64)
+        clk = float(np.median(sv[:, :, 0] / np.maximum(sv[:, :, 1], 1.0))) * 100.0          # MHz inside the loops
+        span = sv[:, :, 3].max(axis=1) - sv[:, :, 2].min(axis=1)                             # per workgroup, 100 MHz ticks
+        span_cyc = float(np.median(span)) * clk / 100.0
+        mfma_cyc = 32.0 * (waves // 4) * tiles * 32                                          # per SIMD
+        ent = {'tiles': tiles, 'avg_launch_ms': round(ms, 5), 'tflops': round(flops / (ms * 1e-3) / 1e12, 1),
+               'flops_per_launch': flops,
+               'mfma_busy_frac': round(mfma_cyc / span_cyc, 4) if span_cyc > 0 else None,
+               'mfma_busy_frac_of_launch': round(mfma_cyc / (ms * 1e-3 * clk * 1e6), 4) if clk > 0 else None,
+               'clock_mhz_in_kernel': round(clk, 1),
+               'loop_us_median_workgroup': round(float(np.median(span)) * 0.01, 1)}
         if k:
-            ent['stream_gbs'] = round(out['stream_bytes_per_launch'] / (ms * 1e-3) / 1e9, 1)
+            ent['stream_gbs'] = round(ncu * waves * tiles * k * 1024 / (ms * 1e-3) / 1e9, 1)
         if a.telemetry_s > 0:
-            tel = SmiSampler(dev.index or 0).under_load(lambda: run(k), min(a.telemetry_s, 0.5))
+            tel = SmiSampler(dev.index or 0).under_load(lambda: run(k, tiles), min(a.telemetry_s, 0.5))
             ent['clock_mhz'], ent['power_w'] = tel.get('clock_mhz'), tel.get('power_w')
         out[name] = ent
     return out
@@ -961,7 +1062,19 @@ def _spawned(local_rank, nprocs, port, argv):
 
 
 def main():
+    global STANDIN
     a = parse()
+    STANDIN = bool(a.standin)
+    if STANDIN:
+        # TEST ONLY: the host logic of this script over gloo on CPU tensors; compute by the test-suite's stand-in backend
+        tdir = os.path.join(ROOT, 'tests')
+        if tdir not in sys.path:
+            sys.path.insert(0, tdir)
+        from cpu_backend import OracleBackend
+        from torchnmf_amd import engine as _engine
+        _engine.DEFAULT_BACKEND_FACTORY = OracleBackend
+        torch.set_num_threads(1)
+        assert a.workload == 'nmf', '--standin covers the dense NMF path'
     if a.precision is None:
         # (betamu: the optimizer's own default -- 'auto' resolves like NMF.fit's since round 5)
         a.precision = 'f16' if a.workload in ('nmf', 'nmfd') else ('auto' if a.workload == 'betamu' else 'bf16')
@@ -981,7 +1094,7 @@ def main():
         # plain `python bench.py --gpus N` (no launcher): spawn the N ranks ourselves, one per GPU, rendezvous on localhost
         import socket
         import torch.multiprocessing as mp
-        assert torch.cuda.device_count() >= a.gpus, f'--gpus {a.gpus} but {torch.cuda.device_count()} devices are visible'
+        assert STANDIN or torch.cuda.device_count() >= a.gpus, f'--gpus {a.gpus} but {torch.cuda.device_count()} devices are visible'
         with socket.socket() as s_:
             s_.bind(('127.0.0.1', 0))
             port = s_.getsockname()[1]
@@ -990,11 +1103,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    assert STANDIN or torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if world != a.gpus:
         raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if STANDIN:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     group = None
     nranks = 1
     if world > 1 or a.force_dist:
@@ -1003,7 +1119,10 @@ def main():
         if a.force_dist and 'RANK' not in os.environ:          # plain `python bench.py --force-dist`: a world of one
             os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
             os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=dev)   # RCCL
+        if STANDIN:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)   # RCCL
         group = dist.group.WORLD
         nranks = dist.get_world_size()                   # as RCCL's communicator reports it
 
@@ -1012,6 +1131,8 @@ def main():
     # --rows / --cols / --rank override the preset.
     preset = a.config or ('cfg5' if world > 1 else 'cfg1')
     pr = {'cfg1': (4096, 65536, 128), 'cfg5': (8192, 262144, 256), 'cfg5full': (8192, 2097152, 256)}[preset]
+    if STANDIN:
+        pr = (64, 96, 8)        # (the CPU oracle computes these iterations: sizes of a unit test)
     N = a.rows if a.rows is not None else pr[0]
     C = a.cols if a.cols is not None else pr[1]
     R = a.rank if a.rank is not None else pr[2]
@@ -1036,6 +1157,21 @@ def main():
 
     head = dense_leg(a, V, W0, H0, beta, a.precision, group, world, dev, not a.no_roofline, betamu, telemetry=True,
                      gram=a.gram and beta == 2 and world == 1)
+    # ---- N > 1: the 1-GPU denominator of THIS workload, measured in THIS run (the default N = 1 line is
+    # configs[1] at rank 128, the N > 1 lines run configs[4]'s shard at rank 256 -- a curve through the default lines would
+    # divide two different workloads).  Rank 0 times its own shard unsharded (no collective, the fused apply instead of
+    # slab reduction + all-reduce + apply) while the other ranks wait at a barrier.
+    same1 = None
+    if world > 1 and (group is not None):
+        import torch.distributed as dist
+        if rank == 0:
+            one = dense_leg(a, V, W0, H0, beta, a.precision, None, 1, dev, False, blocks_min=3)
+            same1 = {'what': f"rank 0's own shard ({N}x{C} rank {R}) as an unsharded 1-GPU problem, same precision, timed in this run "
+                             'between the sharded legs (the other ranks idle at a barrier)',
+                     'ms_per_step': round(one['ms_per_step'], 4), 'iters_per_s': round(1e3 / one['ms_per_step'], 2),
+                     'value': round(one['gflops'], 1), 'unit': 'GFLOP/s', 'blocks_ms_per_step': one['blocks_ms_per_step']}
+            del one
+        dist.barrier()
     asked = a.precision
     if a.precision == 'auto':            # betamu: report what the optimizer's 'auto' resolved to
         a.precision = head['eng'].precision_name
@@ -1182,7 +1318,8 @@ def main():
             'ms_per_step': round(ms_per_step, 4),
             'repeats': len(head['blocks_ms_per_step']), 'blocks_ms_per_step': head['blocks_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': DTYPE_NAME[a.precision], 'dtype_note': DTYPE_LONG[a.precision], 'data': 'synthetic',
+            'dtype': DTYPE_NAME[a.precision], 'dtype_note': DTYPE_LONG[a.precision],
+            'data': 'synthetic' if not STANDIN else 'synthetic -- TEST STAND-IN (--standin: CPU tensors, gloo, oracle-backed backend): NOT a measurement',
             'config': {'workload': (f'NMF {N}x{C * world} rank={R} beta={beta:g}, V column-sharded {world} x {C}, '
                                     f'H replicated, all-reduce of the H numerators per iteration' + (' (BASELINE configs[4])' if (N, C * world, R, beta) == (8192, 2097152, 256, 1.0) else ''))
                        if world > 1 else
@@ -1197,6 +1334,13 @@ def main():
             'beta_sweep': beta_sweep, 'nmfd': nmfd, 'nmf2d': nmf2d, 'fit': fit_obj, 'real_data_mode': real,
             'ref_notebook': ref_nb,
         }
+        if same1 is not None:
+            out['same_shard_1gpu'] = same1
+            out['efficiency'] = round(same1['ms_per_step'] / ms_per_step, 4)
+            out['scaling_note'] = ('weak scaling: every rank owns one shard of this size; efficiency = same_shard_1gpu.ms_per_step / '
+                                   'ms_per_step (1.0 = the all-reduce and the unfused apply cost nothing).  NOTE the default N = 1 line '
+                                   f'of this script is another workload (configs[1], 4096x65536 rank 128); the 1-GPU point of THIS '
+                                   f'curve is same_shard_1gpu (or `--gpus 1 --config {preset}`)')
         if betamu:
             out['config']['precision_asked'] = asked
             out['config']['closure'] = 'returns m() (reconstruction materialised)' if a.materialise else \

@@ -48,7 +48,8 @@ extern "C" {
                                   operand as a sliding window of table entries where its tiles hold no padding (nmfmu_gemm_desc.stage_mode,
                                   nmfmu_gemm_window_staged); nmfmu_conv_apply_pack_w_wk / nmfmu_conv_apply_h_rows_sums / nmfmu_conv_h_rows_parts;
                                9: nmfmu_kernel_family / nmfmu_choose_nsplit_for (round 6: beta == 1 at padded rank 256 with fp16 operands runs the
-                                  software-pipelined one-wave-per-SIMD kernel, ONE workgroup per CU -- the split must know the kernel) */
+                                  software-pipelined one-wave-per-SIMD kernel, ONE workgroup per CU -- the split must know the kernel);
+                                  nmfmu_step.stamps (in-kernel clock stamps in the product build); nmfmu_ubench_mfma_hbm2 */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -112,6 +113,13 @@ typedef struct nmfmu_step {
   float l1, l2;        /* nmf.py:348-349 */
   uint32_t* status;    /* NULL or one device word (ABI 4): bit 0 is OR-ed in when an update had to clamp a factor value
                           at 65504 for its fp16 image (NMFMU_PREC_F16) -- the fit has left the mode's range           */
+  void* stamps;        /* NULL, or (ABI 9) a device buffer of >= 64 + 5 * workgroups uint64: the ping-pong and the
+                          software-pipelined kernel record their clocks there -- workgroup 0, wave 0 (and wave 4 of the
+                          ping-pong pair): shader cycles (s_memtime), the constant 100 MHz clock (s_memrealtime) and the tile
+                          count at kernel entry / loop start / loop end / exit; every workgroup the 100 MHz clock at the same four
+                          points and where it ran.  Nothing is stamped inside the tile loop.  bench.py derives cycles per tile,
+                          the in-kernel clock and the matrix pipe's busy fraction from it (roofline.in_kernel); layout in
+                          tools/pp_timeline.py                                                                          */
 } nmfmu_step;
 
 /* ---- static queries (host only, no device work) ------------------------------------------------------------ */
@@ -646,6 +654,13 @@ int nmfmu_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords /* mult
  * grid * waves * tiles * 32 * 32768.  Asynchronous on `stream`; time it with events.  Not used by the product path. */
 int nmfmu_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
                           int waves, int tiles, int grid, float* out, void* stream);
+/* The same loop with its own clocks (ABI 9): `tiles` may exceed what stream_src holds -- the stream wraps after wrap_tiles
+ * tiles per wave (0 = never) -- and every wave writes {shader cycles, 100 MHz ticks, start tick, end tick} of its tile loop
+ * to stamps[4 * (workgroup * waves + wave) ..] (NULL = no stamps; grid * waves * 4 uint64).  The two waves of a SIMD do not
+ * share the matrix pipe evenly, so the busy fraction is taken over a workgroup's span: 32 cycles x MFMAs per SIMD /
+ * ((max end - min start) x clock), clock = cycles / ticks of any wave. */
+int nmfmu_ubench_mfma_hbm2(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
+                           int waves, int tiles, int wrap_tiles, int grid, float* out, uint64_t* stamps, void* stream);
 /* Diagnostic hook of the ping-pong kernel (nmfmu_pp.h), live only in libraries built with -DNMFMU_DEBUG_HOOKS
  * (NMFMU_ERR_UNSUPPORTED otherwise): with a device buffer of >= (64 + 5 * workgroups) uint64 registered, every
  * workgroup records clock stamps at kernel entry, loop start, loop end and exit (tools/pp_timeline.py).  buf = NULL

@@ -319,6 +319,23 @@ def convnd_h_step(V, W, H, beta, gamma, l1=0.0, l2=0.0):
     return _apply(H, neg, _convnd_grad_h(gp, W, H), False, gamma, l1, l2)
 
 
+def betamu_conv_step(V, W, H, beta, l1=0.0, l2=0.0, ortho=0.0, params=('W', 'H')):
+    """One ``trainer.BetaMu.step`` (trainer.py:35-121) over the parameters of ONE convolutive layer -- NMFD / NMF2D / NMF3D,
+    prediction = ``convNd(H, W.flip, padding = T - 1)`` (nmf.py:776-779, 857-860, 937-940).  The two backward passes of
+    trainer.py:93-97 through the convolution are the tap-wise contractions of ``_convnd_grad_w`` / ``_convnd_grad_h``; beta == 1
+    back-propagates ones (no closed-form shortcut in the trainer), the penalties and the orthogonality term (sum over
+    dim 1 = the rank axis of W (C, R, *T) and of H (B, R, *L)) enter before eps.  Returns (W, H, {name: p.grad})."""
+    gamma = gamma_of(beta)
+    grads = {}
+    for name in params:
+        gn, gp = betamu_terms(V, convnd_reconstruct(H, W), beta)
+        if name == 'W':
+            W, grads['W'] = betamu_update(W, _convnd_grad_w(gn, H, W), _convnd_grad_w(gp, H, W), gamma, l1, l2, ortho)
+        else:
+            H, grads['H'] = betamu_update(H, _convnd_grad_h(gn, W, H), _convnd_grad_h(gp, W, H), gamma, l1, l2, ortho)
+    return W, H, grads
+
+
 # --------------------------------------------------------------------------
 # fit driver (nmf.py:297-409, dense branch)
 # --------------------------------------------------------------------------

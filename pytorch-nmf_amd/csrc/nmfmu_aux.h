@@ -50,6 +50,7 @@ int launch_reconstruct(const float* A, int M, const float* B, int K, int R, floa
 int launch_probe_mfma(const uint16_t* a, const uint16_t* b, float* d, hipStream_t s);
 int launch_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, hipStream_t s);
 int launch_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
-                           int waves, int tiles, int grid, float* out, hipStream_t s);
+                           int waves, int tiles, int grid, float* out, hipStream_t s, int wrap_tiles = 0,
+                           unsigned long long* stamps = nullptr);
 
 }  // namespace nmfmu

@@ -656,7 +656,8 @@ int launch_probe_lds_dma(const uint32_t* src, uint32_t* dst, int n_dwords, hipSt
 // this part under its power limit; bench.py prices the shipped kernel against it next to the nominal 2.5 PFLOP/s.
 template <int NLOAD, bool F16>
 __global__ void __launch_bounds__(512) ubench_mfma_hbm_kernel(const char* __restrict__ operands, size_t operand_bytes,
-                                                              const char* __restrict__ src_all, int tiles, float* __restrict__ out) {
+                                                              const char* __restrict__ src_all, int tiles, float* __restrict__ out,
+                                                              int wrap_tiles, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -678,7 +679,16 @@ __global__ void __launch_bounds__(512) ubench_mfma_hbm_kernel(const char* __rest
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   const unsigned lds_base =
       __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 8192u;
-  const char* src = src_all + ((size_t)blockIdx.x * nwaves + wave) * ((size_t)tiles * (NLOAD ? NLOAD : 1) * 1024) + lane * 16;
+  // (round 6) a launch may run more tiles than the stream holds: it then wraps after wrap_tiles tiles per wave (the ceiling
+  // wants a LONG loop -- 64 tiles are 88 us of which ramp, operand fetch and drain are a fifth); wave 0 stamps the loop
+  const int wt = wrap_tiles > 0 ? wrap_tiles : tiles;
+  const char* src = src_all + ((size_t)blockIdx.x * nwaves + wave) * ((size_t)wt * (NLOAD ? NLOAD : 1) * 1024) + lane * 16;
+  unsigned long long c0 = 0, r0 = 0;
+  if (stamps) {      // every wave stamps its own loop: the two waves of a SIMD do not share the pipe evenly (the older one wins)
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  int tw = 0;
   for (int t = 0; t < tiles; ++t) {
     if constexpr (NLOAD > 0) {
 #pragma unroll
@@ -686,9 +696,10 @@ __global__ void __launch_bounds__(512) ubench_mfma_hbm_kernel(const char* __rest
         const unsigned la = lds_base + (unsigned)((p & 7) * 1024);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
                      :
-                     : "v"(src + (size_t)(t * NLOAD + p) * 1024), "s"(la)
+                     : "v"(src + (size_t)(tw * NLOAD + p) * 1024), "s"(la)
                      : "memory", "m0");
       }
+      tw = tw + 1 == wt ? 0 : tw + 1;
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLOAD > 63 ? 63 : 3 * NLOAD) : "memory");
     }
 #pragma unroll
@@ -704,19 +715,28 @@ __global__ void __launch_bounds__(512) ubench_mfma_hbm_kernel(const char* __rest
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tt += acc[i][e];
+    for (int e = 0; e < 16; ++e) tt += acc[i][e];   // (reads every accumulator: the loop's MFMAs have retired)
+  if (stamps) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      stamps[4 * ((size_t)blockIdx.x * nwaves + wave)] = c1 - c0;       // shader cycles of this wave's loop
+      stamps[4 * ((size_t)blockIdx.x * nwaves + wave) + 1] = r1 - r0;   // 100 MHz ticks of it
+      stamps[4 * ((size_t)blockIdx.x * nwaves + wave) + 2] = r0;        // its start and end on the constant clock: the
+      stamps[4 * ((size_t)blockIdx.x * nwaves + wave) + 3] = r1;        // workgroup's span is max(end) - min(start)
+    }
+  }
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = tt;
 }
 
 int launch_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
-                           int waves, int tiles, int grid, float* out, hipStream_t s) {
+                           int waves, int tiles, int grid, float* out, hipStream_t s, int wrap_tiles, unsigned long long* stamps) {
   auto go = [&](auto kern) {
     static bool done[64] = {};
     (void)done;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), (size_t)waves * 8192, s, (const char*)operands, operand_bytes,
-                       (const char*)stream_src, tiles, out);
+                       (const char*)stream_src, tiles, out, wrap_tiles, stamps);
     return (int)hipGetLastError();
   };
 #define UB(N) \

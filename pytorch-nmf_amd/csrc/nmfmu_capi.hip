@@ -133,13 +133,18 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   if (st->block_rows == 256) {   // the eight-wave ping-pong kernel (beta == 1, one operand plane, padded rank <= 128)
     if (!st->xp || mode == kModeDen || !pp_eligible(st->r_pad, st->precision, st->beta)) return NMFMU_ERR_UNSUPPORTED;
     a.tiles_per_split = (a.tiles_per_split + 1) & ~1;   // its tile loop is unrolled by two
+    a.debug = mode == kModeMU ? st->stamps : nullptr;
 #ifdef NMFMU_DEBUG_HOOKS
-    a.debug = mode == kModeMU ? g_pp_debug : nullptr;
+    if (mode == kModeMU && g_pp_debug) a.debug = g_pp_debug;
 #endif
     return launch_pp(st->r_pad, st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16, mode, a, grid, s);
   }
   if (mode == kModeMU && sp_eligible(st->r_pad, st->precision, st->beta)) {
     a.tiles_per_split = (a.tiles_per_split + 3) & ~3;   // its tile loop runs in groups of four (ring slot = tile & 3)
+    a.debug = st->stamps;
+#ifdef NMFMU_DEBUG_HOOKS
+    if (g_pp_debug) a.debug = g_pp_debug;
+#endif
     return launch_sp(st->r_pad, kOpF16, a, grid, s);
   }
   const int kk = kernel_beta_kind(st->beta);
@@ -515,6 +520,16 @@ int nmfmu_ubench_mfma_hbm(const void* operands, size_t operand_bytes, int f16, c
   if (!operands || operand_bytes < 65536 || !out || (waves != 4 && waves != 8) || tiles <= 0 || grid <= 0) return NMFMU_ERR_ARG;
   if (kib_per_tile != 0 && !stream_src) return NMFMU_ERR_ARG;
   const int rc = launch_ubench_mfma_hbm(operands, operand_bytes, f16, stream_src, kib_per_tile, waves, tiles, grid, out, S(stream));
+  return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
+}
+
+int nmfmu_ubench_mfma_hbm2(const void* operands, size_t operand_bytes, int f16, const void* stream_src, int kib_per_tile,
+                           int waves, int tiles, int wrap_tiles, int grid, float* out, uint64_t* stamps, void* stream) {
+  if (!operands || operand_bytes < 65536 || !out || (waves != 4 && waves != 8) || tiles <= 0 || grid <= 0 || wrap_tiles < 0)
+    return NMFMU_ERR_ARG;
+  if (kib_per_tile != 0 && !stream_src) return NMFMU_ERR_ARG;
+  const int rc = launch_ubench_mfma_hbm(operands, operand_bytes, f16, stream_src, kib_per_tile, waves, tiles, grid, out, S(stream),
+                                        wrap_tiles, reinterpret_cast<unsigned long long*>(stamps));
   return rc == -2 ? NMFMU_ERR_UNSUPPORTED : rc;
 }
 

@@ -135,7 +135,7 @@ struct FusedArgs {
   const uint16_t* gram_lo;
   const float* gram_scale;   // [R_PAD]: 2^gram_exp[r], multiplied back onto the denominator column r
   uint32_t* status;       // or nullptr: bit 0 is set when the fused apply had to clamp an fp16 image value at 65504
-  void* debug;            // NMFMU_DEBUG_HOOKS builds: clock stamps of the ping-pong kernel (tools/pp_timeline.py)
+  void* debug;            // nmfmu_step.stamps: clock stamps of the ping-pong / software-pipelined kernels (tools/pp_timeline.py); kModeXB: diagnostic builds
 };
 
 template <int R_PAD, int BETA, int PREC, int MODE>

@@ -110,13 +110,13 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   const int m0 = mb * C::BM + wave * 32 + j;
 
   if constexpr (OPT == kOpF16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: saturate
-  // Diagnostic builds (make EXTRA=-DNMFMU_DEBUG_HOOKS; tools/pp_timeline.py): with a.debug set, wave 0 / wave 4 of
+  // Clock stamps (nmfmu_step.stamps; round 6: compiled into the product build -- measured free, nothing sits in the loop;
+  // tools/pp_timeline.py, bench.py roofline.in_kernel): with a.debug set, wave 0 / wave 4 of
   // workgroup 0 record the shader clock and the constant 100 MHz clock at kernel entry (slot 2), at the start (0) and
   // the end (1) of the tile loop and at kernel exit (3) -- cycles per tile, the core frequency, what prologue and
   // epilogue cost, unperturbed (nothing inside the loop); every workgroup records the 100 MHz clock at the four points
   // ([64 + 5 wg + slot]) and where it ran ([.. + 4]: XCC_ID << 32 | HW_ID).
   auto stamp = [&](int slot) {
-#ifdef NMFMU_DEBUG_HOOKS
     if constexpr (MODE == kModeMU) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.debug);
       if (!dbg) return;
@@ -139,7 +139,6 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
         }
       }
     }
-#endif
   };
   stamp(2);
 
@@ -782,10 +781,10 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       });
     }
   }
-#ifdef NMFMU_DEBUG_HOOKS
-  if (a.debug) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
-  stamp(3);
-#endif
+  if constexpr (MODE == kModeMU) {
+    if (a.debug) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
+    stamp(3);
+  }
 }
 
 template <int R_PAD, int OPT, int MODE>

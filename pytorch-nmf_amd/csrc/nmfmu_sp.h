@@ -100,6 +100,25 @@ __global__ void __launch_bounds__(256, 1) sp_kernel(const FusedArgs a) {
   const int nt = t1 - t0;    // a multiple of 4: the host rounds tiles_per_split, the padded contraction is a multiple of 256
 
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");  // FP16_OVFL: conversions saturate at 65504
+  // clock stamps (nmfmu_step.stamps; layout of nmfmu_pp.h): kernel entry (slot 2), loop start (0), loop end (1), exit (3)
+  auto stamp = [&](int slot) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.debug);
+    if (!dbg || wave != 0) return;
+    const unsigned long long c = __builtin_amdgcn_s_memtime();
+    const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      if (blockIdx.x == 0) {
+        dbg[slot * 4 + 0] = c;
+        dbg[slot * 4 + 1] = r;
+        dbg[slot * 4 + 2] = (unsigned long long)(nt > 0 ? nt : 0);
+      }
+      dbg[64 + 5 * blockIdx.x + slot] = r;
+      if (slot == 2)
+        dbg[64 + 5 * blockIdx.x + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                                       (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+  };
+  stamp(2);
 
   // numerator accumulators: AGPRs for the whole kernel (every MFMA that touches them names them "+a")
   f32x16 acc[RT];
@@ -346,9 +365,11 @@ __global__ void __launch_bounds__(256, 1) sp_kernel(const FusedArgs a) {
       });
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // XDL write -> VALU read of S (asm MFMAs are not padded)
     }
+    stamp(0);
     int i0 = 0;
     for (; i0 + 4 < nt; i0 += 4) group(i0, std::false_type{});
     group(i0, std::true_type{});
+    stamp(1);
     // XDL write -> VALU read of the accumulators; the clamped tail prefetches: nothing may land in LDS / registers after this
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)"
                  : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[0][2]), "+v"(xb[0][3]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[1][2]),
@@ -499,6 +520,8 @@ __global__ void __launch_bounds__(256, 1) sp_kernel(const FusedArgs a) {
       }
     });
   }
+  if (a.debug) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have left the CU
+  stamp(3);
 }
 
 template <int R_PAD, int OPT>

@@ -42,7 +42,7 @@ class Step(C.Structure):
     _fields_ = [('xp', C.c_void_p), ('owner', Factor), ('panel', Factor), ('slab_num', C.c_void_p),
                 ('slab_den', C.c_void_p), ('rank', C.c_int32), ('r_pad', C.c_int32), ('nsplit', C.c_int32),
                 ('precision', C.c_int32), ('stage', C.c_int32), ('block_rows', C.c_int32), ('beta', C.c_float), ('gamma', C.c_float),
-                ('l1', C.c_float), ('l2', C.c_float), ('status', C.c_void_p)]
+                ('l1', C.c_float), ('l2', C.c_float), ('status', C.c_void_p), ('stamps', C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -218,6 +218,8 @@ SIGNATURES = {
     'nmfmu_debug_set_buffer': (C.c_int, [C.c_void_p]),
     'nmfmu_ubench_mfma_hbm': (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
+    'nmfmu_ubench_mfma_hbm2': (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -609,7 +609,7 @@ class DenseMU(AsyncLossMixin):
     def _local_step(self, st, kl_den, tag):
         """A complete single-device half-step (nmfmu_mu_step); with a timer attached the fused kernel is bracketed."""
         if not hasattr(self.be, 'mu_step'):          # stand-in test backend
-            self.be.mu_partial(st)
+            self._partial(st, tag)
             self.be.mu_apply(st, None, None, 0, kl_den)
         elif self.timer is None:
             self.be.mu_step(st, kl_den, 0)

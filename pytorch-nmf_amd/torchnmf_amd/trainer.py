@@ -10,8 +10,13 @@ closure built.  Two graph shapes are recognised through the provenance tag ``for
   seeds ``G_{k-1} = G_k W_k`` and the parameter gradients ``G_k^T X_{k-1}`` are exact-fp32 MFMA products
   (``nmfmu_reconstruct``), the seeds come from ``nmfmu_mu_terms`` and the update from ``nmfmu_trainer_update``.
 
-Anything else (arithmetic on the prediction, convolutive layers) raises ``NotImplementedError`` -- there is no autograd
-fallback.
+* ONE convolutive layer (``NMFD`` / ``NMF2D`` / ``NMF3D``, round 6): the backward passes through the convolution are the
+  numerator / denominator GEMMs of the convolutive engine (``nmfd_engine.ConvMU``: reconstruction + ratio planes, then
+  ratio x Toeplitz operand for W and ratio x W for H); their results, in the parameter's
+  own layout, go through ``nmfmu_trainer_update`` like a chain's.
+
+Anything else (arithmetic on the prediction, chains that contain a convolutive layer) raises ``NotImplementedError`` --
+there is no autograd fallback.
 
     trainer = BetaMu(m.parameters(), beta=1)
     def closure():
@@ -41,6 +46,73 @@ class SparsityProj(Optimizer):
                                   'hot path torchnmf_amd implements; use the reference package for sparse_fit')
 
 
+class _ConvBinding:
+    """One convolutive layer bound to a target for ``BetaMu``: the convolutive engine drives the GEMMs (no fused update:
+    ``own_loop=False``), this class turns their outputs into (neg, pos) of trainer.py:93-97 in the parameter's layout."""
+
+    def __init__(self, V, W, H, beta, precision):
+        from .nmfd_engine import ConvMU
+        from . import _capi
+        self._capi = _capi
+        # 'auto' = the fp32-grade split mode (the engine's own fp16 admission belongs to its fused fit loop)
+        self.eng = e = ConvMU(V, W, H, beta, precision=('bf16x3' if precision in (None, 'auto') else precision), own_loop=False)
+        self.lib, self.beta = e.lib, float(beta)
+        dev = V.device
+        self.numh = torch.empty(e.B * e.R * e.Lh, dtype=torch.float32, device=dev)
+        self.denh = None if e.kl else torch.empty_like(self.numh)
+
+    @property
+    def precision_name(self):
+        return self.eng.precision_name
+
+    def _s(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _w_plane(self, buf):
+        """[c][(r, t)] GEMM output (row pitch rp_pad, split-K slabs summed) -> tensor of W's shape."""
+        e = self.eng
+        if e.w_ksplit > 1:
+            self._capi.check(self.lib.nmfmu_slab_sum(buf.data_ptr(), (e.c_rows or e.c_pad) * e.rp_pad, e.w_ksplit, self._s()),
+                             'nmfmu_slab_sum')
+        rows = e.c_rows or e.c_pad
+        return buf[:rows * e.rp_pad].view(rows, e.rp_pad)[:e.C, :e.R * e.T].reshape(e.W.shape).contiguous()
+
+    def grads_w(self):
+        """(neg, pos) for W: trainer.py:93-97 through conv's backward = ratio planes x the Toeplitz operand of H."""
+        e, c = self.eng, self._capi
+        e.recon_ratio_w()
+        e._gemm(e.gn, e.hut, c.EPI_F32, out=e.num_w, k_split=e.w_ksplit, m_rows=e.c_rows)
+        neg = self._w_plane(e.num_w)
+        if e.kl:   # beta == 1 back-propagates ones: sum_{b,j} H[b][r][j] for every (c, t) (all taps see the whole of H)
+            pos = e.sum_h.view(1, e.R, *([1] * e.nd)).expand(e.W.shape).contiguous()
+        else:
+            e._gemm(e.gp, e.hut, c.EPI_F32, out=e.den_w, k_split=e.w_ksplit, m_rows=e.c_rows)
+            pos = self._w_plane(e.den_w)
+        return neg, pos
+
+    def _h_fold(self, planes, rows_out, y_out, flat):
+        e, c = self.eng, self._capi
+        if e.h_rows:      # window-operand GEMM over shifted rows of the ratio planes, then the tap fold of its columns
+            e._gemm_win(planes, rows_out)
+            c.check(self.lib.nmfmu_conv_rows_fold(flat.data_ptr(), e.B, e.R, e.Lh // e.lhs[-1], e.lhs[-1], e.wk_fold,
+                                                  rows_out.data_ptr(), e.wk_rows, self._s()), 'nmfmu_conv_rows_fold')
+        else:             # Y [(r,t)][(b,l)] and the col2im sum of conv's backward
+            e._gemm(e.wmt, planes, c.EPI_F32, out=y_out)
+            c.check(self.lib.nmfmu_convnd_fold(flat.data_ptr(), e.B, e.R, e.nd, e._lh_arr, e._t_arr, y_out.data_ptr(), e.bl_pad,
+                                               self._s()), 'nmfmu_convnd_fold')
+        return flat.view(e.H.shape)
+
+    def grads_h(self):
+        e, c = self.eng, self._capi
+        e._gemm(e.hu, e.wm, c.EPI_RATIO, x=e.x_h, gn=e.gnt, gp=e.gpt, n_rows=e.c_rows)
+        neg = self._h_fold(e.gnt, e.hnum if e.h_rows else None, e.y, self.numh)
+        if e.kl:
+            pos = e.sum_w.view(1, e.R, *([1] * e.nd)).expand(e.H.shape).contiguous()
+        else:
+            pos = self._h_fold(e.gpt, e.hden if e.h_rows else None, e.y_den, self.denh)
+        return neg, pos
+
+
 class BetaMu(Optimizer):
     """Multiplicative updater minimising the beta-divergence (same arguments and checks as trainer.py:24-33).
 
@@ -63,7 +135,8 @@ class BetaMu(Optimizer):
     # ------------------------------------------------------------------
     @staticmethod
     def _chain(pred):
-        """(X0, [W1, ..., Wn]) behind the closure's prediction ``X0 @ W1.T @ ... @ Wn.T``, or raise."""
+        """(X0, [W1, ..., Wn], None) behind the closure's prediction ``X0 @ W1.T @ ... @ Wn.T``, or (H, [W], layer) for one
+        convolutive layer, or raise."""
         if isinstance(pred, BaseComponent):            # deferred form: the layer itself
             node = (pred, pred.H, pred.W)
         else:
@@ -76,13 +149,17 @@ class BetaMu(Optimizer):
         Ws: List = []
         while True:
             layer, H, W = node
+            if isinstance(layer, (_nmf.NMFD, _nmf.NMF2D, _nmf.NMF3D)):
+                if Ws or getattr(H, '_nmf_source', None) is not None:
+                    raise NotImplementedError('BetaMu: a convolutive layer is supported on its own, not inside a chain')
+                return H, [W], layer
             if not isinstance(layer, NMF):
-                raise NotImplementedError(f'BetaMu: only NMF layers are supported, got {type(layer).__name__}')
+                raise NotImplementedError(f'BetaMu: only NMF / NMFD / NMF2D / NMF3D layers are supported, got {type(layer).__name__}')
             assert H is not None and W is not None
             Ws.append(W)
             node = getattr(H, '_nmf_source', None)
             if node is None:
-                return H, Ws[::-1]
+                return H, Ws[::-1], None
 
     def _engine(self, V_user, V, converted, H, W, beta, l1, l2) -> DenseMU:
         """DenseMU bound to (target, W, H), rebuilt when any of them is replaced and refreshed when W / H are edited in
@@ -125,6 +202,15 @@ class BetaMu(Optimizer):
                 self._engines[key] = (None, versions, V_user)
                 self.last_precision = 'chain'
                 return None
+        if self._precision in (None, 'auto') and converted and W.shape[1] <= 128:
+            #  a target that is re-packed from its source on every step may CHANGE between steps, and 'f16'
+            # is admitted on the first one's contents (fp16-exact, in range): resolve 'auto' here and take the mode that keeps
+            # the target in fp32 instead
+            from .engine import DEFAULT_BACKEND_FACTORY
+            be = DEFAULT_BACKEND_FACTORY()
+            precision = DenseMU.auto_single_plane(V, W.data, H.data, be.pad_rank(W.shape[1]), be) or 'bf16x3'
+        if self._precision in (None, 'auto') and converted and precision == 'f16':
+            precision = 'f16x'
         eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=precision, allow_f16=True)
         self.last_precision = eng.precision_name       # what 'auto' resolved to (plain attribute, like NMF.last_precision)
         bad, _ = eng.target_flags()
@@ -163,6 +249,60 @@ class BetaMu(Optimizer):
                                              float(l1), float(l2), float(ortho), mu_gamma(float(beta)), p.grad.data_ptr(),
                                              s), 'nmfmu_trainer_update')
 
+    def _watch_range(self, eng):
+        """ the fp16 modes are admitted on the data of the step that built the engine; a factor that later grows
+        beyond 65504 is clamped in its fp16 image and the kernels say so in ``nmfmu_step.status``.  fit() reads that word at
+        its loss checkpoints; the trainer has none, so every 16th update of an fp16-mode engine does (one small device read)
+        and warns once."""
+        if getattr(self, '_range_warned', False) or not hasattr(eng, 'left_f16_range'):
+            return
+        self._range_tick = getattr(self, '_range_tick', 0) + 1
+        if self._range_tick % 16 == 0 and eng.left_f16_range():
+            import warnings
+            warnings.warn("torchnmf_amd: a factor grew beyond fp16's range (65504) during BetaMu steps; its fp16 operand image "
+                          "is clamped from here on and the updates stop following the reference.  Construct the optimizer with "
+                          "precision='bf16x3' for data of this scale.", stacklevel=3)
+            self._range_warned = True
+
+    def _conv_step(self, V_user, V, converted, H, W, p, beta, l1, l2, ortho):
+        """trainer.py:72-112 for parameter ``p`` of ONE convolutive layer (see the module docstring)."""
+        from . import _capi
+        from .engine import mu_gamma
+        key = ('conv', id(V_user), tuple(V.shape), W.data_ptr(), H.data_ptr(), float(beta))
+        hit = self._engines.get(key)
+        versions = [V_user._version, W._version, H._version]
+        if hit is not None and hit[2] is V_user and not converted and hit[1][0] == versions[0]:
+            b, seen, _ = hit
+            if seen[1:] != versions[1:]:               # someone else edited W / H since our last update
+                b.eng.refresh_images()
+        else:
+            for k in [k for k, v in self._engines.items() if v[2] is not V_user or k[0] != 'conv' or k[3:5] != key[3:5]]:
+                del self._engines[k]
+            b = _ConvBinding(V, W.data, H.data, beta, self._precision)
+            bad, _ = b.eng.target_flags()
+            assert not bad, "Target should be non-negative."
+            self.last_precision = b.precision_name
+        neg, pos = b.grads_w() if p is W else b.grads_h()
+        grad = p.grad
+        if ortho > 0:
+            # the orthogonality term sums over dim 1 -- the rank axis of W (C, R, *T) and of H (B, R, *L) -- which the flat
+            # [rows][cols] update kernel cannot see: p.grad = relu(pos) - relu(neg) and the term are formed here (both terms
+            # are sums of non-negative products, so the kernel's relu of the augmented pos changes nothing)
+            torch.sub(pos.relu(), neg.relu(), out=p.grad)
+            pos = pos.relu().add_(p.data.sum(1, keepdim=True) - p.data, alpha=float(ortho))
+            grad = None
+        lib = _capi.load()
+        _capi.check(lib.nmfmu_trainer_update(p.data.data_ptr(), p.shape[0], p.data[0].numel(), neg.data_ptr(), pos.data_ptr(),
+                                             float(l1), float(l2), 0.0, mu_gamma(float(beta)),
+                                             grad.data_ptr() if grad is not None else None,
+                                             torch.cuda.current_stream().cuda_stream), 'nmfmu_trainer_update')
+        # the operand images of the parameter that changed (its rank sums ride along)
+        if p is W:
+            b.eng._pack_w()
+        else:
+            b.eng._pack_h()
+        self._engines[key] = (b, [V_user._version, W._version, H._version], V_user)
+
     @torch.no_grad()
     def step(self, closure):
         """One multiplicative update of every parameter (trainer.py:36-121).
@@ -183,7 +323,7 @@ class BetaMu(Optimizer):
                         continue
                     p.requires_grad = True
                     V, pred = closure()
-                    X0, Ws = self._chain(pred)
+                    X0, Ws, conv = self._chain(pred)
                     names = [X0] + Ws
                     if not any(p is q for q in names):    # p does not feed this prediction (trainer.py:73-75)
                         p.requires_grad = False
@@ -204,6 +344,13 @@ class BetaMu(Optimizer):
                     # where the fp16 modes are not admissible (split bf16 stops at rank 128; _engine then answers None)
                     # and anything wider than the kernels' 256 take the exact chain path below, which has no rank limit
                     # (the reference's BetaMu has none either, trainer.py:72-112).
+                    if conv is not None:
+                        assert V.dim() == Ws[0].dim() and V.shape[0] == X0.shape[0] and V.shape[1] == Ws[0].shape[0] and \
+                            all(l == lh + t - 1 for l, lh, t in zip(V.shape[2:], X0.shape[2:], Ws[0].shape[2:])), \
+                            f'target shape {tuple(V.shape)} does not match the layer'
+                        self._conv_step(V_user, V, converted, X0, Ws[0], p, beta, l1, l2, ortho)
+                        p.requires_grad = False
+                        continue
                     rank1 = Ws[0].shape[1] if len(Ws) == 1 else 0
                     fused_ok = len(Ws) == 1 and (rank1 <= 128 or (rank1 <= 256 and self._precision != 'bf16x3'))
                     eng = None
@@ -214,6 +361,7 @@ class BetaMu(Optimizer):
                         eng = self._engine(V_user, V, converted, H, W, beta, l1, l2)
                     if eng is not None:
                         eng.trainer_step('W' if p is W else 'H', ortho, p.grad)
+                        self._watch_range(eng)
                     else:
                         self._chain_step(V, X0, Ws, p, beta, l1, l2, ortho)
                     p.requires_grad = False

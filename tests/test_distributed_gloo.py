@@ -219,3 +219,33 @@ def test_auto_precision_gate_is_rank_invariant(tmp_path, cols, inexact_rank, wan
     got = [torch.load(tmp_path / f'g{r}.pt') for r in range(world)]
     assert [g_[0] for g_ in got] == [want] * world, got
     assert sorted(g_[1] for g_ in got) == ([64, 64] if cols == 128 else [63, 64])
+
+
+def test_bench_script_control_flow_world2(tmp_path):
+    """`python bench.py --gpus 2` end to end (its N > 1 control flow had never executed anywhere): the script
+    spawns its own two ranks (torch.multiprocessing), they rendezvous on 127.0.0.1, run warm-up / pre-roll / barrier-bracketed
+    blocks of exactly K steps with the MAX over ranks, the roofline leg with the all-reduce span, the same-shard 1-GPU
+    denominator on rank 0 -- and rank 0 prints exactly ONE JSON line.  `--standin` swaps CUDA tensors / RCCL / the HIP library
+    for CPU tensors / gloo / the oracle-backed stand-in backend of this suite: the line measures nothing (and says so); what is
+    under test is every line of host code between `main()` and that print."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--standin', '--steps', '3', '--warmup', '1',
+                        '--repeats', '2', '--cpu-iters', '0', '--rows', '48', '--cols', '40', '--rank', '5'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['nranks'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert 'NOT a measurement' in d['data']
+    assert len(d['blocks_ms_per_step']) == 2 and d['ms_per_step'] > 0 and d['value'] > 0     # fixed block count when sharded
+    assert d['config']['parallelism'] == 'column-shard x2' and d['config']['cols_per_gpu'] == 40
+    rf = d['roofline']
+    assert rf['avg_allreduce_ms'] > 0 and rf['avg_launch_ms_h_step'] > 0 and rf['avg_launch_ms_w_step'] > 0
+    s1 = d['same_shard_1gpu']
+    assert s1['ms_per_step'] > 0 and d['efficiency'] == pytest.approx(s1['ms_per_step'] / d['ms_per_step'], rel=1e-3)
+    assert 'another workload' in d['scaling_note']

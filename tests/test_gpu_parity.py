@@ -1558,6 +1558,68 @@ def test_betamu_g7_golden(dev, case):
     assert m.W.requires_grad and m.H.requires_grad
 
 
+def _g14_cases():
+    return [str(c) for c in load_golden('g14_betamu_conv')['cases']]
+
+
+@pytest.mark.parametrize('case', _g14_cases())
+def test_betamu_conv_g14_golden(dev, case):
+    """trainer.BetaMu over ONE convolutive layer (NMFD / NMF2D / NMF3D; VERDICT r5 Missing 3): the reference's outputs
+    (tools/make_golden.py g14) after 1 and 3 steps of both parameters, beta in {0.5, 1, 2}, plain and with l1 / l2 /
+    orthogonality penalties; p.grad of the step's last parameter on the scale of its terms."""
+    from torchnmf_amd import nmf as anmf
+    from torchnmf_amd.trainer import BetaMu
+    g = load_golden('g14_betamu_conv')
+    name, bs, pen = case.split('_')
+    l1, l2, ortho = {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}[pen]
+    cls = {'1d': anmf.NMFD, '2d': anmf.NMF2D, '3d': anmf.NMF3D}[name]
+    m = cls(W=t(g[f'{name}_W0']), H=t(g[f'{name}_H0'])).to(dev)
+    trainer = BetaMu(m.parameters(), float(bs[1:]), l1, l2, ortho)
+    V = t(g[f'{name}_V']).to(dev)
+
+    def closure():
+        trainer.zero_grad()
+        return V, m()
+    for it in range(1, 4):
+        trainer.step(closure)
+        if it in (1, 3):
+            ew, eh = rel_err(m.W.data.cpu(), g[f'{case}_W{it}']), rel_err(m.H.data.cpu(), g[f'{case}_H{it}'])
+            record('betamu_conv_g14', case=case, it=it, relW=ew, relH=eh)
+            assert ew < TOL and eh < TOL, (it, ew, eh)
+        if it == 1:
+            got, want = m.H.grad.cpu(), t(g[f'{case}_gradH1'])
+            assert float((got - want).norm() / want.norm()) < 2e-3
+    assert trainer.last_precision == 'bf16x3' and m.W.requires_grad and m.H.requires_grad
+
+
+def test_betamu_conv_layer_forms(dev):
+    """The deferred closure form (``return V, m``), one parameter only, an outside edit of a factor between steps (the
+    binding refreshes its operand images), and the refusal of a convolutive layer inside a chain."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.nmf import NMF, NMFD
+    from torchnmf_amd.trainer import BetaMu
+    g = torch.Generator().manual_seed(14)
+    V = torch.rand(2, 40, 96, generator=g)
+    W0, H0 = torch.randn(40, 5, 8, generator=g).abs(), torch.randn(2, 5, 89, generator=g).abs()
+    m = NMFD(W=W0.clone(), H=H0.clone()).to(dev)
+    trainer = BetaMu([m.W], 1, 0, 1e-3, 0)
+    Vd = V.to(dev)
+    trainer.step(lambda: (Vd, m))
+    Wr, _, _ = O.betamu_conv_step(V, W0, H0, 1, 0, 1e-3, 0, params=('W',))
+    assert rel_err(m.W.data.cpu(), Wr) < TOL and torch.equal(m.H.data.cpu(), H0)
+    with torch.no_grad():
+        m.H.mul_(1.5)                                   # outside edit: bumps H._version
+    trainer.step(lambda: (Vd, m))
+    Wr2, _, _ = O.betamu_conv_step(V, Wr, H0 * 1.5, 1, 0, 1e-3, 0, params=('W',))
+    assert rel_err(m.W.data.cpu(), Wr2) < TOL
+    chain = torch.nn.Sequential(NMF((6, 4), 3), NMF((4, 5), 4)).to(dev)
+    mixed = BetaMu(m.parameters(), 1)
+    pred = m()
+    pred._nmf_source = (m, chain(None), m.W)            # a convolutive layer fed by another layer's output
+    with pytest.raises(NotImplementedError):
+        mixed.step(lambda: (Vd, pred))
+
+
 @pytest.mark.parametrize('beta', [-1, 0, 0.5, 1, 1.5, 2, 3])
 @pytest.mark.parametrize('attr', ['W', 'H'])
 def test_betamu_grad_is_beta_div_gradient(dev, beta, attr):
@@ -2180,6 +2242,52 @@ def test_rank256_software_pipelined_kernel(dev, monkeypatch, N, C, nsplit, regs)
     record('rank256_sp_kernel', N=N, C=C, nsplit=(eng.step_w.nsplit, eng.step_h.nsplit), regs=regs, relW=ew, relH=eh)
     assert ew < 4e-4 and eh < 4e-4, (ew, eh)
     assert eng.divergence() == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, 1)), rel=1e-3)
+
+
+def test_cfg5_full_shard_two_iterations(dev):
+    """ONE full per-GPU shard of BASELINE configs[4] -- 8192 x 262144, rank 256, beta = 1, fp16 operands (4 GiB of packed V per
+    orientation; 2 048 workgroups of 128 tiles in the W half-step, 256 x 1 024 tiles in the H half-step) -- through the
+    engine: the loss decreases, every factor entry is finite and positive, and 64 sampled rows of W and of H after the second
+    iteration agree with the oracle's half-steps recomputed for exactly those rows from the factors the GPU held before them
+    (the W half-step of a row needs its column of V and all of H; the H half-step of a row its row of V and all of W).
+    A size-independent check of the launch the slice test (one sixteenth of this shard) cannot see: every row block of the
+    2 048, all eight rounds of workgroups, the fused apply over 256 MiB of master rows."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd.engine import DenseMU
+    N, C, R = 8192, 262144, 256
+    g = torch.Generator(device=dev).manual_seed(54)
+    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float()
+    W = torch.randn(C, R, device=dev, generator=g).abs_()
+    H = torch.randn(N, R, device=dev, generator=g).abs_()
+    eng = DenseMU(V, W, H, 1.0, precision='f16')
+    assert eng.r_pad == 256 and eng.step_w.nsplit == 1 and eng.step_h.owner.rows_pad == N
+    loss0 = eng.divergence()
+    eng.w_step()
+    eng.h_step()
+    loss1 = eng.divergence()
+    Wp, Hp = W.clone(), H.clone()
+    gs = torch.Generator().manual_seed(7)
+    cols = torch.randperm(C, generator=gs)[:64].sort().values
+    rows = torch.randperm(N, generator=gs)[:64].sort().values
+    eng.w_step()
+    torch.cuda.synchronize()
+    Hp_c = Hp.cpu()
+    Wr = O.nmf_w_step(V[:, cols.to(dev)].cpu(), Wp[cols.to(dev)].cpu(), Hp_c, 1, 1.0)
+    ew = rel_err(W[cols.to(dev)].cpu(), Wr)
+    W2 = W.cpu()
+    eng.h_step()
+    torch.cuda.synchronize()
+    Hr = O.nmf_h_step(V[rows.to(dev)].cpu(), W2, Hp_c[rows], 1, 1.0)
+    eh = rel_err(H[rows.to(dev)].cpu(), Hr)
+    loss2 = eng.divergence()
+    wmin, hmin = float(W.min()), float(H.min())
+    record('cfg5_full_shard', relW_rows=ew, relH_rows=eh, loss=(loss0, loss1, loss2), w_min=wmin, h_min=hmin)
+    assert loss0 > loss1 > loss2 > 0
+    assert bool(torch.isfinite(W).all()) and bool(torch.isfinite(H).all())
+    assert wmin >= 0 and hmin >= 0        # (an entry may underflow to exactly 0, as it does in the reference; never below)
+    assert ew < TOL and eh < TOL, (ew, eh)
+    # the column sums the next half-step's closed-form denominators read (nmf.py:122-131) cover every row block
+    assert rel_err(eng.fW.colsum[:R].cpu().double(), W.double().sum(0).cpu()) < 1e-5
 
 
 def test_auto_precision_policy(dev, monkeypatch):

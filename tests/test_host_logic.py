@@ -140,7 +140,7 @@ def test_static_queries():
     assert lib.nmfmu_xp_bytes(4096, 65536, _capi.PREC_BF16) == 4096 * 65536 * 2
     assert lib.nmfmu_slab_bytes(4096, 128, 16) == 16 * 4096 * 128 * 4
     # struct layouts agree with the header (sizeof via a known-good packing: 7 pointers + 2 int32)
-    assert ctypes.sizeof(_capi.Factor) == 64 and ctypes.sizeof(_capi.Step) == 8 + 64 * 2 + 16 + 4 * 6 + 4 * 4 + 8
+    assert ctypes.sizeof(_capi.Factor) == 64 and ctypes.sizeof(_capi.Step) == 8 + 64 * 2 + 16 + 4 * 6 + 4 * 4 + 8 + 8   # (+ stamps, ABI 9)
 
 
 # ---- fit() driver semantics on the stand-in backend -------------------------------------------------------

@@ -313,3 +313,29 @@ def test_g12_betamu_chain_oracle(beta, pen):
             for pn, t_ in (('W1', Ws[0]), ('H1', X0), ('W2', Ws[1]), ('W3', Ws[2])):
                 assert rel_err(t_, g[f'b{beta}_{pen}_{pn}_{it}']) < 1e-4
     assert rel_err(grads['W3'], g[f'b{beta}_{pen}_gradW3']) < 1e-3
+
+
+def g14_cases():
+    return [str(c) for c in load_golden('g14_betamu_conv')['cases']]
+
+
+@pytest.mark.parametrize('case', g14_cases())
+def test_g14_betamu_conv_oracle(case):
+    """oracle.mu_oracle.betamu_conv_step against the reference's trainer.BetaMu on ONE convolutive layer (NMFD / NMF2D /
+    NMF3D; golden g14, tools/make_golden.py g14): factors after 1 and 3 steps, p.grad of the first step's last parameter."""
+    from oracle import mu_oracle as O
+    g = load_golden('g14_betamu_conv')
+    name, bs, pen = case.split('_')
+    beta = float(bs[1:])
+    l1, l2, ortho = (1e-3, 1e-3, 1e-2) if pen == 'pen' else (0, 0, 0)
+    V, W, H = t(g[f'{name}_V']), t(g[f'{name}_W0']), t(g[f'{name}_H0'])
+    order = tuple(str(x) for x in g[f'{name}_param_order'])
+    for it in range(1, 4):
+        W, H, grads = O.betamu_conv_step(V, W, H, beta, l1, l2, ortho, params=order)
+        if it in (1, 3):
+            assert rel_err(W, t(g[f'{case}_W{it}'])) < 2e-6 and rel_err(H, t(g[f'{case}_H{it}'])) < 2e-6
+        if it == 1:
+            for pn in ('W', 'H'):
+                if f'{case}_grad{pn}1' in g.files:
+                    want = t(g[f'{case}_grad{pn}1'])
+                    assert float((grads[pn] - want).abs().max()) < 2e-5 * float(want.abs().max())

@@ -23,6 +23,8 @@ Sets:
   g10_plca       plca.PLCA.fit (EM, plca.py:244-304): plain / Dirichlet priors / frozen Z / frozen W
   g12_betamu_chain  trainer.BetaMu.step on a three-layer nn.Sequential of NMF layers (tests/test_trainer.py:10-32)
   g7_betamu      trainer.BetaMu.step on one NMF layer: every beta x penalties, factors after 1 and 5 steps, p.grad
+  g14_betamu_conv  trainer.BetaMu.step on ONE convolutive layer (NMFD / NMF2D / NMF3D): beta in {0.5, 1, 2} x penalties,
+                 factors after 1 and 3 steps, p.grad of the first step
 """
 import os
 import sys
@@ -410,12 +412,53 @@ def g13():
     np.savez_compressed(os.path.join(OUT, 'g13_plca_tensor_alpha.npz'), **out)
 
 
+def g14():
+    """trainer.BetaMu (trainer.py:35-121) driving one convolutive layer: the backward passes go through conv1d / conv2d / conv3d
+    (nmf.py:776-779, 857-860, 937-940)."""
+    from torchnmf.trainer import BetaMu
+    out = {}
+    cases = {'1d': (ref_nmf.NMFD, (2, 9, 30), 3, (4,)), '2d': (ref_nmf.NMF2D, (1, 4, 14, 12), 3, (3, 2)),
+             '3d': (ref_nmf.NMF3D, (1, 3, 6, 7, 8), 2, (2, 3, 2))}
+    names = []
+    for name, (cls, vshape, R, ks) in cases.items():
+        g = torch.Generator().manual_seed(1014 + len(name) + vshape[-1])
+        V = bf16_round(torch.rand(*vshape, generator=g)) + 2.0 ** -7
+        B, C = vshape[:2]
+        hshape = (B, R) + tuple(l - k + 1 for l, k in zip(vshape[2:], ks))
+        W0 = torch.randn(C, R, *ks, generator=g).abs()
+        H0 = torch.randn(*hshape, generator=g).abs()
+        out[f'{name}_V'], out[f'{name}_W0'], out[f'{name}_H0'] = V.numpy(), W0.numpy(), H0.numpy()
+        for beta in (0.5, 1, 2):
+            for pen, (l1, l2, ortho) in {'plain': (0, 0, 0), 'pen': (1e-3, 1e-3, 1e-2)}.items():
+                m = cls(W=W0.clone(), H=H0.clone())
+                trainer = BetaMu(m.parameters(), beta, l1, l2, ortho)
+
+                def closure():
+                    trainer.zero_grad()
+                    return V, m()
+                key = f'{name}_b{beta}_{pen}'
+                for it in range(1, 4):
+                    trainer.step(closure)
+                    if it in (1, 3):
+                        out[f'{key}_W{it}'] = m.W.detach().numpy().copy()
+                        out[f'{key}_H{it}'] = m.H.detach().numpy().copy()
+                    if it == 1:      # (zero_grad() in the closure drops the earlier parameter's grad: the last one survives)
+                        for pn in ('W', 'H'):
+                            gr = getattr(m, pn).grad
+                            if gr is not None:
+                                out[f'{key}_grad{pn}1'] = gr.detach().numpy().copy()
+                names.append(key)
+        out[f'{name}_param_order'] = np.array([n for n, _ in cls(W=W0.clone(), H=H0.clone()).named_parameters()])
+    out['cases'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'g14_betamu_conv.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # reproducible summation order
     assert torchnmf.__version__ == '0.3.5', torchnmf.__version__
     # `python tools/make_golden.py g13` regenerates only the named sets (round 5 added g13 without touching the others)
-    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13) if len(sys.argv) < 2 or fn.__name__ in sys.argv[1:]]
+    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14) if len(sys.argv) < 2 or fn.__name__ in sys.argv[1:]]
     for fn in todo:
         fn()
         print('wrote', fn.__name__)
