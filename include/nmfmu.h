@@ -141,7 +141,8 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
  * workgroups per CU (the ping-pong and the software-pipelined kernel: one; the four-wave kernel: two where its registers allow) */
 #define NMFMU_KERNEL_FUSED 0 /* nmfmu::fused_kernel, four waves, 128-row tiles (nmfmu_fused.h)                         */
 #define NMFMU_KERNEL_PP 1    /* nmfmu::pp_kernel, eight waves in two half-phases, 256-row tiles (nmfmu_pp.h)            */
-#define NMFMU_KERNEL_SP 2    /* nmfmu::sp_kernel, four waves, software-pipelined across tiles, 128-row tiles (nmfmu_sp.h) */
+#define NMFMU_KERNEL_SP 2    /* nmfmu::sp_kernel / sp2_kernel, four waves, software-pipelined across tiles, 128-row tiles
+                                (nmfmu_sp.h: beta == 1 at padded rank 256; nmfmu_sp2.h: beta != 1, 2 at padded rank 128; fp16) */
 int nmfmu_kernel_family(int r_pad, int precision, float beta);
 int nmfmu_choose_nsplit_for(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int block_rows, int num_cu);
 /* tile height for ONE half-step of this shape (128 where the owner axis alone fills the chip, else nmfmu_block_rows) */

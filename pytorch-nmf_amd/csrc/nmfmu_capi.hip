@@ -12,9 +12,13 @@
 #include "nmfmu_fused.h"
 #include "nmfmu_pp.h"
 #include "nmfmu_sp.h"
+#include "nmfmu_sp2.h"
 
 #ifndef NMFMU_SP
 #define NMFMU_SP 1   // (A/B switch of round 6; 0 = padded rank 256, beta == 1, fp16 stays on the four-wave kernel)
+#endif
+#ifndef NMFMU_SP2
+#define NMFMU_SP2 1  // (A/B switch of round 6; 0 = padded rank 128, beta in {0, 0.5, 1.5, generic}, fp16 stays on the four-wave kernel)
 #endif
 #ifndef NMFMU_FUSE_APPLY_TWO_ACC
 #define NMFMU_FUSE_APPLY_TWO_ACC 1   // (A/B switch of round 3; 0 = beta != 1 always goes through slabs + the apply kernel)
@@ -47,6 +51,12 @@ static bool pp_eligible(int r_pad, int precision, float beta) {
 // padded rank 256 -- the kernel of configs[4]'s shard
 static bool sp_eligible(int r_pad, int precision, float beta) {
   return NMFMU_SP && nmfmu_beta_kind(beta) == NMFMU_BETA_KL && r_pad == 256 && precision == NMFMU_PREC_F16;
+}
+// ... and its two-accumulator sibling (nmfmu_sp2.h): beta != 1 and != 2, fp16 operands and target, padded rank 128 -- the
+// kernel of configs[2]'s beta < 1 legs
+static bool sp2_eligible(int r_pad, int precision, float beta) {
+  const int k = nmfmu_beta_kind(beta);
+  return NMFMU_SP2 && (k == NMFMU_BETA_IS || k == NMFMU_BETA_GEN) && r_pad == 128 && precision == NMFMU_PREC_F16;
 }
 // beta -> kernel branch (nmfmu_fused.h: BetaKind): the public kinds plus the two rsqrt special cases of the generic one
 static int kernel_beta_kind(float beta) {
@@ -147,6 +157,10 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
 #endif
     return launch_sp(st->r_pad, kOpF16, a, grid, s);
   }
+  if (mode == kModeMU && sp2_eligible(st->r_pad, st->precision, st->beta)) {
+    a.tiles_per_split = (a.tiles_per_split + 3) & ~3;
+    return launch_sp2(st->r_pad, kernel_beta_kind(st->beta), a, grid, s);
+  }
   const int kk = kernel_beta_kind(st->beta);
 #ifdef NMFMU_DEBUG_HOOKS
   a.debug = mode == kModeXB ? g_pp_debug : nullptr;   // per-workgroup phase stamps of the streaming kernel (tools/xb_timeline.py)
@@ -214,13 +228,13 @@ int nmfmu_choose_nsplit(int owner_rows_pad, int panel_rows_pad, int block_rows, 
 
 int nmfmu_kernel_family(int r_pad, int precision, float beta) {
   if (pp_eligible(r_pad, precision, beta)) return NMFMU_KERNEL_PP;
-  if (sp_eligible(r_pad, precision, beta)) return NMFMU_KERNEL_SP;
+  if (sp_eligible(r_pad, precision, beta) || sp2_eligible(r_pad, precision, beta)) return NMFMU_KERNEL_SP;
   return NMFMU_KERNEL_FUSED;
 }
 
 int nmfmu_choose_nsplit_for(int owner_rows_pad, int panel_rows_pad, int r_pad, int precision, float beta, int block_rows, int num_cu) {
   if (owner_rows_pad <= 0 || panel_rows_pad <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
-  if (block_rows == 128 && sp_eligible(r_pad, precision, beta)) {
+  if (block_rows == 128 && (sp_eligible(r_pad, precision, beta) || sp2_eligible(r_pad, precision, beta))) {
     // one 512-register workgroup per CU: as many splits as fill the chip ONCE (whole rounds when the row blocks alone
     // exceed it), each a multiple of four tiles
     const int mblocks = owner_rows_pad / 128, ktiles = panel_rows_pad / kBK;

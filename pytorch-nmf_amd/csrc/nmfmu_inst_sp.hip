@@ -10,4 +10,14 @@ int launch_sp(int r_pad, int opt, const FusedArgs& a, int grid, hipStream_t s) {
   return -2;
 }
 
+int launch_sp2_a(int beta_kind, const FusedArgs& a, int grid, hipStream_t s);   // nmfmu_inst_sp2a.hip: kIS, kSqrt
+int launch_sp2_b(int beta_kind, const FusedArgs& a, int grid, hipStream_t s);   // nmfmu_inst_sp2b.hip: kSqrt3, kGen
+
+int launch_sp2(int r_pad, int beta_kind, const FusedArgs& a, int grid, hipStream_t s) {
+  if (r_pad != 128) return -2;
+  if (beta_kind == kIS || beta_kind == kSqrt) return launch_sp2_a(beta_kind, a, grid, s);
+  if (beta_kind == kSqrt3 || beta_kind == kGen) return launch_sp2_b(beta_kind, a, grid, s);
+  return -2;
+}
+
 }  // namespace nmfmu

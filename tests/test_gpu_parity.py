@@ -2290,6 +2290,46 @@ def test_cfg5_full_shard_two_iterations(dev):
     assert rel_err(eng.fW.colsum[:R].cpu().double(), W.double().sum(0).cpu()) < 1e-5
 
 
+@pytest.mark.parametrize('beta', [0.0, 0.5, 1.5, 0.3, 3.0, -1.0])
+@pytest.mark.parametrize('N,C,nsplit,regs', [(300, 200, None, (0.0, 0.0)),      # 4 tiles: the last group alone; ragged rows
+                                              (130, 500, None, (0.0, 0.0)),      # 8 tiles: one pass of the loop + the last group
+                                              (600, 1000, 1, (0.1, 0.5)),        # 16 tiles unsplit: fused apply, regularised
+                                              (260, 2100, 5, (0.0, 0.0)),        # 36 tiles in splits of 8: the last split holds 4
+                                              (1100, 300, 8, (0.0, 0.0))])       # more splits than groups: empty workgroups
+def test_rank128_two_accumulator_software_pipelined_kernel(dev, monkeypatch, beta, N, C, nsplit, regs):
+    """nmfmu::sp2_kernel (round 6: padded rank 128, beta not in {1, 2}, fp16 -- the kernel of configs[2]'s beta < 1 legs) over
+    its control flow -- one / several four-tile groups, the last group's shorter final iteration, contraction splits with
+    short and empty workgroups, both epilogues -- for every elementwise branch: beta = 0 (reciprocal), 0.5 and 1.5 (rsqrt),
+    and the generic log / exp branch on both sides of the scaled range (0.3, 3, -1).  Two iterations against the oracle.  The
+    tolerance is what fp16 operands give on contractions this short; the parity bar itself is held at
+    configs[2]'s own lengths by test_cfg2_full_size_*."""
+    from oracle import mu_oracle as O
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import DenseMU
+    R = 100 if N != 600 else 128
+    g = torch.Generator().manual_seed(N + C)
+    V = torch.rand(N, C, generator=g).bfloat16().float() + 2.0 ** -7
+    W0 = torch.randn(C, R, generator=g).abs() + 0.05
+    H0 = torch.randn(N, R, generator=g).abs() + 0.05
+    if nsplit is not None:
+        monkeypatch.setenv('TORCHNMF_AMD_NSPLIT', str(nsplit))
+    alpha, l1r = regs
+    gam = O.gamma_of(beta)
+    W, H = W0.clone().to(dev), H0.clone().to(dev)
+    eng = DenseMU(V.to(dev), W, H, beta, alpha * l1r, alpha * (1 - l1r), precision='f16')
+    assert eng.r_pad == 128 and eng.be.kernel_family(128, _capi.PREC_F16, float(beta)) == _capi.KERNEL_SP
+    Wr, Hr = W0, H0
+    for _ in range(2):
+        eng.w_step()
+        eng.h_step()
+        Wr = O.nmf_w_step(V, Wr, Hr, beta, gam, alpha * l1r, alpha * (1 - l1r))
+        Hr = O.nmf_h_step(V, Wr, Hr, beta, gam, alpha * l1r, alpha * (1 - l1r))
+    torch.cuda.synchronize()
+    ew, eh = rel_err(W.cpu(), Wr), rel_err(H.cpu(), Hr)
+    record('rank128_sp2_kernel', beta=beta, N=N, C=C, nsplit=(eng.step_w.nsplit, eng.step_h.nsplit), regs=regs, relW=ew, relH=eh)
+    assert ew < 6e-4 and eh < 6e-4, (ew, eh)
+
+
 def test_auto_precision_policy(dev, monkeypatch):
     """'auto' = the fastest mode that meets the 1e-4 bar, never plain bf16: fp16 operands where both dimensions are
     >= 4096, the target is exactly representable in fp16 and the data sit inside fp16's range; split bf16 otherwise

@@ -409,3 +409,84 @@ def test_sp_kernel_stream_tables():
                 g1_half ^= 1
             else:
                 g2_half ^= 1
+
+
+# ---- the two-accumulator software-pipelined kernel (csrc/nmfmu_sp2.h): the plan of its elementwise stage -----------------
+def _sp2_plan(gops, cap, alt, g0=3):
+    """SP2Plan of nmfmu_sp2.h, restated: (n_head, gap of every instruction)."""
+    ne = 8 * gops
+    gap, k = [0] * ne, 0
+    for g in range(g0, 32):
+        c_max = cap + (1 if (alt and g % 2 == 0) else 0)
+        c = 0
+        while c < c_max and k < ne:
+            grp, pos = divmod(k, gops)
+            if pos >= gops - 4 and g < 8 * (grp >> 1) + 8:
+                break
+            gap[k] = g
+            k += 1
+            c += 1
+    n_head = k
+    nq = ne - n_head
+    for i in range(nq):
+        gap[n_head + i] = (i * 16) // max(nq, 1)
+    return n_head, gap
+
+
+@pytest.mark.parametrize('name,gops,cap,alt', [('beta=0', 20, 4, False), ('beta=0.5', 24, 4, True), ('beta=1.5', 16, 3, False),
+                                               ('generic', 28, 5, False)])
+def test_sp2_kernel_elementwise_plan(name, gops, cap, alt):
+    """nmfmu::sp2_kernel keeps the packed GEMM2 operands gn / gp SINGLE-buffered: the elementwise stage of tile t+1 runs its
+    first part in the MFMA gaps of GEMM2(t) and overwrites the words that GEMM2 is still reading.  Replay of the compile-time
+    plan against the rule that makes this legal: GEMM2 entry j (MFMAs 2j, 2j+1; (tt, m2) = j // 4) reads the words the
+    conversions of groups 2 (j // 4) and 2 (j // 4) + 1 write, so such a conversion placed in P' gap g (= behind MFMA g) must
+    come behind MFMA 8 c4 + 7 with one more MFMA in between (g >= 8 c4 + 8).  Also: every instruction is placed exactly
+    once and in order, the head fits P' (gaps 3 .. 31: the S tile it reads was finished by GEMM1 five MFMAs earlier), the
+    tail fits the 16 gaps of Q', and no gap carries more than the issue budget of its phase."""
+    n_head, gap = _sp2_plan(gops, cap, alt)
+    ne = 8 * gops
+    assert 0 < n_head < ne
+    head, tail = gap[:n_head], gap[n_head:]
+    assert head == sorted(head) and tail == sorted(tail) and min(head) >= 3 and max(head) <= 31
+    assert min(tail) == 0 and max(tail) <= 15
+    for k in range(n_head):
+        grp, pos = divmod(k, gops)
+        if pos >= gops - 4:                      # a conversion in P': writes words of GEMM2 entries 4 c4 .. 4 c4 + 3
+            assert gap[k] >= 8 * (grp >> 1) + 8, (name, k, gap[k])
+    per_gap = [head.count(g) for g in range(32)]
+    assert max(per_gap) <= cap + (1 if alt else 0)
+    per_q = [tail.count(g) for g in range(16)]
+    assert max(per_q) - min(per_q) <= 1          # spread evenly
+    # a group's conversions come last in it, and its transcendental is never consumed by the instruction right behind it
+    # (four elements per stage: the consumer of element i's result sits four instructions later)
+    assert gops % 4 == 0
+
+
+def test_sp2_kernel_address_registers():
+    """Padded rank 128 (16 sixteen-byte slots per row): ga[kk] / gb[2 m2 + h][rt] + immediates reproduce the four-wave kernel's
+    LDS addresses in every slot of the 4 x 16 KiB ring, and every immediate fits 16 bits (no address upkeep in the loop)."""
+    r_pad, rowb, img = 128, 256, 64 * 256
+    for lane in range(64):
+        j, hl = lane & 31, lane >> 5
+        row0 = 32 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3)
+        sw0 = p1_swz(row0, r_pad)
+        ga = [row0 * rowb + (((2 * v + hl) ^ sw0) << 4) for v in range(8)]
+        grp, s16 = lane >> 4, lane & 15
+        cslot, lr = 2 * (grp & 1) + ((s16 & 3) >> 1), (s16 >> 2) & 3
+        gb = [[(32 * (grp >> 1) + (s16 >> 2)) * rowb + (((cslot ^ c) | ((lr ^ p) << 2)) << 4) + 8 * (s16 & 1) for p in range(4)]
+              for c in range(4)]
+        for slot in range(4):
+            for tt in range(2):
+                for kk in range(8):
+                    imm = tt * 16 * rowb + slot * img
+                    assert 0 <= imm < 65536
+                    row = 32 * ((j >> 2) & 1) + 16 * tt + (j & 3) + 4 * (j >> 3)
+                    assert ga[kk] + imm == slot * img + row * rowb + ((kk * 32 + hl * 16) ^ (p1_swz(row, r_pad) << 4))
+                for m2 in range(2):
+                    for h in range(2):
+                        for rt in range(4):
+                            imm = (16 * tt + 8 * m2 + 4 * h) * rowb + slot * img
+                            assert 0 <= imm < 65536
+                            row = 32 * (grp >> 1) + 16 * tt + 8 * m2 + 4 * h + (s16 >> 2)
+                            base = row * rowb + ((cslot ^ p1_swz(row, r_pad)) << 4) + 8 * (s16 & 1)
+                            assert gb[2 * m2 + h][rt] + imm == slot * img + (base ^ (rt * 64))
