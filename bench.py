@@ -70,7 +70,7 @@ def parse():
     ap.add_argument('--no-sweep', action='store_true', help='skip the beta_sweep (configs[2]) and nmfd (configs[3]) sub-objects '
                     'of the default run')
     ap.add_argument('--beta', type=float, default=1.0)
-    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16', 'f16x', 'auto'],
+    ap.add_argument('--precision', default=None, choices=['bf16', 'bf16x3', 'f16', 'f16x', 'f16r', 'auto'],
                     help="operand type of the headline leg: 'f16' (default: fp16 operands, bf16's MFMA rate, meets the 1e-4 "
                          "parity bar; nmf and nmfd workloads), 'bf16' (the type configs[1] names; factors ~2e-4 after 3 "
                          "iterations; default of the other workloads), 'bf16x3'")
@@ -746,7 +746,7 @@ def dense_leg(a, V, W0, H0, beta, precision, group, world, dev, want_roofline, b
         all_ms = spans.get('w', []) + spans.get('h', [])
         avg_ms = sum(all_ms) / len(all_ms)
         flops_per_launch = flops_per_iter_gpu / 2.0                    # one half-step = 2 (3) contractions
-        elt = 4 if eng.precision_name in ('bf16x3', 'f16x') else 2
+        elt = {'bf16x3': 4, 'f16x': 4, 'f16r': 3}.get(eng.precision_name, 2)
         bytes_per_launch = N * C * elt + 1.5 * (C * R + N * R) * 4    # one read of V + half the factor traffic
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         # which kernel ran (include/nmfmu.h: NMFMU_KERNEL_*): the ping-pong kernel, the software-pipelined rank-256 kernel
@@ -1046,9 +1046,12 @@ def ref_notebook_leg(a, dev, do_cpu):
     return out
 
 
-DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)', 'f16x': 'f16 operands, f32 target'}
+DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)', 'f16x': 'f16 operands, f32 target',
+              'f16r': 'f16 operands, 3-byte target (f16 head + 8-bit relative residual)'}
 DTYPE_LONG = {'f16': 'f16 operands and target / fp32 accumulate (same MFMA rate as bf16; meets the 1e-4 parity bar)',
               'f16x': 'f16 operands, fp32 target / fp32 accumulate (1x MFMA work, twice the V stream; for targets fp16 does not hold exactly)',
+              'f16r': 'f16 operands, 3-byte target (fp16 head rounded toward zero + one byte u: x ~ h (1 + u 2^-18), 19 significant bits) / '
+                      'fp32 accumulate (1x MFMA work, 1.5x the V stream; what auto takes for targets fp16 does not hold exactly, beta != 2)',
               'bf16': 'bf16 operands and target / fp32 accumulate (the type configs[1] names; factors ~2e-4 after 3 iterations)',
               'bf16x3': 'split bf16 (3 MFMAs per product, fp32 target): fp32-grade'}
 
@@ -1280,7 +1283,8 @@ def main():
         gr = torch.Generator(device=dev).manual_seed(4000)
         Vr = torch.rand(N, C, device=dev, generator=gr)             # plain fp32 U[0,1): fp16 would round it
         be = head['eng'].be
-        picks = DenseMU.auto_single_plane(Vr, W0, H0, be.pad_rank(R), be) or 'bf16x3'
+        # what fit()'s 'auto' resolves to on this target: ask an engine (one admission test; 'f16r' since round 6)
+        picks = DenseMU(Vr, W0.clone(), H0.clone(), beta, precision='auto', allow_f16=True).precision_name
         leg = dense_leg(a, Vr, W0, H0, beta, picks, None, 1, dev, True, blocks_min=3)
         rf = leg['roofline']
         real = {'target': 'plain fp32 U[0,1) (not exactly representable in fp16)', 'auto_picks': picks, 'dtype': DTYPE_LONG[picks],

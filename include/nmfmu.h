@@ -49,7 +49,8 @@ extern "C" {
                                   nmfmu_gemm_window_staged); nmfmu_conv_apply_pack_w_wk / nmfmu_conv_apply_h_rows_sums / nmfmu_conv_h_rows_parts;
                                9: nmfmu_kernel_family / nmfmu_choose_nsplit_for (round 6: beta == 1 at padded rank 256 with fp16 operands runs the
                                   software-pipelined one-wave-per-SIMD kernel, ONE workgroup per CU -- the split must know the kernel);
-                                  nmfmu_step.stamps (in-kernel clock stamps in the product build); nmfmu_ubench_mfma_hbm2 */
+                                  nmfmu_step.stamps (in-kernel clock stamps in the product build); nmfmu_ubench_mfma_hbm2;
+                                  NMFMU_PREC_F16R (3-byte target) */
 
 #define NMFMU_OK 0
 #define NMFMU_ERR_UNSUPPORTED (-2) /* rank / precision / beta combination not built */
@@ -67,6 +68,9 @@ extern "C" {
                                (nmf.py:65 is where X enters; it stays in fp32 VALU arithmetic, for beta == 2 it is an fp16
                                hi + lo operand pair), so the mode is parity-grade on targets fp16 does not hold exactly, at 1x
                                MFMA work and twice the X stream.  Four-wave kernel, every beta, padded rank <= 256 */
+#define NMFMU_PREC_F16R 4   /* (ABI 9) as F16X at THREE bytes per element of X: an fp16 head h <= x (rounded toward zero) plus one byte
+                               u, x ~ h (1 + u 2^-18): 19 significant bits with a uniform relative step -- what 'auto' takes for a
+                               target fp16 does not hold exactly.  Four-wave kernel, every beta but 2, padded rank <= 256 */
 
 /* beta branches of nmf.py:61-74 / metrics.py:78-96 */
 #define NMFMU_BETA_KL 0  /* beta == 1 */

@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
                                                      void* __restrict__ xp, int ktiles, int64_t nchunks,
                                                      uint32_t* flags, int G) {
   constexpr bool FP32 = FMT == 1;
-  constexpr int NQ = FP32 ? 8 : 4;
+  constexpr bool F16R = FMT == 3;   // fp16 head (rounded toward zero) in chunks 0..3 + one residual byte per element in chunks 4, 5
+  constexpr int NQ = FP32 ? 8 : (F16R ? 6 : 4);
   constexpr int EPC = FP32 ? 4 : 8;
   const int M = TRANSPOSE ? cols : rows;  // owner axis length
   const int K = TRANSPOSE ? rows : cols;
@@ -36,6 +37,27 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
     const int64_t kt = r % ktiles;
     const int64_t mb = r / ktiles;
     const int64_t m = mb * (128 * G) + w * (32 * G) + g * 32 + (lane & 31);
+    if constexpr (F16R) {
+      if (q >= 4) {
+        // residual bytes of elements 16 (q - 4) .. + 15 of this lane's 32 columns: u = round((x / h - 1) 2^18) with h the fp16
+        // head rounded toward zero (x >= 0), so that x ~ h (1 + u 2^-18) with a relative step of 2^-19
+        u32x4 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t k = kt * 64 + 32 * (lane >> 5) + 16 * (q - 4) + i;
+          float x = 0.f;
+          if (m < M && k < K) x = TRANSPOSE ? v[k * ld + m] : v[m * ld + k];
+          x = fminf(fmaxf(x, 0.f), 65504.f);
+          _Float16 h = (_Float16)x;
+          if ((float)h > x) h = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, h) - 1));
+          const float hf = (float)h;
+          const float u = hf > 0.f ? fminf(rintf((x / hf - 1.f) * 262144.f), 255.f) : 0.f;
+          o[i >> 2] |= (uint32_t)u << (8 * (i & 3));
+        }
+        reinterpret_cast<u32x4*>(xp)[c] = o;
+        continue;    // (validation flags are taken by the head chunks, which see every element once)
+      }
+    }
     const int64_t k0 = kt * 64 + 32 * (lane >> 5) + (int64_t)q * EPC;
     float e[EPC];
 #pragma unroll
@@ -53,6 +75,20 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
     if constexpr (FP32) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(uint32_t, e[i]);
+    } else if constexpr (F16R) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t wv = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const float x = fminf(fmaxf(e[2 * i + hh], 0.f), 65504.f);
+          _Float16 h = (_Float16)x;
+          unsigned short hb = __builtin_bit_cast(unsigned short, h);
+          if ((float)h > x) hb -= 1;          // toward zero: the residual byte then only ever adds
+          wv |= (uint32_t)hb << (16 * hh);
+        }
+        o[i] = wv;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = pack_img(e[2 * i], e[2 * i + 1], FMT == 2);
@@ -76,10 +112,12 @@ int launch_pack_x(const float* v, int64_t ld, int rows, int cols, bool transpose
                   int k_pad, uint32_t* flags, int G, hipStream_t s) {
   const bool fp32 = fmt == 1;
   const int ktiles = k_pad / kBK;
-  const int64_t nchunks = (int64_t)m_pad * k_pad * (fp32 ? 4 : 2) / 16;
+  const int64_t nchunks = (int64_t)m_pad * k_pad * (fp32 ? 4 : (fmt == 3 ? 3 : 2)) / 16;
   const int grid = (int)std::min<int64_t>((nchunks + 255) / 256, 256 * 32);
 #define L(F, T) hipLaunchKernelGGL((pack_x_kernel<F, T>), dim3(grid), dim3(256), 0, s, v, ld, rows, cols, xp, ktiles, nchunks, flags, G)
-  if (fp32 && transpose) L(1, true);
+  if (fmt == 3 && transpose) L(3, true);
+  else if (fmt == 3) L(3, false);
+  else if (fp32 && transpose) L(1, true);
   else if (fp32) L(1, false);
   else if (fmt == 2 && transpose) L(2, true);
   else if (fmt == 2) L(2, false);

@@ -29,7 +29,9 @@ using namespace nmfmu;
 namespace {
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline bool is_f16(int precision) { return precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_F16X; }   // fp16 operand images
+inline bool is_f16(int precision) {   // fp16 operand images
+  return precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_F16X || precision == NMFMU_PREC_F16R;
+}
 inline bool x_is_f32(int precision) { return precision == NMFMU_PREC_BF16X3 || precision == NMFMU_PREC_F16X; }
 
 // Diagnostic builds only (make EXTRA=-DNMFMU_DEBUG_HOOKS): NMFMU_FORCE_NSPLIT overrides the contraction split and
@@ -88,6 +90,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   const bool x3 = st->precision == NMFMU_PREC_BF16X3;
   if (x3 && (!st->owner.p1_lo || !st->panel.p1_lo)) return NMFMU_ERR_ARG;
   const int kind = nmfmu_beta_kind(st->beta);
+  if (st->precision == NMFMU_PREC_F16R && kind == NMFMU_BETA_EUC) return NMFMU_ERR_UNSUPPORTED;   // the target is an operand there: F16X
   FusedArgs a{};
   a.xp = st->xp;
   a.p1_hi = static_cast<const uint16_t*>(st->panel.p1_hi);
@@ -201,6 +204,7 @@ int nmfmu_supported(int r_pad, int precision) {
   if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
   if (precision == NMFMU_PREC_F16) return 1;                // ping-pong kernel (beta == 1, r_pad <= 128), else four-wave
   if (precision == NMFMU_PREC_F16X) return 1;               // four-wave kernel: fp16 operands, fp32 target
+  if (precision == NMFMU_PREC_F16R) return 1;               // four-wave kernel: fp16 operands, 3-byte target (beta != 2)
   return 0;
 }
 
@@ -253,7 +257,7 @@ int nmfmu_step_block_rows(int owner_rows_pad, int panel_rows_pad, int r_pad, int
 }
 
 size_t nmfmu_xp_bytes(int owner_rows_pad, int panel_rows_pad, int precision) {
-  return (size_t)owner_rows_pad * (size_t)panel_rows_pad * (x_is_f32(precision) ? 4 : 2);
+  return (size_t)owner_rows_pad * (size_t)panel_rows_pad * (x_is_f32(precision) ? 4 : (precision == NMFMU_PREC_F16R ? 3 : 2));
 }
 size_t nmfmu_image_bytes(int rows_pad, int r_pad) { return (size_t)rows_pad * (size_t)r_pad * 2; }
 size_t nmfmu_slab_bytes(int owner_rows_pad, int r_pad, int nsplit) {
@@ -266,7 +270,7 @@ int nmfmu_pack_x(const float* v, int64_t ld, int rows, int cols, int transpose, 
   if (!v || !xp || rows <= 0 || cols <= 0 || (block_rows != 128 && block_rows != 256)) return NMFMU_ERR_ARG;
   const int m = transpose ? cols : rows, k = transpose ? rows : cols;
   if (owner_rows_pad != pad_rows(m) || panel_rows_pad != pad_rows(k)) return NMFMU_ERR_ARG;
-  const int fmt = x_is_f32(precision) ? 1 : (precision == NMFMU_PREC_F16 ? 2 : 0);
+  const int fmt = x_is_f32(precision) ? 1 : (precision == NMFMU_PREC_F16 ? 2 : (precision == NMFMU_PREC_F16R ? 3 : 0));
   return launch_pack_x(v, ld, rows, cols, transpose != 0, fmt, xp, owner_rows_pad, panel_rows_pad, flags,
                        block_rows / 128, S(stream));
 }

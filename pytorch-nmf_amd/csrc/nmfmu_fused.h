@@ -31,6 +31,10 @@
 //            saturate at 65504.  For beta < 1 the elementwise terms are negative powers of S and can sit at the
 //            bottom of fp16's range, so Gn and Gp are multiplied by a power of two derived from the factors' column
 //            sums (identical in every workgroup) before the conversion; the epilogue scales the accumulators back.
+//   f16r   : (round 6) as f16x at THREE bytes per element of X: an fp16 head h <= x (rounded toward zero) plus one byte u with
+//            x ~ h (1 + u 2^-18) -- 19 significant bits, a uniform RELATIVE step, so no per-tile scale.  The ratio stage
+//            multiplies its x-independent factor by (1 + u 2^-18) (two VALU per element) before the mixed multiply by h.
+//            beta != 2 (there the target is an MFMA operand itself: 'f16x' keeps its hi + lo pair).
 //   f16x   : fp16 operands as above, but X stays fp32 in HBM (round 4) -- the target is never rounded, so the mode is
 //            parity-grade on data fp16 does not hold exactly (STFT magnitudes, plain floats) at 1x MFMA work; the X
 //            stream doubles (HBM-bound: 1.07 GB per half-step at configs[1]).  The ratio is formed in fp32 from the
@@ -80,7 +84,7 @@ enum BetaKind : int { kKL = 0, kEuc = 1, kIS = 2, kGen = 3, kSqrt = 4, kSqrt3 = 
 // kModeMU2: kModeMU for a SPLIT panel -- the row-major image (first GEMM) and the transposed image (second GEMM) hold
 // different matrices (PLCA: the Z-scaled factor and the unscaled one), so both are staged (no FusedCfg::TR).
 enum FusedMode : int { kModeMU = 0, kModeLoss = 1, kModeDen = 2, kModeXB = 3, kModeMU2 = 4 };
-enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2, kPrecF16X = 3 };   // = NMFMU_PREC_* of include/nmfmu.h
+enum Precision : int { kPrecBf16 = 0, kPrecX3 = 1, kPrecF16 = 2, kPrecF16X = 3, kPrecF16R = 4 };   // = NMFMU_PREC_* of include/nmfmu.h
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -141,7 +145,8 @@ struct FusedArgs {
 template <int R_PAD, int BETA, int PREC, int MODE>
 struct FusedCfg {
   static constexpr bool X3 = PREC == kPrecX3;                           // two operand planes (hi / lo)
-  static constexpr bool F16 = PREC == kPrecF16 || PREC == kPrecF16X;   // fp16 operand type
+  static constexpr bool F16 = PREC == kPrecF16 || PREC == kPrecF16X || PREC == kPrecF16R;   // fp16 operand type
+  static constexpr bool XR = PREC == kPrecF16R;                        // X = fp16 head + 8-bit relative residual (3 bytes per element)
   static constexpr bool XF32 = X3 || PREC == kPrecF16X;                // X stored fp32 (fragment order, 8 chunks per lane)
   static constexpr int BM = 128, WAVES = 4, THREADS = 256;
   static constexpr int KS = R_PAD / 16;      // k-steps of GEMM1 (contraction over rank)
@@ -166,7 +171,7 @@ struct FusedCfg {
   static constexpr int P2HI = XB ? 0 : NPL * IMG;
   static constexpr int P2LO = P2HI + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  static constexpr int NQ = XF32 ? 8 : 4;    // 16-byte X chunks per lane per tile
+  static constexpr int NQ = XF32 ? 8 : (XR ? 6 : 4);    // 16-byte X chunks per lane per tile (f16r: 4 of heads + 2 of residual bytes)
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
   // fp32 target as an fp16 MFMA operand (f16x, beta = 2: Gn = X): hi + lo pair, two MFMAs for the numerator product
   static constexpr bool XSPLIT = PREC == kPrecF16X && BETA == kEuc && !LOSS && !DEN;   // (kModeXB included)
@@ -640,6 +645,15 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       x1 = unpack_hi<OPT>(w);
     }
     const float s0 = stt[2 * d], s1 = stt[2 * d + 1];
+    float f0 = 1.f, f1 = 1.f;   // f16r: x = head * (1 + u 2^-18), u = byte (16 tt + 2 d) of this lane's 32 residual bytes
+    if constexpr (C::XR) {
+      const uint32_t uw = x[4 + tt][d >> 1];
+      const float u0 = (float)((uw >> (16 * (d & 1))) & 0xffu);         // (hipcc selects v_cvt_f32_ubyte0 .. 3)
+      const float u1 = (float)((uw >> (16 * (d & 1) + 8)) & 0xffu);
+      f0 = __builtin_fmaf(u0, 3.814697265625e-06f, 1.f);
+      f1 = __builtin_fmaf(u1, 3.814697265625e-06f, 1.f);
+      if constexpr (C::LOSS) x0 *= f0, x1 *= f1;
+    }
     if constexpr (C::LOSS) {
       constexpr int LB = (BETA == kSqrt || BETA == kSqrt3) ? (int)kGen : BETA;
       const int k0 = t * kBK + 32 * hl + 16 * tt + 2 * d;
@@ -666,6 +680,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         mu_elem<BETA>(s1, xb, a.beta, n1, p1);
       }
 #endif
+      if constexpr (C::XR) n0 *= f0, n1 *= f1;
       if constexpr (MIX) {
         const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
         float m0, m1;
@@ -1202,6 +1217,10 @@ int launch_fused_dispatch(int beta_kind, int prec, int mode, const FusedArgs& a,
   NMFMU_CASE_LOSS(kPrecF16)
   NMFMU_CASE_MU(kPrecF16X)
   NMFMU_CASE_LOSS(kPrecF16X)
+  // f16r (3-byte target): every beta but 2 (whose target is an MFMA operand: 'f16x')
+  NMFMU_CASE(kKL, kPrecF16R, kModeMU) NMFMU_CASE(kIS, kPrecF16R, kModeMU) NMFMU_CASE(kGen, kPrecF16R, kModeMU)
+  NMFMU_CASE(kSqrt, kPrecF16R, kModeMU) NMFMU_CASE(kSqrt3, kPrecF16R, kModeMU)
+  NMFMU_CASE(kKL, kPrecF16R, kModeLoss) NMFMU_CASE(kIS, kPrecF16R, kModeLoss) NMFMU_CASE(kGen, kPrecF16R, kModeLoss)
   NMFMU_CASE(kGen, kPrecBf16, kModeDen)
   NMFMU_CASE(kKL, kPrecBf16, kModeMU2) NMFMU_CASE(kKL, kPrecF16, kModeMU2)
   NMFMU_CASE(kEuc, kPrecBf16, kModeXB) NMFMU_CASE(kEuc, kPrecF16, kModeXB)

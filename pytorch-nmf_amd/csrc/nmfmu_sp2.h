@@ -10,12 +10,11 @@
 //
 //   Q'(t): 16 MFMAs of GEMM1(t+1) -> S[(t+1) & 1]              fillers: their 16 ds_read_b128, the LAST third of the
 //                                                                elementwise stage of tile t
-//          s_waitcnt vmcnt(4)                                    (X(t+1) has landed)
+//          s_waitcnt vmcnt(0); s_barrier                         (X(t+1) and panel tile t+2 have landed and are visible)
 //   P'(t): 32 MFMAs of GEMM2(t): num += gn x P1^T, den += gp x P1^T (each transposed panel fragment feeds both)
 //                                                                fillers: 32 ds_read_b64_tr_b16, the FIRST two thirds of
 //                                                                the elementwise stage of tile t+1, the X loads of tile
 //                                                                t+2, the LDS-DMA of panel tile t+3
-//          s_waitcnt vmcnt(8); s_barrier                         (panel tile t+2 has landed and is visible)
 //
 // The packed operands gn / gp are SINGLE-buffered: the elementwise stage of tile t+1 overwrites a word only after the
 // last MFMA of GEMM2(t) that reads it has issued (GEMM2 consumes the words in the order the stage produces them; the
@@ -369,10 +368,17 @@ __global__ void __launch_bounds__(256, 1) sp2_kernel(const FusedArgs a) {
           }
           ratio_gap(std::false_type{}, K{}, std::integral_constant<int, e.it & 1>{});
           if constexpr (e.k == N1 - 1) {
-            // X(i0+it+1) has landed (the head of its elementwise stage starts below): this wave's 4 youngest loads -- the
-            // panel pieces of tile i0+it+2 -- may stay in flight
+            // Everything P'(it-1) issued -- X(i0+it+1), whose elementwise stage starts below, and the panel pieces of tile
+            // i0+it+2 -- has landed, and after the barrier every wave's pieces are visible: the first reads of that slot are
+            // the operand prefetch in the tail of P'(it), and the LDS-DMA of P'(it) overwrites the slot every wave finished
+            // reading in P'(it-1).  vmcnt(0), not a counted wait: the first build left "the 4 youngest" (the LDS-DMA pieces) in
+            // flight behind the X loads -- and ran non-deterministic: LDS-DMA pieces (L2 hits) complete BEFORE older register
+            // loads (HBM), so a count says nothing about which loads are still out (tools/sp_bitcompare.py against itself;
+            // the drain costs nothing measurable).  The barrier sits HERE and not behind P': the prefetch for Q'(it+1) is
+            // issued four entries before P' ends.
             u32x4(&xn)[4] = xb[(e.it + 1) & 1];
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+            barrier();
           }
         } else {
           // ---- P'(it): GEMM2 of tile i0+it, numerator and denominator from the same panel fragment; head of the
@@ -392,11 +398,6 @@ __global__ void __launch_bounds__(256, 1) sp2_kernel(const FusedArgs a) {
           if constexpr (!final_it) {
             if constexpr (e.k < 2) load_x1(xs, xb[e.it & 1], std::integral_constant<int, 2 * e.k + 1>{});
             ratio_gap(std::true_type{}, GapD{}, SBN{});
-            if constexpr (e.k == N2 - 1) {
-              // the panel pieces of tile i0+it+2 (issued a tile ago) have landed: at most this iteration's 4 X loads + 4 pieces stay in flight
-              asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-              barrier();
-            }
           }
         }
       });

@@ -18,12 +18,12 @@ OK = 0
 ERR_UNSUPPORTED = -2
 ERR_ARG = -3
 ERR_ALLOC = -4
-PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16X = 0, 1, 2, 3
+PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16X, PREC_F16R = 0, 1, 2, 3, 4
 STAGE_REG, STAGE_DMA, STAGE_DMA_SPLIT = 0, 1, 2
 BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
 KERNEL_FUSED, KERNEL_PP, KERNEL_SP = 0, 1, 2
 
-PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16, 'f16x': PREC_F16X}
+PRECISIONS = {'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3, 'f16': PREC_F16, 'f16x': PREC_F16X, 'f16r': PREC_F16R}
 
 
 class NmfmuError(RuntimeError):

@@ -381,6 +381,7 @@ class DenseMU(AsyncLossMixin):
     #    grows with the iteration count towards the perturbed fixed point (3e-4 after 200 iterations at any size);
     #  * data inside fp16's range with room for the ratios.
     F16_MIN_DIM = 4096
+    _F16_MODES = (_capi.PREC_F16, _capi.PREC_F16X, _capi.PREC_F16R)     # fp16 operand images (range watch applies)
     F16_MAX_ABS = 3.0e4
     F16_MIN_MEAN = 2.0 ** -10
 
@@ -436,6 +437,18 @@ class DenseMU(AsyncLossMixin):
                 level = 0
         return {2: 'f16', 1: 'f16x', 0: None}[level]
 
+    @classmethod
+    def auto_mode(cls, V, W, H, r_pad, be, beta, group=None) -> Optional[str]:
+        """``auto_single_plane`` with the 3-byte target (round 6): a target fp16 does not hold exactly runs as 'f16r' -- fp16
+        head + 8-bit relative residual, 19 significant bits, 25 % fewer bytes of V per iteration than 'f16x', nothing rounded
+        that the parity bar can see -- except for beta == 2, where the target is an MFMA operand itself and stays fp32
+        ('f16x').  Rank-invariant like its input (same library and environment on every rank)."""
+        mode = cls.auto_single_plane(V, W, H, r_pad, be, group)
+        if (mode == 'f16x' and float(beta) != 2.0 and hasattr(_capi, 'PREC_F16R') and be.supported(r_pad, _capi.PREC_F16R)
+                and os.environ.get('TORCHNMF_AMD_AUTO_F16R', '1') != '0'):
+            mode = 'f16r'
+        return mode
+
     def __init__(self, V, W, H, beta, l1=0.0, l2=0.0, precision='auto', stage=None, group=None, backend=None,
                  update_W=True, update_H=True, block_rows=None, allow_f16=False, ar_overlap=None, allow_gram=False,
                  ar_direct=None):
@@ -455,7 +468,7 @@ class DenseMU(AsyncLossMixin):
             # fp16 operands (1x MFMA work) where the contraction lengths average the rounding errors down and the data
             # fit fp16's range (sharded: every rank must decide alike, so the range test is all-reduced), else split
             # bf16 (3x MFMA work, fp32-grade, padded rank <= 128), else an error.
-            precision = self.auto_single_plane(V, W, H, self.r_pad, self.be, group) if allow_f16 else None
+            precision = self.auto_mode(V, W, H, self.r_pad, self.be, self.beta, group) if allow_f16 else None
             if precision is None:
                 if not self.be.supported(self.r_pad, _capi.PREC_BF16X3):
                     raise NotImplementedError(
@@ -717,7 +730,7 @@ class DenseMU(AsyncLossMixin):
     def left_f16_range(self) -> bool:
         """fp16 mode: has any update so far clamped a factor value at 65504 for its image?  (One small device read; fit()
         asks at its loss checkpoints, where it synchronises anyway.)"""
-        return self.precision in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)) and bool(int(self.status.item()) & 1)
+        return self.precision in self._F16_MODES and bool(int(self.status.item()) & 1)
 
     # -- AsyncLossMixin (unsharded fits)
     def _loss_device(self):
@@ -725,7 +738,7 @@ class DenseMU(AsyncLossMixin):
         return self.loss_out
 
     def _range_flag_device(self):
-        if self.precision not in (_capi.PREC_F16, getattr(_capi, 'PREC_F16X', -1)):
+        if self.precision not in self._F16_MODES:
             return None
         return (self.status & 1).double()
 

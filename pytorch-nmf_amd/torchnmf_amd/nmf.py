@@ -310,11 +310,11 @@ class NMF(BaseComponent):
         auto = precision in (None, 'auto')
         wide = R > 256 or (R > 128 and precision == 'bf16x3')
         if R > 128 and R <= 256 and auto:
-            # one admission test for both engines (DenseMU.auto_single_plane; sharded: its answer is all-reduced, so every
+            # one admission test for both engines (DenseMU.auto_mode; sharded: its answer is all-reduced, so every
             # rank takes the same branch -- including the raise below)
             from .engine import DenseMU as _D, DEFAULT_BACKEND_FACTORY
             be = DEFAULT_BACKEND_FACTORY()
-            single = _D.auto_single_plane(V, self.W.data, self.H.data, be.pad_rank(R), be, group)
+            single = _D.auto_mode(V, self.W.data, self.H.data, be.pad_rank(R), be, beta, group)
             if single is not None:
                 precision = single
             elif group is None:

@@ -98,7 +98,9 @@ class ConvMU(AsyncLossMixin):
         # own_loop=False: a caller that drives the GEMMs itself (plca._ConvPlcaEM): none of the paths that fuse this engine's
         # own update into a GEMM's neighbours (fold parts, fused sums, ragged channels), split bf16 unless told otherwise
         self.lib = _capi.load()
-        self.staged = {}          # tag of a GEMM launch -> nmfmu_gemm_window_staged() of its descriptor
+        self.staged = {}          # tag of a GEMM launch -> nmfmu_gemm_window_staged() of its descriptor (None: the query failed)
+        # (resolved once, not per launch) '0' keeps the chunk-major implicit tiles of rounds 1-4 (A/B switch)
+        self._stage_mode = 1 if os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1') == '0' else 0
         if not torch.cuda.is_available():
             raise _capi.NmfmuError('torchnmf_amd needs a ROCm device (MI355X); there is no CPU fallback')
         # NMFD has one shift axis, NMF2D / NMF3D two / three (nmf.py:700-942); flattened they are the same problem
@@ -371,10 +373,11 @@ class ConvMU(AsyncLossMixin):
             d.t_koff = self.koff[ops].data_ptr()
         # implicit operands are staged as a window of table entries wherever the library's shape test admits it (round 5);
         # TORCHNMF_AMD_NMFD_WINSTAGE=0 keeps the chunk-major tiles of rounds 1-4 (A/B switch; bit-identical results)
-        d.stage_mode = 1 if os.environ.get('TORCHNMF_AMD_NMFD_WINSTAGE', '1') == '0' else 0
+        d.stage_mode = self._stage_mode
         timer = getattr(self, 'timer', None) if tag else None
         if tag and tag not in self.staged:       # which launches stage their implicit operand as a window (host-side query, once)
-            self.staged[tag] = int(self.lib.nmfmu_gemm_window_staged(C.byref(d), epi))
+            q = int(self.lib.nmfmu_gemm_window_staged(C.byref(d), epi))
+            self.staged[tag] = q if q >= 0 else None        # (a negative answer is an error code, not a flag)
         if timer is not None:
             timer.mark(tag + '<')
         _capi.check(self.lib.nmfmu_gemm(C.byref(d), epi, _stream()), 'nmfmu_gemm')
@@ -555,6 +558,9 @@ class ConvMU(AsyncLossMixin):
                 self._pack_h(sums=False)
                 self._h_parts_valid = True
                 return
+            #  with rows_fused the rank sums ride in the fused kernels and self.sum_w is only as fresh as the last
+            # unfused pass: this fallback must not be reached once the fused form has run
+            assert not (self.rows_fused and self._h_parts_valid), 'stale sum_w: the unfused H update after a fused one'
             _capi.check(self.lib.nmfmu_conv_apply_h_rows(
                 self.H.data_ptr(), self.B, self.R, self.Lh // self.lhs[-1], self.lhs[-1], self.wk_fold, self.hnum.data_ptr(),
                 _ptr(self.hden),

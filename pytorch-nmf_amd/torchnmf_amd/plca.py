@@ -134,8 +134,10 @@ class BaseComponent(nn.Module):
         # or 1-element tensor, possibly on another device -- and raises "Boolean value of Tensor with more than one value
         # is ambiguous" otherwise.  Same contract here: one-element tensors are taken by value, anything larger raises
         # the RuntimeError the reference's ``if`` raises.
-        W_alpha, H_alpha, Z_alpha = (_scalar_alpha(a, n, f) for a, n, f in ((W_alpha, 'W_alpha', W), (H_alpha, 'H_alpha', H),
-                                                                            (Z_alpha, 'Z_alpha', Z)))
+        #  the reference evaluates ``if X_alpha != 1`` only inside ``if X.requires_grad`` (plca.py:255-287): the
+        # hyper-parameter of a FROZEN factor is never looked at there, so it is neither validated nor converted here
+        W_alpha, H_alpha, Z_alpha = (_scalar_alpha(a, n, f) if f.requires_grad else 1.0
+                                     for a, n, f in ((W_alpha, 'W_alpha', W), (H_alpha, 'H_alpha', H), (Z_alpha, 'Z_alpha', Z)))
         for t_, what in ((V, 'fit'), (W, 'fit'), (H, 'fit'), (Z, 'fit')):
             _require_device(t_, what)
         V = V.detach().float()
@@ -188,11 +190,11 @@ class _PlcaEM:
             precision = 'bf16x3' if self.be.supported(self.r_pad, _capi.PREC_BF16X3) else 'bf16'
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_capi.PRECISIONS)} or 'auto', got {precision!r}")
-        if precision == 'f16x':
-            # (the EM steps use the split-panel instance kModeMU2, which exists for 'bf16' and 'f16')
-            raise NotImplementedError("precision 'f16x' is not built for PLCA (its split-panel kernel exists for 'bf16x3' up "
-                                      "to rank 128, 'bf16' and 'f16'); the target is normalised to sum 1 here, so 'f16' "
-                                      "would flush it to zero as well -- use 'bf16x3' (the default) or 'bf16'")
+        if precision in ('f16x', 'f16'):
+            #  the target is normalised to sum 1 here and the factors are probability tables: both sit in
+            # fp16's subnormals, so either fp16 mode would flush them (and 'f16x' has no split-panel instance at all)
+            raise NotImplementedError(f"precision {precision!r} is not available for PLCA: the normalised target and factors "
+                                      "sit below fp16's range -- use 'bf16x3' (the default) or 'bf16'")
         self.prec = _capi.PRECISIONS[precision]
         self.precision_name = precision
         if not self.be.supported(self.r_pad, self.prec):

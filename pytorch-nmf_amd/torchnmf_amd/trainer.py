@@ -189,15 +189,15 @@ class BetaMu(Optimizer):
         # other hyper-parameter sets stay
         for k in [k for k, v in self._engines.items() if v[2] is not V_user or k[2:4] != key[2:4]]:
             del self._engines[k]
-        # precision='auto' resolves like NMF.fit's (one admission test, DenseMU.auto_single_plane): a single-plane fp16 mode
-        # at 1x MFMA work where it meets the 1e-4 bar -- 'f16' for an fp16-exact target, 'f16x' otherwise -- else split
+        # precision='auto' resolves like NMF.fit's (one admission test, DenseMU.auto_mode): a single-plane fp16 mode
+        # at 1x MFMA work where it meets the 1e-4 bar -- 'f16' for an fp16-exact target, else 'f16r' ('f16x' for beta == 2) -- else split
         # bf16 (rank <= 128).  Rank 129..256 without an admissible fp16 mode has no parity-grade fused mode: the binding is
         # remembered as None and step() takes the exact chain path.
         precision = self._precision
         if precision in (None, 'auto') and W.shape[1] > 128:
             from .engine import DEFAULT_BACKEND_FACTORY
             be = DEFAULT_BACKEND_FACTORY()
-            precision = DenseMU.auto_single_plane(V, W.data, H.data, be.pad_rank(W.shape[1]), be)
+            precision = DenseMU.auto_mode(V, W.data, H.data, be.pad_rank(W.shape[1]), be, beta)
             if precision is None:
                 self._engines[key] = (None, versions, V_user)
                 self.last_precision = 'chain'
@@ -208,9 +208,9 @@ class BetaMu(Optimizer):
             # the target in fp32 instead
             from .engine import DEFAULT_BACKEND_FACTORY
             be = DEFAULT_BACKEND_FACTORY()
-            precision = DenseMU.auto_single_plane(V, W.data, H.data, be.pad_rank(W.shape[1]), be) or 'bf16x3'
-        if self._precision in (None, 'auto') and converted and precision == 'f16':
-            precision = 'f16x'
+            precision = DenseMU.auto_mode(V, W.data, H.data, be.pad_rank(W.shape[1]), be, beta) or 'bf16x3'
+        if self._precision in (None, 'auto') and converted and precision in ('f16', 'f16r'):
+            precision = 'f16x'      # 'f16r' keeps an fp16 head of the target: the same range admission as 'f16'
         eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=precision, allow_f16=True)
         self.last_precision = eng.precision_name       # what 'auto' resolved to (plain attribute, like NMF.last_precision)
         bad, _ = eng.target_flags()

@@ -23,7 +23,7 @@ class OracleBackend:
         raise NotImplementedError('rank > 256')
 
     def supported(self, r_pad, precision):
-        return precision in (0, 2, 3) or r_pad <= 128  # like the library: single-plane modes (bf16, f16, f16x) at every rank pad, bf16x3 <= 128
+        return precision in (0, 2, 3, 4) or r_pad <= 128  # like the library: single-plane modes (bf16, f16, f16x, f16r) at every rank pad, bf16x3 <= 128
 
     def block_rows(self, r_pad, precision, beta):
         return 128

@@ -209,7 +209,7 @@ def _worker_gate(rank, world, port, cols, inexact_rank, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('cols,inexact_rank,want', [(128, -1, 'f16'), (128, 1, 'f16x'), (127, -1, 'bf16x3'), (127, 0, 'bf16x3')])
+@pytest.mark.parametrize('cols,inexact_rank,want', [(128, -1, 'f16'), (128, 1, 'f16r'), (127, -1, 'bf16x3'), (127, 0, 'bf16x3')])
 def test_auto_precision_gate_is_rank_invariant(tmp_path, cols, inexact_rank, want):
     """the admission test of the fp16 modes looks at the LOCAL shard (size, exactness), so with uneven shards
     straddling F16_MIN_DIM (64 | 63 columns here) or one rank holding an fp16-inexact value the ranks used to disagree about

@@ -539,8 +539,10 @@ def test_auto_f16x_real_data_200_iterations(dev):
     H0 = torch.randn(N, R, generator=g).abs()
     m = NMF(W=W0, H=H0).to(dev)
     Vd = V.to(dev)
-    assert engine.DenseMU(Vd, m.W.data.clone(), m.H.data.clone(), 1.0, precision='auto', allow_f16=True).precision_name == 'f16x'
+    # (round 6: the 3-byte form of the unrounded target, 'f16r'; 'f16x' through round 5)
+    assert engine.DenseMU(Vd, m.W.data.clone(), m.H.data.clone(), 1.0, precision='auto', allow_f16=True).precision_name == 'f16r'
     n = m.fit(Vd, 1, NO_STOP, 200)
+    assert m.last_precision == 'f16r'
     torch.set_num_threads(min(16, torch.get_num_threads()))
     Wr, Hr = aten_port.mu_iterations(V, W0, H0, 1, 200)
     ew, eh = rel_err(m.W.data.cpu(), Wr), rel_err(m.H.data.cpu(), Hr)
@@ -1673,8 +1675,8 @@ def test_betamu_default_precision_above_rank_128(dev, rank, beta):
     assert ew < TOL and eh < TOL, (ew, eh)
 
 
-@pytest.mark.parametrize('exact,rank,beta,want', [(False, 128, 1, 'f16x'), (True, 128, 1, 'f16'), (False, 128, 2, 'f16x'),
-                                                  (False, 200, 1, 'f16x'), (True, 64, 0.5, 'f16')])
+@pytest.mark.parametrize('exact,rank,beta,want', [(False, 128, 1, 'f16r'), (True, 128, 1, 'f16'), (False, 128, 2, 'f16x'),
+                                                  (False, 200, 1, 'f16r'), (True, 64, 0.5, 'f16')])
 def test_betamu_auto_takes_the_1x_modes(dev, exact, rank, beta, want):
     """BetaMu's 'auto' resolves like NMF.fit's -- fp16 operands at 1x MFMA work where both dimensions
     reach 4096 and the data fit fp16's range ('f16' for an fp16-exact target, 'f16x' otherwise), also at rank 129..256
@@ -1822,6 +1824,11 @@ def test_plca_fit_g13_tensor_alphas_golden(dev):
         assert rel_err(p.data.cpu(), g[k]) < TOL, (k, rel_err(p.data.cpu(), g[k]))
     with pytest.raises(NotImplementedError, match="f16x"):
         m.fit(t(g['V']).to(dev), max_iter=1, precision='f16x')
+    with pytest.raises(NotImplementedError, match="below fp16's range"):      # ('f16' as well)
+        m.fit(t(g['V']).to(dev), max_iter=1, precision='f16')
+    #  the hyper-parameter of a FROZEN factor is never evaluated by the reference: a multi-element tensor passes there
+    m2 = PLCA(W=t(g['W0']), H=t(g['H0']), Z=t(g['Z0']), trainable_W=False).to(dev)
+    m2.fit(t(g['V']).to(dev), max_iter=2, W_alpha=torch.ones(3))
 
 
 @pytest.mark.parametrize('rank,prec', [(5, 'bf16x3'), (100, 'bf16x3'), (100, 'bf16'), (200, None)])
@@ -2139,8 +2146,8 @@ def test_cfg1_full_size_20_iterations_f16_unrounded_target(dev):
     Vd = V.to(dev)
     # not fp16-exact: 'auto' keeps the target in fp32 (round 4: at fp16 operands -- 'f16x'; before, split bf16)
     assert DenseMU(Vd[:4096, :4096].contiguous(), W0[:4096].clone().to(dev), H0.clone().to(dev), 1.0, precision='auto',
-                   allow_f16=True).precision_name == 'f16x'
-    for prec in ('f16', 'f16x'):
+                   allow_f16=True).precision_name == 'f16r'
+    for prec in ('f16', 'f16x', 'f16r'):
         W, H = W0.clone().to(dev), H0.clone().to(dev)
         eng = DenseMU(Vd, W, H, 1.0, precision=prec)
         for _ in range(20):
@@ -2330,6 +2337,95 @@ def test_rank128_two_accumulator_software_pipelined_kernel(dev, monkeypatch, bet
     assert ew < 6e-4 and eh < 6e-4, (ew, eh)
 
 
+@pytest.mark.parametrize('N,C,R,beta', [(4096, 65536, 128, 0.5), (4096, 65536, 128, 0.0), (8192, 65536, 256, 1.0)])
+def test_software_pipelined_kernels_are_deterministic_under_load(dev, N, C, R, beta):
+    """The hand-placed kernels of round 6 order their memory traffic by counted waits and ONE barrier per tile; a wrong count
+    or a misplaced barrier shows only under load, as run-to-run differences (the first sp2_kernel build left its LDS-DMA
+    pieces "in flight behind" older register loads -- they complete first -- and prefetched operands ahead of the barrier
+    that publishes them: every small test passed, configs[2]'s in-run parity at k = 10 did not).  Full-chip problems, two
+    iterations, three runs from identical inputs: bitwise equal factors."""
+    from torchnmf_amd.engine import DenseMU
+    g = torch.Generator(device=dev).manual_seed(N + R)
+    V = torch.rand(N, C, device=dev, generator=g).bfloat16().float() + (2.0 ** -7 if beta <= 0 else 0.0)
+    W0 = torch.randn(C, R, device=dev, generator=g).abs_()
+    H0 = torch.randn(N, R, device=dev, generator=g).abs_()
+    outs = []
+    for _ in range(3):
+        W, H = W0.clone(), H0.clone()
+        eng = DenseMU(V, W, H, beta, precision='f16')
+        for _ in range(2):
+            eng.w_step()
+            eng.h_step()
+        torch.cuda.synchronize()
+        outs.append((W.clone(), H.clone()))
+        del eng
+    for W, H in outs[1:]:
+        assert torch.equal(W, outs[0][0]) and torch.equal(H, outs[0][1])
+
+
+@pytest.mark.parametrize('beta', [1, 0, 0.5, 1.5, 3])
+@pytest.mark.parametrize('shape', [(600, 2000, 100), (300, 700, 200), (200, 330, 24)])
+def test_half_steps_f16r_every_beta(dev, beta, shape):
+    """precision='f16r' (round 6): fp16 operands, the target at THREE bytes per element -- an fp16 head rounded toward zero plus
+    one byte u, x ~ h (1 + u 2^-18), 19 significant bits.  One iteration on plain fp32 floats (which fp16 would round) against
+    the oracle ON THE UNROUNDED TARGET; as close as 'f16x' (whose target is exact) within the operands' own rounding."""
+    from oracle import mu_oracle as O
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + C + R)
+    V = torch.rand(N, C, generator=g) + (2.0 ** -7 if beta <= 0 else 0.0)
+    W0 = torch.randn(C, R, generator=g).abs() + 0.05
+    H0 = torch.randn(N, R, generator=g).abs() + 0.05
+    gam = O.gamma_of(beta)
+    Wr = O.nmf_w_step(V, W0, H0, beta, gam)
+    Hr = O.nmf_h_step(V, Wr, H0, beta, gam)
+    res = {}
+    for prec in ('f16r', 'f16x'):
+        W1, H1, l0, l1 = _one_iter(dev, V, W0, H0, beta, prec, 1)
+        res[prec] = (rel_err(W1, Wr), rel_err(H1, Hr))
+        assert l1 == pytest.approx(float(O.beta_div(O.nmf_reconstruct(Hr, Wr), V, beta)), rel=5e-3)
+    record('f16r_half_steps', beta=beta, shape=shape, f16r=res['f16r'], f16x=res['f16x'])
+    assert max(res['f16r']) < 6e-4                                   # short contractions: what fp16 operands give here
+    assert max(res['f16r']) < 1.25 * max(res['f16x']) + 2e-6         # the 3-byte target costs nothing the operands do not
+
+
+def test_f16r_target_packing_is_19_bits(dev):
+    """nmfmu_pack_x for NMFMU_PREC_F16R: decode the packed words on the host (head = fp16 bits, u = residual byte,
+    x ~ h (1 + u 2^-18)) -- relative error <= 2^-19 for values in fp16's normal range, heads never above the value, zeros exact,
+    values beyond 65504 clamped, and the layout is the f16 fragment order with two residual chunks behind the four head
+    chunks of every lane (csrc/nmfmu_layout.h)."""
+    from torchnmf_amd import _capi
+    lib = _capi.load()
+    N, C = 256, 256
+    g = torch.Generator().manual_seed(19)
+    V = torch.rand(N, C, generator=g) * torch.tensor(10.0) ** torch.randint(-4, 4, (N, C), generator=g).float()
+    V[0, :8] = torch.tensor([0.0, 1.0, 65504.0, 7e4, 6e-8, 1e-7, 0.333333343, 2049.0])
+    Vd = V.to(dev)
+    xp = torch.zeros(N * C * 3, dtype=torch.uint8, device=dev)
+    flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
+    _capi.check(lib.nmfmu_pack_x(Vd.data_ptr(), C, N, C, 0, _capi.PREC_F16R, 128, xp.data_ptr(), N, C, flags.data_ptr(), _stream()), 'pack_x')
+    torch.cuda.synchronize()
+    raw = xp.cpu().numpy()
+    got = np.zeros((N, C), dtype=np.float64)
+    ktiles = C // 64
+    for m in range(N):
+        mb, ml = divmod(m, 128)
+        w, j = divmod(ml, 32)
+        for k in range(C):
+            kt, kl = divmod(k, 64)
+            hl, i = divmod(kl, 32)                      # element i of this lane's 32 columns
+            lane = hl * 32 + j
+            base = ((mb * ktiles + kt) * 4 + w) * 6     # first of this wave-tile's six 1-KiB chunk rows
+            hoff = ((base + i // 8) * 64 + lane) * 16 + 2 * (i % 8)
+            roff = ((base + 4 + i // 16) * 64 + lane) * 16 + (i % 16)
+            h = np.frombuffer(raw[hoff:hoff + 2].tobytes(), dtype=np.float16)[0].astype(np.float64)
+            got[m, k] = h * (1.0 + float(raw[roff]) * 2.0 ** -18)
+    want = np.minimum(V.numpy().astype(np.float64), 65504.0)
+    big = want >= 6.2e-5                                # fp16's normal range
+    assert np.all(np.abs(got[big] - want[big]) <= want[big] * 2.0 ** -19 * 1.01)
+    assert np.all(np.abs(got[~big] - want[~big]) <= 6.0e-8)
+    assert got[0, 0] == 0.0 and got[0, 1] == 1.0 and got[0, 2] == 65504.0 and got[0, 3] == 65504.0
+
+
 def test_auto_precision_policy(dev, monkeypatch):
     """'auto' = the fastest mode that meets the 1e-4 bar, never plain bf16: fp16 operands where both dimensions are
     >= 4096, the target is exactly representable in fp16 and the data sit inside fp16's range; split bf16 otherwise
@@ -2347,8 +2443,9 @@ def test_auto_precision_policy(dev, monkeypatch):
     assert pick(4096, 4352, 64) == 'f16'
     assert pick(4096, 4352, 64, beta=2.0) == 'f16' and pick(4096, 4352, 64, beta=0.5) == 'f16'
     assert pick(4096, 4352, 200) == 'f16'                      # padded rank 256: the four-wave fp16 kernel
-    assert pick(4096, 4352, 64, exact=False) == 'f16x'         # fp16 would round the target: it stays fp32 (round 4)
-    assert pick(4096, 4352, 200, exact=False, beta=2.0) == 'f16x'
+    assert pick(4096, 4352, 64, exact=False) == 'f16r'         # fp16 would round the target: 3-byte form (round 6; 'f16x' in round 4)
+    assert pick(4096, 4352, 200, exact=False, beta=0.5) == 'f16r'
+    assert pick(4096, 4352, 200, exact=False, beta=2.0) == 'f16x'   # beta == 2: the target is an MFMA operand, it stays fp32
     monkeypatch.setenv('TORCHNMF_AMD_AUTO_F16X', '0')
     assert pick(4096, 4352, 64, exact=False) == 'bf16x3'
     monkeypatch.delenv('TORCHNMF_AMD_AUTO_F16X')

@@ -19,16 +19,17 @@ ap.add_argument('--save')
 ap.add_argument('--compare')
 ap.add_argument('--shapes', default='8192x16384x256,300x65600x200,1000x3000x256')
 ap.add_argument('--iters', type=int, default=3)
+ap.add_argument('--beta', type=float, default=1.0)
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 out = {}
 for sh in a.shapes.split(','):
     N, C, R = (int(x) for x in sh.split('x'))
     g = torch.Generator().manual_seed(N + C + R)
-    V = torch.rand(N, C, generator=g).bfloat16().float().to(dev)
+    V = (torch.rand(N, C, generator=g).bfloat16().float() + (2.0 ** -7 if a.beta <= 0 else 0.0)).to(dev)
     W = torch.randn(C, R, generator=g).abs().to(dev)
     H = torch.randn(N, R, generator=g).abs().to(dev)
-    eng = DenseMU(V, W, H, 1.0, precision='f16')
+    eng = DenseMU(V, W, H, a.beta, precision='f16')
     for _ in range(a.iters):
         eng.w_step()
         eng.h_step()
@@ -45,6 +46,9 @@ if a.compare:
         Wr, Hr, lr, nsr = ref[sh]
         eq = torch.equal(W, Wr) and torch.equal(H, Hr)
         rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
-        print(f'{sh}: nsplit {ns} vs {nsr}: bit-identical={eq} relW={rel(W, Wr):.3e} relH={rel(H, Hr):.3e} loss {loss} vs {lr}')
+        nbad_w = int((W != Wr).any(dim=1).sum())
+        nbad_h = int((H != Hr).any(dim=1).sum())
+        print(f'{sh}: nsplit {ns} vs {nsr}: bit-identical={eq} relW={rel(W, Wr):.3e} relH={rel(H, Hr):.3e} loss {loss} vs {lr}; '
+              f'rows of W / H that differ: {nbad_w} / {nbad_h}; max abs dW {float((W - Wr).abs().max()):.3e}')
         ok &= eq or ns != nsr
     sys.exit(0 if ok else 1)
