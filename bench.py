@@ -1047,10 +1047,10 @@ def ref_notebook_leg(a, dev, do_cpu):
 
 
 DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'bf16x3': 'bf16x3 (split bf16, fp32-grade)', 'f16x': 'f16 operands, f32 target',
-              'f16r': 'f16 operands, 3-byte target (f16 head + 8-bit relative residual)'}
+              'f16r': 'f16 operands, 3-byte target (top 24 bits of the fp32)'}
 DTYPE_LONG = {'f16': 'f16 operands and target / fp32 accumulate (same MFMA rate as bf16; meets the 1e-4 parity bar)',
               'f16x': 'f16 operands, fp32 target / fp32 accumulate (1x MFMA work, twice the V stream; for targets fp16 does not hold exactly)',
-              'f16r': 'f16 operands, 3-byte target (fp16 head rounded toward zero + one byte u: x ~ h (1 + u 2^-18), 19 significant bits) / '
+              'f16r': 'f16 operands, 3-byte target (the fp32 rounded to its top 24 bits: 16 significant bits, fp32 range) / '
                       'fp32 accumulate (1x MFMA work, 1.5x the V stream; what auto takes for targets fp16 does not hold exactly, beta != 2)',
               'bf16': 'bf16 operands and target / fp32 accumulate (the type configs[1] names; factors ~2e-4 after 3 iterations)',
               'bf16x3': 'split bf16 (3 MFMAs per product, fp32 target): fp32-grade'}

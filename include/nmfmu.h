@@ -68,9 +68,12 @@ extern "C" {
                                (nmf.py:65 is where X enters; it stays in fp32 VALU arithmetic, for beta == 2 it is an fp16
                                hi + lo operand pair), so the mode is parity-grade on targets fp16 does not hold exactly, at 1x
                                MFMA work and twice the X stream.  Four-wave kernel, every beta, padded rank <= 256 */
-#define NMFMU_PREC_F16R 4   /* (ABI 9) as F16X at THREE bytes per element of X: an fp16 head h <= x (rounded toward zero) plus one byte
-                               u, x ~ h (1 + u 2^-18): 19 significant bits with a uniform relative step -- what 'auto' takes for a
-                               target fp16 does not hold exactly.  Four-wave kernel, every beta but 2, padded rank <= 256 */
+#define NMFMU_PREC_F16R 4   /* (ABI 9) as F16X at THREE bytes per element of X: the target rounded (nearest even) to the top 24 bits
+                               of its fp32 word -- 16 significant bits (relative error <= 2^-16), fp32's whole range -- stored as
+                               the f16 layout's 16-bit words (bits 31..16) plus one byte per element (bits 15..8); the kernels
+                               rebuild the fp32 with one v_perm_b32 per element.  What 'auto' takes for a target fp16 does not
+                               hold exactly.  beta == 1 at padded rank <= 128: ping-pong kernel; every other beta but 2: the
+                               four-wave kernel, padded rank <= 256 */
 
 /* beta branches of nmf.py:61-74 / metrics.py:78-96 */
 #define NMFMU_BETA_KL 0  /* beta == 1 */

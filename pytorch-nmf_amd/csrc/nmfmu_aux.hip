@@ -14,12 +14,22 @@ namespace nmfmu {
 // pack_x: V fp32 (row-major, ld) -> fragment-order X (bf16 or fp32), zero padded.  One thread = one 16-byte chunk.
 // Fused with the validation passes of nmf.py:329-336 (any(v < 0 or NaN), min(v)).
 // ------------------------------------------------------------------------------------------------------------
+// NMFMU_PREC_F16R: the target rounded (to nearest, ties to even) to the top 24 bits of its fp32 word -- sign, 8 exponent bits,
+// 15 mantissa bits: 16 significant bits, relative error <= 2^-16, fp32's whole range (subnormals included).  A value that
+// would round up to infinity is truncated instead.  The kernels put the word back together with ONE v_perm_b32 per element.
+__device__ __forceinline__ uint32_t round24(float x) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, x);
+  uint32_t r = b + 0x7fu + ((b >> 8) & 1u);
+  if ((r & 0x7f800000u) == 0x7f800000u && (b & 0x7f800000u) != 0x7f800000u) r = b;
+  return r & 0xffffff00u;
+}
+
 template <int FMT, bool TRANSPOSE>
 __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
                                                      void* __restrict__ xp, int ktiles, int64_t nchunks,
                                                      uint32_t* flags, int G) {
   constexpr bool FP32 = FMT == 1;
-  constexpr bool F16R = FMT == 3;   // fp16 head (rounded toward zero) in chunks 0..3 + one residual byte per element in chunks 4, 5
+  constexpr bool F16R = FMT == 3;   // the fp32 rounded to its top 24 bits: bits 31..16 in chunks 0..3, bits 15..8 in chunks 4, 5
   constexpr int NQ = FP32 ? 8 : (F16R ? 6 : 4);
   constexpr int EPC = FP32 ? 4 : 8;
   const int M = TRANSPOSE ? cols : rows;  // owner axis length
@@ -39,20 +49,14 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
     const int64_t m = mb * (128 * G) + w * (32 * G) + g * 32 + (lane & 31);
     if constexpr (F16R) {
       if (q >= 4) {
-        // residual bytes of elements 16 (q - 4) .. + 15 of this lane's 32 columns: u = round((x / h - 1) 2^18) with h the fp16
-        // head rounded toward zero (x >= 0), so that x ~ h (1 + u 2^-18) with a relative step of 2^-19
+        // third bytes (bits 15..8 of the rounded word) of elements 16 (q - 4) .. + 15 of this lane's 32 columns
         u32x4 o = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int64_t k = kt * 64 + 32 * (lane >> 5) + 16 * (q - 4) + i;
           float x = 0.f;
           if (m < M && k < K) x = TRANSPOSE ? v[k * ld + m] : v[m * ld + k];
-          x = fminf(fmaxf(x, 0.f), 65504.f);
-          _Float16 h = (_Float16)x;
-          if ((float)h > x) h = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, h) - 1));
-          const float hf = (float)h;
-          const float u = hf > 0.f ? fminf(rintf((x / hf - 1.f) * 262144.f), 255.f) : 0.f;
-          o[i >> 2] |= (uint32_t)u << (8 * (i & 3));
+          o[i >> 2] |= ((round24(x) >> 8) & 0xffu) << (8 * (i & 3));
         }
         reinterpret_cast<u32x4*>(xp)[c] = o;
         continue;    // (validation flags are taken by the head chunks, which see every element once)
@@ -77,18 +81,7 @@ __global__ void __launch_bounds__(256) pack_x_kernel(const float* __restrict__ v
       for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(uint32_t, e[i]);
     } else if constexpr (F16R) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t wv = 0;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const float x = fminf(fmaxf(e[2 * i + hh], 0.f), 65504.f);
-          _Float16 h = (_Float16)x;
-          unsigned short hb = __builtin_bit_cast(unsigned short, h);
-          if ((float)h > x) hb -= 1;          // toward zero: the residual byte then only ever adds
-          wv |= (uint32_t)hb << (16 * hh);
-        }
-        o[i] = wv;
-      }
+      for (int i = 0; i < 4; ++i) o[i] = (round24(e[2 * i]) >> 16) | (round24(e[2 * i + 1]) & 0xffff0000u);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = pack_img(e[2 * i], e[2 * i + 1], FMT == 2);

@@ -44,10 +44,14 @@ static int env_int(const char* name, int dflt) {
 }
 static void* g_pp_debug = nullptr;
 #endif
-// which half-steps the ping-pong kernel serves: beta == 1, one operand plane (bf16 or fp16), padded rank <= 128
+#ifndef NMFMU_PP_F16R
+#define NMFMU_PP_F16R 1   // 0: the 3-byte target stays on the four-wave kernel at beta == 1 as well (A/B builds)
+#endif
+// which half-steps the ping-pong kernel serves: beta == 1, one operand plane (bf16 or fp16; fp16 with the 3-byte target),
+// padded rank <= 128
 static bool pp_eligible(int r_pad, int precision, float beta) {
   return nmfmu_beta_kind(beta) == NMFMU_BETA_KL && r_pad <= 128 &&
-         (precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_BF16);
+         (precision == NMFMU_PREC_F16 || precision == NMFMU_PREC_BF16 || (NMFMU_PP_F16R && precision == NMFMU_PREC_F16R));
 }
 // which half-steps the software-pipelined one-wave-per-SIMD kernel serves (nmfmu_sp.h): beta == 1, fp16 operands and target,
 // padded rank 256 -- the kernel of configs[4]'s shard
@@ -150,7 +154,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
 #ifdef NMFMU_DEBUG_HOOKS
     if (mode == kModeMU && g_pp_debug) a.debug = g_pp_debug;
 #endif
-    return launch_pp(st->r_pad, st->precision == NMFMU_PREC_F16 ? kOpF16 : kOpBf16, mode, a, grid, s);
+    return launch_pp(st->r_pad, is_f16(st->precision) ? kOpF16 : kOpBf16, mode, a, grid, s, st->precision == NMFMU_PREC_F16R);
   }
   if (mode == kModeMU && sp_eligible(st->r_pad, st->precision, st->beta)) {
     a.tiles_per_split = (a.tiles_per_split + 3) & ~3;   // its tile loop runs in groups of four (ring slot = tile & 3)
@@ -204,7 +208,7 @@ int nmfmu_supported(int r_pad, int precision) {
   if (precision == NMFMU_PREC_BF16X3) return r_pad <= 128;  // 4 image planes x 2 stages must fit 160 KiB of LDS
   if (precision == NMFMU_PREC_F16) return 1;                // ping-pong kernel (beta == 1, r_pad <= 128), else four-wave
   if (precision == NMFMU_PREC_F16X) return 1;               // four-wave kernel: fp16 operands, fp32 target
-  if (precision == NMFMU_PREC_F16R) return 1;               // four-wave kernel: fp16 operands, 3-byte target (beta != 2)
+  if (precision == NMFMU_PREC_F16R) return 1;               // as F16 with a 3-byte target (beta != 2): ping-pong / four-wave kernel
   return 0;
 }
 

@@ -146,7 +146,7 @@ template <int R_PAD, int BETA, int PREC, int MODE>
 struct FusedCfg {
   static constexpr bool X3 = PREC == kPrecX3;                           // two operand planes (hi / lo)
   static constexpr bool F16 = PREC == kPrecF16 || PREC == kPrecF16X || PREC == kPrecF16R;   // fp16 operand type
-  static constexpr bool XR = PREC == kPrecF16R;                        // X = fp16 head + 8-bit relative residual (3 bytes per element)
+  static constexpr bool XR = PREC == kPrecF16R;                        // X = the top 24 bits of the fp32 (3 bytes per element)
   static constexpr bool XF32 = X3 || PREC == kPrecF16X;                // X stored fp32 (fragment order, 8 chunks per lane)
   static constexpr int BM = 128, WAVES = 4, THREADS = 256;
   static constexpr int KS = R_PAD / 16;      // k-steps of GEMM1 (contraction over rank)
@@ -171,7 +171,7 @@ struct FusedCfg {
   static constexpr int P2HI = XB ? 0 : NPL * IMG;
   static constexpr int P2LO = P2HI + IMG;
   static constexpr int STAGE_BYTES = NIMG * IMG;
-  static constexpr int NQ = XF32 ? 8 : (XR ? 6 : 4);    // 16-byte X chunks per lane per tile (f16r: 4 of heads + 2 of residual bytes)
+  static constexpr int NQ = XF32 ? 8 : (XR ? 6 : 4);    // 16-byte X chunks per lane per tile (f16r: 4 of high halves + 2 of third bytes)
   static constexpr bool TWO_ACC = (BETA != kKL) && !LOSS && !DEN;
   // fp32 target as an fp16 MFMA operand (f16x, beta = 2: Gn = X): hi + lo pair, two MFMAs for the numerator product
   static constexpr bool XSPLIT = PREC == kPrecF16X && BETA == kEuc && !LOSS && !DEN;   // (kModeXB included)
@@ -639,21 +639,20 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       const uint32_t u1 = x[4 * tt + (d >> 1)][2 * (d & 1) + 1];
       x0 = __builtin_bit_cast(float, u0);
       x1 = __builtin_bit_cast(float, u1);
+    } else if constexpr (C::XR) {
+      // 3-byte target: bits 31..16 in the 16-bit word of the f16 layout, bits 15..8 = byte (16 tt + 2 d [+ 1]) of this lane's
+      // 32 third bytes (chunks 4, 5) -- ONE v_perm_b32 per element puts the fp32 back together (selector bytes: 4..7 = the
+      // first source, 0..3 = the second, 0x0c = zero)
+      const uint32_t w = x[2 * tt + (d >> 2)][d & 3], uw = x[4 + tt][d >> 1];
+      const uint32_t j0 = 2 * (d & 1);
+      x0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(w, uw, 0x0504000cu | (j0 << 8)));
+      x1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(w, uw, 0x0706000cu | ((j0 + 1) << 8)));
     } else {
       const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
       x0 = unpack_lo<OPT>(w);
       x1 = unpack_hi<OPT>(w);
     }
     const float s0 = stt[2 * d], s1 = stt[2 * d + 1];
-    float f0 = 1.f, f1 = 1.f;   // f16r: x = head * (1 + u 2^-18), u = byte (16 tt + 2 d) of this lane's 32 residual bytes
-    if constexpr (C::XR) {
-      const uint32_t uw = x[4 + tt][d >> 1];
-      const float u0 = (float)((uw >> (16 * (d & 1))) & 0xffu);         // (hipcc selects v_cvt_f32_ubyte0 .. 3)
-      const float u1 = (float)((uw >> (16 * (d & 1) + 8)) & 0xffu);
-      f0 = __builtin_fmaf(u0, 3.814697265625e-06f, 1.f);
-      f1 = __builtin_fmaf(u1, 3.814697265625e-06f, 1.f);
-      if constexpr (C::LOSS) x0 *= f0, x1 *= f1;
-    }
     if constexpr (C::LOSS) {
       constexpr int LB = (BETA == kSqrt || BETA == kSqrt3) ? (int)kGen : BETA;
       const int k0 = t * kBK + 32 * hl + 16 * tt + 2 * d;
@@ -664,7 +663,7 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
       float n0, n1, p0, p1;
       // fp16 target: the factor of Gn that does not depend on x first, then ONE v_fma_mix_f32 per element multiplies it
       // by the fp16 half of the stored word (no separate conversion of x)
-      constexpr bool MIX = C::F16 && !C::XF32 && BETA != kEuc;
+      constexpr bool MIX = C::F16 && !C::XF32 && !C::XR && BETA != kEuc;
       const float xa = MIX ? 1.f : x0, xb = MIX ? 1.f : x1;
 #ifdef NMFMU_FUSED_ABL_NOELEM
       // timing-only ablation (wrong results; round 5): the transcendental / multiply chain of nmf.py:61-74 is
@@ -680,7 +679,6 @@ __global__ void __launch_bounds__(256, (FusedCfg<R_PAD, BETA, PREC, MODE>::MINW)
         mu_elem<BETA>(s1, xb, a.beta, n1, p1);
       }
 #endif
-      if constexpr (C::XR) n0 *= f0, n1 *= f1;
       if constexpr (MIX) {
         const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
         float m0, m1;

@@ -9,7 +9,12 @@ bool pp_available(int r_pad, int opt, int mode) {
 }
 
 template <int R_PAD>
-static int launch_pp_r(int opt, int mode, const FusedArgs& a, int grid, hipStream_t s) {
+static int launch_pp_r(int opt, int mode, const FusedArgs& a, int grid, hipStream_t s, bool xr) {
+  if (xr) {   // the 3-byte target (NMFMU_PREC_F16R): fp16 operands only
+    if (opt == kOpF16 && mode == kModeMU) return launch_pp_one<R_PAD, kOpF16, kModeMU, true>(a, grid, s);
+    if (opt == kOpF16 && mode == kModeLoss) return launch_pp_one<R_PAD, kOpF16, kModeLoss, true>(a, grid, s);
+    return -2;
+  }
   if (opt == kOpBf16 && mode == kModeMU) return launch_pp_one<R_PAD, kOpBf16, kModeMU>(a, grid, s);
   if (opt == kOpF16 && mode == kModeMU) return launch_pp_one<R_PAD, kOpF16, kModeMU>(a, grid, s);
   if (opt == kOpBf16 && mode == kModeLoss) return launch_pp_one<R_PAD, kOpBf16, kModeLoss>(a, grid, s);
@@ -17,11 +22,11 @@ static int launch_pp_r(int opt, int mode, const FusedArgs& a, int grid, hipStrea
   return -2;
 }
 
-int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s) {
+int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s, bool xr) {
   switch (r_pad) {
-    case 32: return launch_pp_r<32>(opt, mode, a, grid, s);
-    case 64: return launch_pp_r<64>(opt, mode, a, grid, s);
-    case 128: return launch_pp_r<128>(opt, mode, a, grid, s);
+    case 32: return launch_pp_r<32>(opt, mode, a, grid, s, xr);
+    case 64: return launch_pp_r<64>(opt, mode, a, grid, s, xr);
+    case 128: return launch_pp_r<128>(opt, mode, a, grid, s, xr);
   }
   return -2;
 }

@@ -63,10 +63,18 @@
 #ifndef NMFMU_PP_DUP
 #define NMFMU_PP_DUP 0
 #endif
+// Where a wave issues its X loads (round 6): 0 = all of them at the end of its E segment, behind the ratios (rounds 2-5);
+// 1 = one at a time in the gaps of its next M segment.  At the end of E the four E-ing waves of a CU issue their loads in the
+// same few hundred cycles and the texture-address path takes 64 B per clock: ~70 cycles per 1-KiB load on the segment that
+// is the pole of the ping-pong pair (profiles/r06_joule_budget.md); spread over the M segment the same loads wait for nobody.
+// -1 = the shipped choice: in M for the 3-byte target (six loads per tile), at the end of E otherwise.
+#ifndef NMFMU_PP_XM
+#define NMFMU_PP_XM -1
+#endif
 
 namespace nmfmu {
 
-template <int R_PAD, int OPT, int MODE>
+template <int R_PAD, int OPT, int MODE, bool XR_ = false>
 struct PPCfg {
   static constexpr int BM = 256, WAVES = 8, THREADS = 512;
   static constexpr int KS = R_PAD / 16;      // k-steps of G1 (contraction over rank)
@@ -76,7 +84,11 @@ struct PPCfg {
   static constexpr bool LOSS = MODE == kModeLoss;
   static constexpr int LEAD = 2;             // P1 runs LEAD tiles ahead, P2 LEAD - 1
   static constexpr int NSLOT = 3;            // ring depth of P1 and of P2
-  static constexpr int XTILE = BM * kBK * 2; // one X tile: 256 rows x 64 columns x 2 bytes = 32 KiB
+  static constexpr bool XR = XR_;            // 3-byte target (NMFMU_PREC_F16R): the f16 layout's words + one byte per element
+  static constexpr int NX = XR ? 6 : 4;      // 16-byte X chunks per lane per tile
+  static constexpr int XTILE = BM * kBK * (XR ? 3 : 2);   // one X tile: 256 rows x 64 columns x 2 (3) bytes = 32 (48) KiB
+  static_assert(!XR || OPT == kOpF16, "the 3-byte target comes with fp16 operands");
+  static constexpr bool XM = (NMFMU_PP_DUP & (4 | 32)) ? false : (NMFMU_PP_XM < 0 ? XR : NMFMU_PP_XM != 0);   // X loads in the M segment
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG;
   static constexpr int LDS_MAIN = 2 * NSLOT * IMG;
   static constexpr int LDS_EPI = LOSS ? 64 : WAVES * 32 * R_PAD * 4;   // fused-apply staging tile per wave
@@ -89,9 +101,10 @@ struct PPCfg {
   static_assert(NSTEP1 >= PF, "ring deeper than G1");
 };
 
-template <int R_PAD, int OPT, int MODE>
+template <int R_PAD, int OPT, int MODE, bool XR = false>
 __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
-  using C = PPCfg<R_PAD, OPT, MODE>;
+  using C = PPCfg<R_PAD, OPT, MODE, XR>;
+  constexpr int NX = C::NX;
   constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, PF = C::PF;
   constexpr int NSTEP1 = C::NSTEP1, NSTEP2 = C::NSTEP2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     const unsigned lds_base =
         __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     const char* xsrc = reinterpret_cast<const char*>(a.xp) + ((size_t)mb * a.ktiles + t0) * (size_t)C::XTILE +
-                       (size_t)wave * 4096;
+                       (size_t)wave * (size_t)(NX * 1024);
     const char* p1src = reinterpret_cast<const char*>(a.p1_hi) + (size_t)t0 * IMG;
     const char* p2src = reinterpret_cast<const char*>(a.p2_hi) + (size_t)t0 * IMG;
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -248,7 +261,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #else
 #define NMFMU_PP_XPOL " nt"
 #endif
-    u32x4 xA[4], xB[4];   // X(even tiles) / X(odd tiles)
+    u32x4 xA[NX], xB[NX];   // X(even tiles) / X(odd tiles)
 #if NMFMU_PP_DUP & (4 | 32)
     // dead landing registers of the duplicated X loads, one set per X buffer: a duplicate stays in flight exactly as long
     // as its original, so it is tied at the SAME counted wait (one set tied a tile early let hipcc reuse registers that
@@ -263,7 +276,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #if NMFMU_PP_DUP & (4 | 32)
 #define NMFMU_PP_XDUP(x) ((&(x)[0] == &xA[0]) ? xdupA : xdupB)
 #endif
-    auto load_x = [&](int t, u32x4(&x)[4]) {
+    auto load_x = [&](int t, u32x4(&x)[NX]) {
       const char* src = xsrc + (size_t)clampt(t) * (size_t)C::XTILE;
 #if NMFMU_PP_DUP & (4 | 32)
       u32x4(&xdup)[4] = NMFMU_PP_XDUP(x);
@@ -277,22 +290,51 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           : "v"(lane16), "s"(src + xmirror)
           : "memory");
 #endif
-      asm volatile(
-          "s_nop 4\n\t"
-          "global_load_dwordx4 %0, %4, %5" NMFMU_PP_XPOL "\n\t"
-          "global_load_dwordx4 %1, %4, %5 offset:1024" NMFMU_PP_XPOL "\n\t"
-          "global_load_dwordx4 %2, %4, %5 offset:2048" NMFMU_PP_XPOL "\n\t"
-          "global_load_dwordx4 %3, %4, %5 offset:3072" NMFMU_PP_XPOL
-          : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
-          : "v"(lane16), "s"(src)
-          : "memory");
+      if constexpr (C::XR) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %6, %7" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %1, %6, %7 offset:1024" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %2, %6, %7 offset:2048" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %3, %6, %7 offset:3072" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %4, %6, %8" NMFMU_PP_XPOL "\n\t"               // the third bytes of the lane's 32 elements
+            "global_load_dwordx4 %5, %6, %8 offset:1024" NMFMU_PP_XPOL              // (13-bit signed offsets end at 4095)
+            : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[NX - 2]), "=&v"(x[NX - 1])
+            : "v"(lane16), "s"(src), "s"(src + 4096)
+            : "memory");
+      } else {
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %4, %5" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %1, %4, %5 offset:1024" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %2, %4, %5 offset:2048" NMFMU_PP_XPOL "\n\t"
+            "global_load_dwordx4 %3, %4, %5 offset:3072" NMFMU_PP_XPOL
+            : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+            : "v"(lane16), "s"(src)
+            : "memory");
+      }
     };
-    auto wait_x = [&](u32x4(&x)[4]) {
+    auto tie_x = [&](u32x4(&x)[NX]) {   // "these registers are written by loads in flight / have landed": hipcc may not move them
+      asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[NX - 2]), "+v"(x[NX - 1]));
+    };
+    // one 1-KiB piece of a tile's X (piece i of NX) -- the form the M segment issues between its MFMAs.  `src` / `src4` (the
+    // tile's base and base + 4 KiB: 13-bit signed instruction offsets end at 4095) are formed and laundered by the caller
+    // BEFORE the segment, far from their first VMEM use
+    auto load_x1 = [&](auto ic, u32x4(&x)[NX], const char* src, const char* src4) {
+      constexpr int i = decltype(ic)::value;
+      const unsigned l16 = lane16;
+      if constexpr (i < 4)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" NMFMU_PP_XPOL : "=&v"(x[i]) : "v"(l16), "s"(src), "n"(i * 1024) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" NMFMU_PP_XPOL : "=&v"(x[i]) : "v"(l16), "s"(src4), "n"((i - 4) * 1024) : "memory");
+    };
+    auto wait_x = [&](u32x4(&x)[NX]) {
 #if NMFMU_PP_DUP & (4 | 32)
       u32x4(&xdup)[4] = NMFMU_PP_XDUP(x);
       asm volatile("s_waitcnt vmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(xdup[0]), "+v"(xdup[1]), "+v"(xdup[2]), "+v"(xdup[3])::"memory");
 #else
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+      if constexpr (C::XR) asm volatile("s_waitcnt vmcnt(6)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[NX - 2]), "+v"(x[NX - 1])::"memory");
+      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
 #endif
     };
     auto barrier = [&]() {
@@ -402,7 +444,8 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
     };
     // M(t): G1(t) if g1, then G2(t-1) if g2
-    auto matrix_segment = [&](auto g1c, auto g2c) {
+    auto no_fill = [](auto) {};
+    auto matrix_segment = [&](auto g1c, auto g2c, auto fillc, auto&& fill) {   // fill(i): X piece i of the tile two ahead (C::XM)
       constexpr bool g1 = decltype(g1c)::value, g2 = decltype(g2c)::value && !C::LOSS;
       constexpr int N1 = g1 ? NSTEP1 : 0, N2 = g2 ? NSTEP2 : 0, NS = N1 + N2;
       static_for<NS>([&](auto ec) {
@@ -438,6 +481,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
           mma(acc[rt], nh, op);
         }
         if constexpr (e + PF < NS) opnd(ring[e % PF], std::integral_constant<int, e + PF>{}, g1c);
+        if constexpr (decltype(fillc)::value) {
+          static_for<NX>([&](auto ic) {
+            if constexpr ((decltype(ic)::value * NS) / NX == e) fill(ic);
+          });
+        }
       });
       // asm MFMAs are not padded by hipcc: when no G2 follows G1, the S tiles are read by the VALU right after the
       // barrier -- cover the XDL write -> VALU read distance (18 wait states for a 16-pass MFMA) here
@@ -446,7 +494,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     // E(t): ratios of tile t from S and X(t); operand prefetch for the next M segment, panel DMA (waves 0-3) and this
     // wave's X piece two tiles ahead.  tail (the last two tiles): nothing is prefetched past the end -- an asm load
     // whose result is never read would land in registers hipcc has already handed to something else
-    auto elementwise_segment = [&](int t, auto nextc, u32x4(&x)[4], auto tailc) {
+    auto elementwise_segment = [&](int t, auto nextc, u32x4(&x)[NX], auto tailc) {
       constexpr bool next_has_g1 = decltype(nextc)::value;
       constexpr bool tail = decltype(tailc)::value;
       advance_slots();
@@ -463,12 +511,48 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #pragma unroll
           for (int d = 0; d < 8; ++d) {
             const uint32_t w = x[2 * tt + (d >> 2)][d & 3];
-            const float x0 = unpack_lo<OPT>(w), x1 = unpack_hi<OPT>(w);
+            float x0, x1;
+            if constexpr (C::XR) {   // bits 31..16 from the 16-bit word, bits 15..8 from the lane's third bytes (chunks 4, 5)
+              const uint32_t uw = x[4 + tt][d >> 1], j0 = 2 * (d & 1);
+              x0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(w, uw, 0x0504000cu | (j0 << 8)));
+              x1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(w, uw, 0x0706000cu | ((j0 + 1) << 8)));
+            } else {
+              x0 = unpack_lo<OPT>(w), x1 = unpack_hi<OPT>(w);
+            }
             const int k0 = (t0 + t) * kBK + 32 * hl + 16 * tt + 2 * d;
             const bool rowok = m0 < a.M;
             constexpr float un = SCALED ? 1.1920928955078125e-07f : 1.f;
             lacc += (rowok && k0 < a.K) ? loss_elem<kKL>(S[tt][2 * d] * un, x0, 1.f) : 0.f;
             lacc += (rowok && k0 + 1 < a.K) ? loss_elem<kKL>(S[tt][2 * d + 1] * un, x1, 1.f) : 0.f;
+          }
+        } else if constexpr (C::XR) {
+          // 3-byte target, four elements per statement: 4 x v_rcp_f32, 4 x v_perm_b32 (the fp32 of the target from its 16-bit
+          // word and its third byte; selector in an SGPR), 4 x v_mul_f32, 2 x v_cvt_pk_f16_f32 -- four VALU slots more than
+          // the fp16 target's statement, inside a segment that runs under the partner wave's MFMAs
+#pragma unroll
+          for (int d = 0; d < 8; d += 2) {
+            const uint32_t w0 = x[2 * tt + (d >> 2)][d & 3], w1 = x[2 * tt + (d >> 2)][(d & 3) + 1], uw = x[4 + tt][d >> 1];
+            float r0, r1, r2, r3, y0, y1, y2, y3;
+            uint32_t g0, g1;
+            asm("v_rcp_f32 %2, %10\n\t"
+                "v_rcp_f32 %3, %11\n\t"
+                "v_rcp_f32 %4, %12\n\t"
+                "v_rcp_f32 %5, %13\n\t"
+                "v_perm_b32 %6, %14, %16, %17\n\t"
+                "v_perm_b32 %7, %14, %16, %18\n\t"
+                "v_perm_b32 %8, %15, %16, %19\n\t"
+                "v_perm_b32 %9, %15, %16, %20\n\t"
+                "v_mul_f32 %2, %6, %2\n\t"
+                "v_mul_f32 %3, %7, %3\n\t"
+                "v_mul_f32 %4, %8, %4\n\t"
+                "v_mul_f32 %5, %9, %5\n\t"
+                "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                "v_cvt_pk_f16_f32 %1, %4, %5"
+                : "=&v"(g0), "=&v"(g1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(w0), "v"(w1),
+                  "v"(uw), "s"(0x0504000cu), "s"(0x0706010cu), "s"(0x0504020cu), "s"(0x0706030cu));
+            gn[tt][d] = g0;
+            gn[tt][d + 1] = g1;
           }
         } else if constexpr (OPT == kOpF16) {
           // four elements per statement: 4 x v_rcp_f32, 4 x v_fma_mix_f32 (fp16 half of the X word x fp32
@@ -533,7 +617,7 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       p1_issue_off = next_off(p1_issue_off);
       p2_issue_off = next_off(p2_issue_off);
       __builtin_amdgcn_sched_barrier(0);   // this wave's reads of X(t) are complete (their values were consumed)
-      if constexpr (!tail) load_x(t + 2, x);   // ... before its register buffer is refilled
+      if constexpr (!tail && !C::XM) load_x(t + 2, x);   // ... before its register buffer is refilled (XM: in the next M segment)
     };
 
     // ---- prologue: P1(0), P1(1), P2(0), X(0), X(1); everything landed before the first barrier
@@ -550,6 +634,8 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     load_owner();
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(xA[0]), "+v"(xA[1]), "+v"(xA[2]), "+v"(xA[3]), "+v"(xB[0]), "+v"(xB[1]), "+v"(xB[2]), "+v"(xB[3])::"memory");
+    tie_x(xA);
+    tie_x(xB);
 #if NMFMU_PP_DUP & (4 | 32)
     asm volatile("" : "+v"(xdupA[0]), "+v"(xdupA[1]), "+v"(xdupA[2]), "+v"(xdupA[3]), "+v"(xdupB[0]), "+v"(xdupB[1]), "+v"(xdupB[2]), "+v"(xdupB[3]));
 #endif
@@ -557,19 +643,27 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
     barrier();
     prefetch(std::true_type{});
     if (half) barrier();                       // waves 4-7 run one segment behind
-    matrix_segment(std::true_type{}, std::false_type{});
+    matrix_segment(std::true_type{}, std::false_type{}, std::false_type{}, no_fill);
     stamp(0);
     // one tile = barrier, E(t), barrier, M(t+1).  `xc` holds X(t); the wait that ends M(t+1) names the buffer the NEXT
     // elementwise segment reads.  The last tile is peeled (a join of two differently shaped M segments inside the loop
     // would cost a register copy of every accumulator per tile).
-    auto tile_full = [&](int t, u32x4(&xc)[4], u32x4(&xn)[4], auto tailc) {
+    auto tile_full = [&](int t, u32x4(&xc)[NX], u32x4(&xn)[NX], auto tailc) {
       constexpr bool tail = decltype(tailc)::value;
       barrier();
       elementwise_segment(t, std::true_type{}, xc, tailc);
       barrier();
-      matrix_segment(std::true_type{}, std::true_type{});
+      if constexpr (!tail && C::XM) {
+        const char* src = xsrc + (size_t)clampt(t + 2) * (size_t)C::XTILE;
+        const char* src4 = src + 4096;
+        asm volatile("" : "+s"(src), "+s"(src4));
+        matrix_segment(std::true_type{}, std::true_type{}, std::true_type{}, [&](auto ic) { load_x1(ic, xc, src, src4); });
+      } else {
+        matrix_segment(std::true_type{}, std::true_type{}, std::false_type{}, no_fill);
+      }
       if constexpr (tail) {  // nothing younger than X(t+1) except tail panel pieces: drain
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3])::"memory");
+        tie_x(xn);
 #if NMFMU_PP_DUP & (4 | 32)
         asm volatile("" : "+v"(xdupA[0]), "+v"(xdupA[1]), "+v"(xdupA[2]), "+v"(xdupA[3]), "+v"(xdupB[0]), "+v"(xdupB[1]), "+v"(xdupB[2]), "+v"(xdupB[3]));
 #endif
@@ -577,11 +671,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
       else
         wait_x(xn);
     };
-    auto tile_last = [&](int t, u32x4(&xc)[4], auto tailc) {
+    auto tile_last = [&](int t, u32x4(&xc)[NX], auto tailc) {
       barrier();
       elementwise_segment(t, std::false_type{}, xc, tailc);
       barrier();
-      matrix_segment(std::false_type{}, std::true_type{});
+      matrix_segment(std::false_type{}, std::true_type{}, std::false_type{}, no_fill);
     };
     // static register buffers => the tile loop is unrolled by two; the host gives every workgroup an EVEN number of
     // tiles (tiles_per_split is rounded up to even, the padded contraction length is a multiple of 256), so there is
@@ -787,11 +881,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   }
 }
 
-template <int R_PAD, int OPT, int MODE>
+template <int R_PAD, int OPT, int MODE, bool XR = false>
 int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
-  using C = PPCfg<R_PAD, OPT, MODE>;
+  using C = PPCfg<R_PAD, OPT, MODE, XR>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
-  auto kern = pp_kernel<R_PAD, OPT, MODE>;
+  auto kern = pp_kernel<R_PAD, OPT, MODE, XR>;
   static bool done[64] = {};
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -805,7 +899,7 @@ int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
 }
 
 // Host-side launcher (nmfmu_inst_pp.hip).  opt = OperandType, mode = kModeMU | kModeLoss.
-int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s);
+int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s, bool xr = false);
 bool pp_available(int r_pad, int opt, int mode);
 
 }  // namespace nmfmu

@@ -439,9 +439,9 @@ class DenseMU(AsyncLossMixin):
 
     @classmethod
     def auto_mode(cls, V, W, H, r_pad, be, beta, group=None) -> Optional[str]:
-        """``auto_single_plane`` with the 3-byte target (round 6): a target fp16 does not hold exactly runs as 'f16r' -- fp16
-        head + 8-bit relative residual, 19 significant bits, 25 % fewer bytes of V per iteration than 'f16x', nothing rounded
-        that the parity bar can see -- except for beta == 2, where the target is an MFMA operand itself and stays fp32
+        """``auto_single_plane`` with the 3-byte target (round 6): a target fp16 does not hold exactly runs as 'f16r' -- the
+        fp32 rounded to its top 24 bits (16 significant bits, fp32's range), 25 % fewer bytes of V per iteration than 'f16x',
+        nothing rounded that the parity bar can see -- except for beta == 2, where the target is an MFMA operand itself and stays fp32
         ('f16x').  Rank-invariant like its input (same library and environment on every rank)."""
         mode = cls.auto_single_plane(V, W, H, r_pad, be, group)
         if (mode == 'f16x' and float(beta) != 2.0 and hasattr(_capi, 'PREC_F16R') and be.supported(r_pad, _capi.PREC_F16R)

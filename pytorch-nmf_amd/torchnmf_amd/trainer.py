@@ -209,8 +209,8 @@ class BetaMu(Optimizer):
             from .engine import DEFAULT_BACKEND_FACTORY
             be = DEFAULT_BACKEND_FACTORY()
             precision = DenseMU.auto_mode(V, W.data, H.data, be.pad_rank(W.shape[1]), be, beta) or 'bf16x3'
-        if self._precision in (None, 'auto') and converted and precision in ('f16', 'f16r'):
-            precision = 'f16x'      # 'f16r' keeps an fp16 head of the target: the same range admission as 'f16'
+        if self._precision in (None, 'auto') and converted and precision == 'f16':
+            precision = 'f16r' if float(beta) != 2.0 else 'f16x'   # 24-bit / fp32 target: nothing to admit per step
         eng = DenseMU(V, W.data, H.data, beta, l1, l2, precision=precision, allow_f16=True)
         self.last_precision = eng.precision_name       # what 'auto' resolved to (plain attribute, like NMF.last_precision)
         bad, _ = eng.target_flags()

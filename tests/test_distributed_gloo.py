@@ -242,7 +242,7 @@ def test_bench_script_control_flow_world2(tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['nranks'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert 'NOT a measurement' in d['data']
-    assert len(d['blocks_ms_per_step']) == 2 and d['ms_per_step'] > 0 and d['value'] > 0     # fixed block count when sharded
+    assert len(d['blocks_ms_per_step']) == 2 and d['ms_per_step'] > 0 and d['value'] >= 0    # fixed block count when sharded (the stand-in's tiny shape may round to 0.0 GFLOP/s on a busy host)
     assert d['config']['parallelism'] == 'column-shard x2' and d['config']['cols_per_gpu'] == 40
     rf = d['roofline']
     assert rf['avg_allreduce_ms'] > 0 and rf['avg_launch_ms_h_step'] > 0 and rf['avg_launch_ms_w_step'] > 0

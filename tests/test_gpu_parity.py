@@ -2366,9 +2366,10 @@ def test_software_pipelined_kernels_are_deterministic_under_load(dev, N, C, R, b
 @pytest.mark.parametrize('beta', [1, 0, 0.5, 1.5, 3])
 @pytest.mark.parametrize('shape', [(600, 2000, 100), (300, 700, 200), (200, 330, 24)])
 def test_half_steps_f16r_every_beta(dev, beta, shape):
-    """precision='f16r' (round 6): fp16 operands, the target at THREE bytes per element -- an fp16 head rounded toward zero plus
-    one byte u, x ~ h (1 + u 2^-18), 19 significant bits.  One iteration on plain fp32 floats (which fp16 would round) against
-    the oracle ON THE UNROUNDED TARGET; as close as 'f16x' (whose target is exact) within the operands' own rounding."""
+    """precision='f16r' (round 6): fp16 operands, the target at THREE bytes per element -- the fp32 rounded to its top 24 bits,
+    16 significant bits.  One iteration on plain fp32 floats (which fp16 would round) against the oracle ON THE UNROUNDED
+    TARGET; as close as 'f16x' (whose target is exact) within the operands' own rounding.  beta == 1 at rank <= 128 runs the
+    ping-pong kernel's 3-byte instance, everything else the four-wave kernel's."""
     from oracle import mu_oracle as O
     N, C, R = shape
     g = torch.Generator().manual_seed(N + C + R)
@@ -2388,42 +2389,42 @@ def test_half_steps_f16r_every_beta(dev, beta, shape):
     assert max(res['f16r']) < 1.25 * max(res['f16x']) + 2e-6         # the 3-byte target costs nothing the operands do not
 
 
-def test_f16r_target_packing_is_19_bits(dev):
-    """nmfmu_pack_x for NMFMU_PREC_F16R: decode the packed words on the host (head = fp16 bits, u = residual byte,
-    x ~ h (1 + u 2^-18)) -- relative error <= 2^-19 for values in fp16's normal range, heads never above the value, zeros exact,
-    values beyond 65504 clamped, and the layout is the f16 fragment order with two residual chunks behind the four head
-    chunks of every lane (csrc/nmfmu_layout.h)."""
+def test_f16r_target_packing_is_the_top_24_bits(dev):
+    """nmfmu_pack_x for NMFMU_PREC_F16R: decode the packed bytes on the host (bits 31..16 = the 16-bit word of the f16 fragment
+    order, bits 15..8 = the element's byte in the two chunks behind the four word chunks of every lane, csrc/nmfmu_layout.h)
+    and compare with the fp32 rounded to nearest-even at bit 8: bit-exact, relative error <= 2^-16 everywhere in fp32's range
+    (subnormals: absolute 2^-142), zero / one / huge / tiny values, a value that would round up to infinity truncated."""
     from torchnmf_amd import _capi
     lib = _capi.load()
     N, C = 256, 256
     g = torch.Generator().manual_seed(19)
-    V = torch.rand(N, C, generator=g) * torch.tensor(10.0) ** torch.randint(-4, 4, (N, C), generator=g).float()
-    V[0, :8] = torch.tensor([0.0, 1.0, 65504.0, 7e4, 6e-8, 1e-7, 0.333333343, 2049.0])
+    V = torch.rand(N, C, generator=g) * torch.tensor(10.0) ** torch.randint(-30, 30, (N, C), generator=g).float()
+    V[0, :8] = torch.tensor([0.0, 1.0, 65504.0, 7e4, 6e-8, 1e-40, 0.333333343, 2049.0])
+    V[0, 8] = torch.tensor(0x7f7fffff, dtype=torch.int32).view(torch.float32)       # FLT_MAX: truncated, not rounded up to inf
     Vd = V.to(dev)
     xp = torch.zeros(N * C * 3, dtype=torch.uint8, device=dev)
     flags = torch.tensor([0, 0x7f800000], dtype=torch.int32, device=dev)
     _capi.check(lib.nmfmu_pack_x(Vd.data_ptr(), C, N, C, 0, _capi.PREC_F16R, 128, xp.data_ptr(), N, C, flags.data_ptr(), _stream()), 'pack_x')
     torch.cuda.synchronize()
-    raw = xp.cpu().numpy()
-    got = np.zeros((N, C), dtype=np.float64)
-    ktiles = C // 64
-    for m in range(N):
-        mb, ml = divmod(m, 128)
-        w, j = divmod(ml, 32)
-        for k in range(C):
-            kt, kl = divmod(k, 64)
-            hl, i = divmod(kl, 32)                      # element i of this lane's 32 columns
-            lane = hl * 32 + j
-            base = ((mb * ktiles + kt) * 4 + w) * 6     # first of this wave-tile's six 1-KiB chunk rows
-            hoff = ((base + i // 8) * 64 + lane) * 16 + 2 * (i % 8)
-            roff = ((base + 4 + i // 16) * 64 + lane) * 16 + (i % 16)
-            h = np.frombuffer(raw[hoff:hoff + 2].tobytes(), dtype=np.float16)[0].astype(np.float64)
-            got[m, k] = h * (1.0 + float(raw[roff]) * 2.0 ** -18)
-    want = np.minimum(V.numpy().astype(np.float64), 65504.0)
-    big = want >= 6.2e-5                                # fp16's normal range
-    assert np.all(np.abs(got[big] - want[big]) <= want[big] * 2.0 ** -19 * 1.01)
-    assert np.all(np.abs(got[~big] - want[~big]) <= 6.0e-8)
-    assert got[0, 0] == 0.0 and got[0, 1] == 1.0 and got[0, 2] == 65504.0 and got[0, 3] == 65504.0
+    raw = xp.cpu().numpy().astype(np.uint32)
+    m, k = np.meshgrid(np.arange(N), np.arange(C), indexing='ij')
+    mb, ml = m // 128, m % 128
+    w, j = ml // 32, ml % 32
+    kt, kl = k // 64, k % 64
+    hl, i = kl // 32, kl % 32                        # element i of this lane's 32 columns
+    lane = hl * 32 + j
+    base = ((mb * (C // 64) + kt) * 4 + w) * 6       # first of this wave-tile's six 1-KiB chunk rows
+    hoff = ((base + i // 8) * 64 + lane) * 16 + 2 * (i % 8)
+    roff = ((base + 4 + i // 16) * 64 + lane) * 16 + (i % 16)
+    got = (raw[hoff + 1] << 24) | (raw[hoff] << 16) | (raw[roff] << 8)
+    bits = V.numpy().view(np.uint32).astype(np.uint64)
+    want = (bits + 0x7f + ((bits >> 8) & 1)) & 0xffffff00
+    want[0, 8] = 0x7f7fff00
+    assert np.array_equal(got.astype(np.uint64), want)
+    dec = got.astype(np.uint32).view(np.float32).astype(np.float64)
+    ref = V.numpy().astype(np.float64)
+    assert np.all(np.abs(dec - ref) <= np.maximum(ref * 2.0 ** -16, 2.0 ** -142))
+    assert dec[0, 0] == 0.0 and dec[0, 1] == 1.0 and dec[0, 2] == 65504.0 and int(flags[0]) == 0
 
 
 def test_auto_precision_policy(dev, monkeypatch):
