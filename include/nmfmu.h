@@ -272,6 +272,31 @@ int nmfmu_trainer_update(float* f, int rows, int cols, const float* neg, const f
  */
 int nmfmu_loss_part_count(int owner_rows_pad, int block_rows, int nsplit);
 int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream);
+/* (ABI 9) nmfmu_loss + everything else a loss checkpoint of the fit loop needs, in two launches: out2[0] = the same value
+ * nmfmu_loss writes (same kernels, same summation order), out2[1] = 1.0 when bit 0 of st->status is set (a factor left fp16's
+ * range; 0.0 without a status word), and the two factors' fp32 masters fa / fb (na / nb floats, multiples of 4, 16-byte
+ * aligned) copied into fa_snap / fb_snap -- the snapshot a deferred stop decision rolls back to (nmf.py:393-407 judged one
+ * checkpoint late). */
+/* (ABI 9) "riding loss": the periodic KL loss of the fit loop (nmf.py:400-401) WITHOUT its own pass over the target.
+ * metrics.py:22 is  target @ (log(target + eps) - log(input + eps)) - target.sum() + input.sum():
+ *   nmfmu_target_sums        once per fit: out2 = { sum x ln(x + eps), sum x } of the fp32 target (part: 2 * nmfmu_target_sums_nparts()
+ *                            doubles of scratch)
+ *   nmfmu_mu_step_with_loss  the half-step that FOLLOWS a checkpoint (= nmfmu_mu_step(st, kl_den, 0, ..)), its kernel also
+ *                            accumulating sum x log2(s) and sum s over its elements -- s = owner panel^T + eps is the reconstruction
+ *                            of the factors before the update, i.e. the input the reference evaluates, from the same operand
+ *                            images nmfmu_loss reads -- into xlogs_part (nmfmu_riding_loss_part_count() floats), then
+ *                            out2 = { loss, fp16-range flag } (device doubles, as nmfmu_loss_checkpoint).  The caller snapshots
+ *                            the factors at the checkpoint itself (they are the ones this loss belongs to)
+ * nmfmu_riding_loss_supported: beta == 1 on the ping-pong kernel, fp16 operands (NMFMU_PREC_F16 / F16R), the buffers of
+ * nmfmu_mu_step present.  Three VALU instructions per element on the half-steps that carry it. */
+int nmfmu_riding_loss_supported(const nmfmu_step* st);
+int nmfmu_riding_loss_part_count(const nmfmu_step* st);
+int nmfmu_target_sums_nparts(void);
+int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out2, void* stream);
+int nmfmu_mu_step_with_loss(const nmfmu_step* st, const float* kl_den, float* xlogs_part, const double* target_sums,
+                            double* out2, void* stream);
+int nmfmu_loss_checkpoint(const nmfmu_step* st, float* loss_part, double* out2, const float* fa, float* fa_snap, int64_t na,
+                          const float* fb, float* fb_snap, int64_t nb, void* stream);
 
 /* nmfmu_beta_div: metrics.beta_div(x, y, beta) on two plain fp32 device arrays of n elements.
  * part: 1024 doubles of scratch. */

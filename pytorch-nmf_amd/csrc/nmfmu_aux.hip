@@ -419,6 +419,120 @@ int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// loss checkpoint of fit() in ONE launch behind the loss kernel (round 6): block 0 = sum_finalize_kernel's fixed-order sum
+// of the partials (the same value, bit for bit) into out[0] and the fp16-range flag (bit 0 of the step's status word)
+// into out[1]; every block copies its share of the two factors into their snapshots (what rollback() restores when the
+// stop rule of nmf.py:405 turns out to have fired at this checkpoint).  Replaces the finalize launch, five small torch
+// launches and two copies per checkpoint.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) checkpoint_kernel(const float* __restrict__ part, int n, const uint32_t* __restrict__ status,
+                                                         double* __restrict__ out, const float4* __restrict__ a,
+                                                         float4* __restrict__ a_snap, int64_t na4, const float4* __restrict__ b,
+                                                         float4* __restrict__ b_snap, int64_t nb4) {
+  if (blockIdx.x == 0) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out[0] = red[0];
+      out[1] = (status && (*status & 1u)) ? 1.0 : 0.0;
+    }
+  }
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4; i += stride) a_snap[i] = a[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb4; i += stride) b_snap[i] = b[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// "riding loss" (round 6): fit()'s periodic KL loss without its own pass over V (reference: nmf.py:400-401 evaluates
+// kl_div(H W^T, V), metrics.py:22 = target @ (log(target + eps) - log(input + eps)) - target.sum() + input.sum()).
+//   A = sum x ln(x + eps), C = sum x        target_sums_kernel, once per fit (V does not change)
+//   B = ln 2 * sum x log2(s + eps), D = sum s - (count) eps
+//                                           accumulated by the NEXT W half-step's kernel (its s is this iteration's H W^T + eps,
+//                                           from the same operand images the loss pass would read)
+//   loss = A - B - C + D                    riding_finish_kernel
+// (sum(H W^T) from the masters' column sums instead of D costs one VALU less per element, but differs from the images' sum by
+// their rounding: 2e-5 of the loss at 300 x 1000 -- measured, and too close to the stop rule's 1e-4.)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) target_sums_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
+                                                          double* __restrict__ part) {
+  __shared__ double red[2][4];
+  double a = 0.0, c = 0.0;
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = ld == cols ? v[i] : v[(i / cols) * ld + (i % cols)];
+    a += (double)(x * (__builtin_amdgcn_logf(x + kEps) * 0.6931471805599453f));
+    c += (double)x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64), c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a, red[1][threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__global__ void __launch_bounds__(256) target_sums_finalize_kernel(const double* __restrict__ part, int n, double* __restrict__ out2) {
+  __shared__ double red[2][256];
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[2 * i], c += part[2 * i + 1];
+  red[0][threadIdx.x] = a, red[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o], red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out2[0] = red[0][0], out2[1] = red[1][0];
+}
+int launch_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, int nparts, double* out2, hipStream_t s) {
+  hipLaunchKernelGGL(target_sums_kernel, dim3(nparts), dim3(256), 0, s, v, ld, rows, cols, part);
+  hipLaunchKernelGGL(target_sums_finalize_kernel, dim3(1), dim3(256), 0, s, part, nparts, out2);
+  return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) riding_finish_kernel(const float* __restrict__ part, int npairs, const double* __restrict__ ac,
+                                                            double n_all, const uint32_t* __restrict__ status,
+                                                            double* __restrict__ out2) {
+  // part: pairs { sum x log2(s), sum s } per wave (s = reconstruction + eps, over EVERY processed element: n_all of them,
+  // padding rows / columns hold x = 0 and s = eps)
+  __shared__ double red[2][256];
+  double b = 0.0, d = 0.0;
+  for (int i = threadIdx.x; i < npairs; i += 256) b += (double)part[2 * i], d += (double)part[2 * i + 1];
+  red[0][threadIdx.x] = b, red[1][threadIdx.x] = d;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o], red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = ((ac[0] - red[0][0] * 0.6931471805599453) - ac[1]) + (red[1][0] - n_all * (double)kEps);
+    out2[1] = (status && (*status & 1u)) ? 1.0 : 0.0;
+  }
+}
+int launch_riding_finish(const float* part, int npairs, const double* ac, double n_all, const uint32_t* status, double* out2,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(riding_finish_kernel, dim3(1), dim3(256), 0, s, part, npairs, ac, n_all, status, out2);
+  return (int)hipGetLastError();
+}
+
+int launch_checkpoint(const float* part, int n, const uint32_t* status, double* out, const float* a, float* a_snap, int64_t na,
+                      const float* b, float* b_snap, int64_t nb, hipStream_t s) {
+  const int64_t work = (na + nb) / 4;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((work + 256 * 8 - 1) / (256 * 8), 2048));
+  hipLaunchKernelGGL(checkpoint_kernel, dim3(grid), dim3(256), 0, s, part, n, status, out, reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<float4*>(a_snap), na / 4, reinterpret_cast<const float4*>(b),
+                     reinterpret_cast<float4*>(b_snap), nb / 4);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // metrics.beta_div(x, y, beta) on plain arrays (metrics.py:60-96): the public metric, not the fit hot loop.
 // ------------------------------------------------------------------------------------------------------------
 template <int BETA>

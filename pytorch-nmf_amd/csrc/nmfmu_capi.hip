@@ -154,7 +154,8 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
 #ifdef NMFMU_DEBUG_HOOKS
     if (mode == kModeMU && g_pp_debug) a.debug = g_pp_debug;
 #endif
-    return launch_pp(st->r_pad, is_f16(st->precision) ? kOpF16 : kOpBf16, mode, a, grid, s, st->precision == NMFMU_PREC_F16R);
+    return launch_pp(st->r_pad, is_f16(st->precision) ? kOpF16 : kOpBf16, mode, a, grid, s, st->precision == NMFMU_PREC_F16R,
+                     /*riding loss*/ mode == kModeMU && loss_part != nullptr);
   }
   if (mode == kModeMU && sp_eligible(st->r_pad, st->precision, st->beta)) {
     a.tiles_per_split = (a.tiles_per_split + 3) & ~3;   // its tile loop runs in groups of four (ring slot = tile & 3)
@@ -475,6 +476,47 @@ int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream
   int e = fused_dispatch(st, kModeLoss, loss_part, st->owner.rows, st->panel.rows, S(stream));
   if (e) return e;
   return launch_sum_finalize_f32(loss_part, (st->owner.rows_pad / st->block_rows) * st->nsplit, out, S(stream));
+}
+
+int nmfmu_loss_checkpoint(const nmfmu_step* st, float* loss_part, double* out2, const float* fa, float* fa_snap, int64_t na,
+                          const float* fb, float* fb_snap, int64_t nb, void* stream) {
+  if (!st || !loss_part || !out2 || !fa || !fa_snap || !fb || !fb_snap || na < 0 || nb < 0 || (na & 3) || (nb & 3)) return NMFMU_ERR_ARG;
+  if (!nmfmu_supported(st->r_pad, st->precision)) return NMFMU_ERR_UNSUPPORTED;
+  int e = fused_dispatch(st, kModeLoss, loss_part, st->owner.rows, st->panel.rows, S(stream));
+  if (e) return e;
+  return launch_checkpoint(loss_part, (st->owner.rows_pad / st->block_rows) * st->nsplit, st->status, out2, fa, fa_snap, na, fb,
+                           fb_snap, nb, S(stream));
+}
+
+int nmfmu_riding_loss_supported(const nmfmu_step* st) {
+  // the half-steps whose kernel can carry the loss term: beta == 1 on the ping-pong kernel with fp16 operands (either target
+  // width); unsplit contraction (fused apply) or split (partial sums + apply kernel) alike
+  if (!st || !st->xp || st->block_rows != 256 || !pp_eligible(st->r_pad, st->precision, st->beta) || !is_f16(st->precision)) return 0;
+  if (st->stage == NMFMU_STAGE_DMA_SPLIT || st->nsplit < 1 || !st->slab_num) return 0;
+  return st->owner.f && st->owner.colsum ? 1 : 0;
+}
+int nmfmu_riding_loss_part_count(const nmfmu_step* st) {
+  return nmfmu_riding_loss_supported(st) ? 16 * (st->owner.rows_pad / st->block_rows) * st->nsplit : NMFMU_ERR_UNSUPPORTED;
+}
+int nmfmu_target_sums_nparts(void) { return 1024; }
+int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out2, void* stream) {
+  if (!v || !part || !out2 || rows <= 0 || cols <= 0 || ld < cols) return NMFMU_ERR_ARG;
+  return launch_target_sums(v, ld, rows, cols, part, nmfmu_target_sums_nparts(), out2, S(stream));
+}
+int nmfmu_mu_step_with_loss(const nmfmu_step* st, const float* kl_den, float* xlogs_part, const double* target_sums,
+                            double* out2, void* stream) {
+  if (!st || !kl_den || !xlogs_part || !target_sums || !out2) return NMFMU_ERR_ARG;
+  if (!nmfmu_riding_loss_supported(st)) return NMFMU_ERR_UNSUPPORTED;
+  // (the same two launches as nmfmu_mu_step(st, kl_den, 0, stream), the first one on the kernel instance that also accumulates)
+  const bool fuse = st->nsplit == 1 && st->owner.p2_hi && st->owner.colsum_part;
+  int e = fuse ? fused_dispatch(st, kModeMU, xlogs_part, st->owner.rows, st->panel.rows, S(stream), kl_den, true)
+               : fused_dispatch(st, kModeMU, xlogs_part, st->owner.rows, st->panel.rows, S(stream));
+  if (e) return e;
+  e = fuse ? launch_colsum_finalize(st->owner.colsum_part, st->owner.rows_pad / st->block_rows, st->r_pad, st->owner.colsum, S(stream))
+           : nmfmu_mu_apply(st, nullptr, nullptr, 0, kl_den, stream);
+  if (e) return e;
+  return launch_riding_finish(xlogs_part, nmfmu_riding_loss_part_count(st) / 2, target_sums,
+                              (double)st->owner.rows_pad * (double)st->panel.rows_pad, st->status, out2, S(stream));
 }
 
 int nmfmu_beta_div(const float* x, const float* y, int64_t n, float beta, double* part, double* out, void* stream) {

@@ -74,7 +74,7 @@
 
 namespace nmfmu {
 
-template <int R_PAD, int OPT, int MODE, bool XR_ = false>
+template <int R_PAD, int OPT, int MODE, bool XR_ = false, bool LACC_ = false>
 struct PPCfg {
   static constexpr int BM = 256, WAVES = 8, THREADS = 512;
   static constexpr int KS = R_PAD / 16;      // k-steps of G1 (contraction over rank)
@@ -88,6 +88,13 @@ struct PPCfg {
   static constexpr int NX = XR ? 6 : 4;      // 16-byte X chunks per lane per tile
   static constexpr int XTILE = BM * kBK * (XR ? 3 : 2);   // one X tile: 256 rows x 64 columns x 2 (3) bytes = 32 (48) KiB
   static_assert(!XR || OPT == kOpF16, "the 3-byte target comes with fp16 operands");
+  // "riding loss" (round 6, fit()'s periodic loss without its own pass over V): the MU half-step also accumulates
+  // sum x log2(s) over its elements -- s = owner panel^T + eps is the reconstruction of the factors BEFORE this update, i.e. the
+  // KL term of the iteration just finished that needs V (metrics.py:22: target @ log(input + eps)) -- and sum s (input.sum() +
+  // eps per element, padding included: the host subtracts the count); 8 pairs of partials per workgroup into a.loss_part.
+  // Three VALU per element (v_log_f32, fused multiply-add, add) on the half-steps that carry it.
+  static constexpr bool LACC = LACC_;
+  static_assert(!LACC || (OPT == kOpF16 && MODE == kModeMU), "riding loss: fp16 operands, MU half-step");
   static constexpr bool XM = (NMFMU_PP_DUP & (4 | 32)) ? false : (NMFMU_PP_XM < 0 ? XR : NMFMU_PP_XM != 0);   // X loads in the M segment
   static constexpr int P1_BASE = 0, P2_BASE = NSLOT * IMG;
   static constexpr int LDS_MAIN = 2 * NSLOT * IMG;
@@ -101,9 +108,9 @@ struct PPCfg {
   static_assert(NSTEP1 >= PF, "ring deeper than G1");
 };
 
-template <int R_PAD, int OPT, int MODE, bool XR = false>
+template <int R_PAD, int OPT, int MODE, bool XR = false, bool LACC = false>
 __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
-  using C = PPCfg<R_PAD, OPT, MODE, XR>;
+  using C = PPCfg<R_PAD, OPT, MODE, XR, LACC>;
   constexpr int NX = C::NX;
   constexpr int KS = C::KS, RT = C::RT, ROWB = C::ROWB, IMG = C::IMG, PF = C::PF;
   constexpr int NSTEP1 = C::NSTEP1, NSTEP2 = C::NSTEP2;
@@ -210,6 +217,8 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   for (int e = 0; e < 16; ++e) epsv[e] = SCALED ? 1.0f : kEps;
   if constexpr (!SCALED) asm volatile("" : "+v"(epsv));
   float lacc = 0.f;
+  float la[4] = {0.f, 0.f, 0.f, 0.f};   // riding loss: four independent chains of sum x log2(s) ...
+  float ls[4] = {0.f, 0.f, 0.f, 0.f};   // ... and of sum s (the SAME s: consistent with the loss pass to the last bit of the images)
 
   if (nt > 0) {
     // ---- address generators.  All bases are wave-uniform (SGPR); the per-lane part is a 32-bit offset.
@@ -553,6 +562,25 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
                   "v"(uw), "s"(0x0504000cu), "s"(0x0706010cu), "s"(0x0504020cu), "s"(0x0706030cu));
             gn[tt][d] = g0;
             gn[tt][d + 1] = g1;
+            if constexpr (C::LACC) {   // y0..y3 = the four targets in fp32 (the v_perm_b32 results above)
+              float l0, l1, l2, l3;
+              asm("v_log_f32 %4, %12\n\t"
+                  "v_log_f32 %5, %13\n\t"
+                  "v_log_f32 %6, %14\n\t"
+                  "v_log_f32 %7, %15\n\t"
+                  "v_fma_f32 %0, %16, %4, %0\n\t"
+                  "v_fma_f32 %1, %17, %5, %1\n\t"
+                  "v_fma_f32 %2, %18, %6, %2\n\t"
+                  "v_fma_f32 %3, %19, %7, %3\n\t"
+                  "v_add_f32 %8, %8, %12\n\t"
+                  "v_add_f32 %9, %9, %13\n\t"
+                  "v_add_f32 %10, %10, %14\n\t"
+                  "v_add_f32 %11, %11, %15"
+                  : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "+v"(ls[0]),
+                    "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3])
+                  : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(y0), "v"(y1),
+                    "v"(y2), "v"(y3));
+            }
           }
         } else if constexpr (OPT == kOpF16) {
           // four elements per statement: 4 x v_rcp_f32, 4 x v_fma_mix_f32 (fp16 half of the X word x fp32
@@ -603,6 +631,24 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #endif
             gn[tt][d] = g0;
             gn[tt][d + 1] = g1;
+            if constexpr (C::LACC) {   // sum x log2(s): the fp16 half of the stored word times the fp32 logarithm, one mixed FMA
+              float l0, l1, l2, l3;
+              asm("v_log_f32 %4, %12\n\t"
+                  "v_log_f32 %5, %13\n\t"
+                  "v_log_f32 %6, %14\n\t"
+                  "v_log_f32 %7, %15\n\t"
+                  "v_fma_mix_f32 %0, %16, %4, %0 op_sel_hi:[1,0,0]\n\t"
+                  "v_fma_mix_f32 %1, %16, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                  "v_fma_mix_f32 %2, %17, %6, %2 op_sel_hi:[1,0,0]\n\t"
+                  "v_fma_mix_f32 %3, %17, %7, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                  "v_add_f32 %8, %8, %12\n\t"
+                  "v_add_f32 %9, %9, %13\n\t"
+                  "v_add_f32 %10, %10, %14\n\t"
+                  "v_add_f32 %11, %11, %15"
+                  : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "+v"(ls[0]),
+                    "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3])
+                  : "v"(S[tt][2 * d]), "v"(S[tt][2 * d + 1]), "v"(S[tt][2 * d + 2]), "v"(S[tt][2 * d + 3]), "v"(w0), "v"(w1));
+            }
           }
         } else {
 #pragma unroll
@@ -696,6 +742,12 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
 #endif
   }
   __syncthreads();               // LDS is reused by the epilogue
+  if constexpr (C::LACC) {       // riding loss: one partial per wave, [8 * workgroup + wave] (no LDS, no barrier)
+    float lsum = (la[0] + la[1]) + (la[2] + la[3]), ssum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64), ssum += __shfl_xor(ssum, o, 64);
+    if (lane == 0) a.loss_part[16 * blockIdx.x + 2 * wave] = lsum, a.loss_part[16 * blockIdx.x + 2 * wave + 1] = ssum;
+  }
 
   // The epilogue re-derives its lane coordinates from a laundered copy of the thread id: otherwise hipcc hoists the
   // epilogue's address arithmetic above the main loop and keeps it live across it (the loop has no registers to spare).
@@ -881,11 +933,11 @@ __global__ void __launch_bounds__(512, 2) pp_kernel(const FusedArgs a) {
   }
 }
 
-template <int R_PAD, int OPT, int MODE, bool XR = false>
+template <int R_PAD, int OPT, int MODE, bool XR = false, bool LACC = false>
 int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
-  using C = PPCfg<R_PAD, OPT, MODE, XR>;
+  using C = PPCfg<R_PAD, OPT, MODE, XR, LACC>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
-  auto kern = pp_kernel<R_PAD, OPT, MODE, XR>;
+  auto kern = pp_kernel<R_PAD, OPT, MODE, XR, LACC>;
   static bool done[64] = {};
   bool* flag = attr_flag(done);
   if (!*flag) {
@@ -899,7 +951,7 @@ int launch_pp_one(const FusedArgs& a, int grid, hipStream_t s) {
 }
 
 // Host-side launcher (nmfmu_inst_pp.hip).  opt = OperandType, mode = kModeMU | kModeLoss.
-int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s, bool xr = false);
+int launch_pp(int r_pad, int opt, int mode, const FusedArgs& a, int grid, hipStream_t s, bool xr = false, bool lacc = false);
 bool pp_available(int r_pad, int opt, int mode);
 
 }  // namespace nmfmu

@@ -100,6 +100,13 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     'nmfmu_loss_part_count': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'nmfmu_loss': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_riding_loss_supported': (C.c_int, [C.POINTER(Step)]),
+    'nmfmu_riding_loss_part_count': (C.c_int, [C.POINTER(Step)]),
+    'nmfmu_target_sums_nparts': (C.c_int, []),
+    'nmfmu_target_sums': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_mu_step_with_loss': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nmfmu_loss_checkpoint': (C.c_int, [C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
     'nmfmu_beta_div': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_mu_terms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nmfmu_trainer_update': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,

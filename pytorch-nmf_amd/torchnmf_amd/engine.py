@@ -171,6 +171,30 @@ class HipBackend:
     def loss(self, st, loss_part, out):
         _capi.check(self.lib.nmfmu_loss(C.byref(st.struct), _ptr(loss_part), _ptr(out), self.stream()), 'nmfmu_loss')
 
+    # -- "riding loss" (include/nmfmu.h): fit()'s periodic KL loss carried by the next W half-step's kernel
+    def riding_supported(self, st) -> bool:
+        return self.lib.nmfmu_riding_loss_supported(C.byref(st.struct)) == 1
+
+    def riding_alloc(self, st, device):
+        n = self.lib.nmfmu_riding_loss_part_count(C.byref(st.struct))
+        return (torch.empty(n, dtype=torch.float32, device=device),
+                torch.empty(2 * self.lib.nmfmu_target_sums_nparts(), dtype=torch.float64, device=device),
+                torch.zeros(2, dtype=torch.float64, device=device))          # [sum x ln(x + eps), sum x]
+
+    def target_sums(self, V, part, out2):
+        _capi.check(self.lib.nmfmu_target_sums(_ptr(V), V.stride(0), V.shape[0], V.shape[1], _ptr(part), _ptr(out2), self.stream()),
+                    'nmfmu_target_sums')
+
+    def mu_step_with_loss(self, st, kl_den, xlogs_part, target_sums, out2):
+        _capi.check(self.lib.nmfmu_mu_step_with_loss(C.byref(st.struct), _ptr(kl_den), _ptr(xlogs_part), _ptr(target_sums),
+                                                     _ptr(out2), self.stream()), 'nmfmu_mu_step_with_loss')
+
+    def loss_checkpoint(self, st, loss_part, out2, fa, fa_snap, fb, fb_snap):
+        """nmfmu_loss + the rest of a fit() loss checkpoint in two launches: out2 = (loss, fp16-range flag), factor snapshots."""
+        _capi.check(self.lib.nmfmu_loss_checkpoint(C.byref(st.struct), _ptr(loss_part), _ptr(out2), _ptr(fa), _ptr(fa_snap),
+                                                   fa.numel(), _ptr(fb), _ptr(fb_snap), fb.numel(), self.stream()),
+                    'nmfmu_loss_checkpoint')
+
 
 class _Comm:
     """Owner of an nmfmu_comm handle (destroyed with the engine)."""
@@ -344,18 +368,33 @@ class AsyncLossMixin:
                         'stage': torch.zeros(2, dtype=torch.float64, device=tens[0].device),
                         'ev': torch.cuda.Event() if on_gpu else None}
         ck = self._ck
-        ck['stage'][0:1].copy_(self._loss_device())
-        flag = self._range_flag_device()
-        if flag is not None:
-            ck['stage'][1:2].copy_(flag)
-        ck['host'].copy_(ck['stage'], non_blocking=True)
-        for s_, t_ in zip(ck['snap'], tens):
-            s_.copy_(t_)
+        if self._checkpoint_riding(ck, tens):      # the loss rides in the next W half-step (round 6): nothing else to launch now
+            return
+        if self._checkpoint_fused(ck['stage'], tens, ck['snap']):     # loss + flag + snapshots in two launches (round 6)
+            ck['host'].copy_(ck['stage'], non_blocking=True)
+        else:
+            ck['stage'][0:1].copy_(self._loss_device())
+            flag = self._range_flag_device()
+            if flag is not None:
+                ck['stage'][1:2].copy_(flag)
+            ck['host'].copy_(ck['stage'], non_blocking=True)
+            for s_, t_ in zip(ck['snap'], tens):
+                s_.copy_(t_)
         if ck['ev'] is not None:
             ck['ev'].record()
 
+    def _checkpoint_fused(self, stage, tens, snaps) -> bool:
+        """Engines whose backend has a one-call checkpoint override this; False = take the generic sequence above."""
+        return False
+
+    def _checkpoint_riding(self, ck, tens) -> bool:
+        """Engines that can let the NEXT half-step carry the loss override this: True = snapshots taken, the loss value, the
+        host copy and the event follow with that half-step."""
+        return False
+
     def checkpoint_result(self):
         """(divergence, left_f16_range) of the last ``checkpoint_begin``."""
+        assert not getattr(self, '_riding_pending', False), 'the half-step that carries the loss has not run'
         if self._ck['ev'] is not None:
             self._ck['ev'].synchronize()
         return float(self._ck['host'][0]), bool(self._ck['host'][1] != 0)
@@ -528,6 +567,14 @@ class DenseMU(AsyncLossMixin):
         self.refresh_images()
         self.loss_part = torch.empty(max((n_pad // br) * ns_h, 1), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        # "riding loss" (round 6): unsharded beta == 1 fits on the ping-pong kernel let the W half-step that follows a loss
+        # checkpoint carry the checkpoint's loss (its reconstruction IS the one nmf.py:400-401 evaluates): no pass over V
+        self._riding = None
+        self._riding_pending = False
+        if (group is None and self.kl and self.step_w is not None and update_H and hasattr(self.be, 'riding_supported')
+                and os.environ.get('TORCHNMF_AMD_RIDING_LOSS', '1') != '0' and V.dtype == torch.float32 and V.stride(1) == 1
+                and self.be.riding_supported(self.step_w)):
+            self._riding = {'V': V, 'bufs': None}       # (target sums: computed at the first checkpoint, once)
         if group is not None:
             # [numerator | denominator (N x R for beta != 1, else R column sums)] -> ONE all-reduce per iteration
             tail = self.r_pad if self.kl else self.step_h.plane
@@ -656,6 +703,15 @@ class DenseMU(AsyncLossMixin):
         """nmf.py:367-378.  Local even when sharded: W rows belong to this rank's columns."""
         if self.gram_path:
             return self._gram_step(self.step_w, 'w')
+        if self._riding_pending:      # this half-step carries the loss of the checkpoint just begun (AsyncLossMixin)
+            self._riding_pending = False
+            part, _, sums = self._riding['bufs']
+            ck = self._ck
+            self.be.mu_step_with_loss(self.step_w, self.fH.colsum, part, sums, ck['stage'])
+            ck['host'].copy_(ck['stage'], non_blocking=True)
+            if ck['ev'] is not None:
+                ck['ev'].record()
+            return
         self._local_step(self.step_w, self.fH.colsum if self.kl else None, 'w')
 
     def h_step(self):
@@ -741,6 +797,29 @@ class DenseMU(AsyncLossMixin):
         if self.precision not in self._F16_MODES:
             return None
         return (self.status & 1).double()
+
+    def _checkpoint_riding(self, ck, tens) -> bool:
+        rd = self._riding
+        if (rd is None or len(tens) != 2
+                or any(t.numel() % 4 or t.data_ptr() % 16 or not t.is_contiguous() for t in list(tens) + list(ck['snap']))):
+            return False
+        if rd['bufs'] is None:
+            rd['bufs'] = self.be.riding_alloc(self.step_w, tens[0].device)
+            self.be.target_sums(rd['V'], rd['bufs'][1], rd['bufs'][2])
+            rd['V'] = None                                  # (the engine does not keep the caller's target alive)
+        # snapshots of (W, H) as they are now; the W half-step that follows does the rest
+        for s_, t_ in zip(ck['snap'], tens):
+            s_.copy_(t_)
+        self._riding_pending = True
+        return True
+
+    def _checkpoint_fused(self, stage, tens, snaps) -> bool:
+        if (not hasattr(self.be, 'loss_checkpoint') or len(tens) != 2 or os.environ.get('TORCHNMF_AMD_FUSED_CHECKPOINT', '1') == '0'
+                or any(t.numel() % 4 or t.data_ptr() % 16 or not t.is_contiguous() for t in list(tens) + list(snaps))):
+            return False
+        # (status is only wired into the step structs of the fp16 modes' engines; other precisions never set bit 0)
+        self.be.loss_checkpoint(self.step_h, self.loss_part, stage, tens[0], snaps[0], tens[1], snaps[1])
+        return True
 
     def _ckpt_tensors(self):
         return [self.fW.f, self.fH.f]

@@ -640,6 +640,96 @@ def test_fit_g3_early_stop(dev, beta):
     assert rel_err(m.W.data.cpu(), g[f'b{beta}_W']) < TOL and rel_err(m.H.data.cpu(), g[f'b{beta}_H']) < TOL
 
 
+@pytest.mark.parametrize('prec,beta,shape', [('f16', 1, (512, 768, 20)), ('bf16x3', 0.5, (300, 520, 12)), ('f16r', 1, (301, 333, 5)),
+                                             ('f16', 2, (512, 768, 20))])
+def test_fused_loss_checkpoint_equals_the_generic_sequence(dev, monkeypatch, prec, beta, shape):
+    """Round 6: a loss checkpoint of fit() is the loss kernel + ONE launch (nmfmu_loss_checkpoint: fixed-order sum of the
+    partials, fp16-range flag, snapshots of both factors) instead of the loss's two launches, five small torch launches and
+    two copies.  Same loss bit for bit, same flag, same snapshots, same rollback; factors whose size is not a multiple of
+    four floats take the generic sequence (third case); fit() returns the same count and factors either way."""
+    from torchnmf_amd.engine import DenseMU
+    from torchnmf_amd.nmf import NMF
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + R)
+    V = (torch.rand(N, C, generator=g) + 0.01).to(dev)
+    W0, H0 = torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1
+    out = {}
+    monkeypatch.setenv('TORCHNMF_AMD_RIDING_LOSS', '0')     # (beta == 1 on the ping-pong kernel would not make a loss pass at all)
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_FUSED_CHECKPOINT', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = DenseMU(V, W, H, float(beta), precision=prec, allow_gram=(beta == 2))
+        took = []
+        orig = eng._checkpoint_fused
+        eng._checkpoint_fused = lambda *a: took.append(orig(*a)) or took[-1]
+        for _ in range(3):
+            eng.w_step(), eng.h_step()
+        eng.checkpoint_begin()
+        Wk, Hk = W.clone(), H.clone()
+        for _ in range(2):
+            eng.w_step(), eng.h_step()
+        div, left = eng.checkpoint_result()
+        sync = eng.divergence()
+        eng.rollback()
+        torch.cuda.synchronize()
+        assert torch.equal(W, Wk) and torch.equal(H, Hk)
+        assert took == [mode == '1' and (C * R) % 4 == 0 and (N * R) % 4 == 0]
+        assert eng.divergence() == div and sync < div and not left
+        out[mode] = (div, W.cpu().clone(), H.cpu().clone())
+    assert out['1'][0] == out['0'][0] and torch.equal(out['1'][1], out['0'][1]) and torch.equal(out['1'][2], out['0'][2])
+    fits = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_FUSED_CHECKPOINT', mode)
+        m = NMF(W=W0.clone(), H=H0.clone()).to(dev)
+        fits[mode] = (m.fit(V, beta, 2e-3, 120, precision=prec), m.W.data.cpu().clone(), m.H.data.cpu().clone())
+    assert fits['1'][0] == fits['0'][0] and fits['1'][0] < 120
+    assert torch.equal(fits['1'][1], fits['0'][1]) and torch.equal(fits['1'][2], fits['0'][2])
+
+
+@pytest.mark.parametrize('prec,shape', [('f16', (300, 1000, 20)), ('f16r', (300, 1000, 20)), ('f16', (1024, 2048, 64)),
+                                        ('f16r', (2048, 4096, 128)), ('f16', (4096, 16384, 100))])
+def test_riding_loss_equals_the_loss_pass(dev, monkeypatch, prec, shape):
+    """Round 6: on unsharded beta == 1 fits served by the ping-pong kernel the loss of a checkpoint is not a
+    pass over V any more -- the W half-step that FOLLOWS the checkpoint accumulates sum x log2(s + eps) (its reconstruction is
+    the one nmf.py:400-401 evaluates), the other three sums of metrics.py:22 come from the target (once) and the factors'
+    column sums.  Same value as the loss pass on the checkpoint's factors (<= 2e-6 relative: fp32 partial sums in another
+    order), bit-identical factors from the carrying half-step, same stop iteration and factors from fit()."""
+    from torchnmf_amd.engine import DenseMU
+    from torchnmf_amd.nmf import NMF
+    N, C, R = shape
+    g = torch.Generator().manual_seed(N + R)
+    V = torch.rand(N, C, generator=g) * torch.rand(N, 1, generator=g)
+    V = (V.half().float() if prec == 'f16' else V).to(dev)
+    W0, H0 = torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_RIDING_LOSS', mode)
+        W, H = W0.clone().to(dev), H0.clone().to(dev)
+        eng = DenseMU(V, W, H, 1.0, precision=prec)
+        assert (eng._riding is not None) == (mode == '1')
+        for _ in range(3):
+            eng.w_step(), eng.h_step()
+        eng.checkpoint_begin()
+        assert eng._riding_pending == (mode == '1')
+        eng.w_step(), eng.h_step()
+        W4, H4 = W.clone(), H.clone()
+        div, left = eng.checkpoint_result()
+        eng.rollback()
+        ref = eng.divergence()                     # the loss pass on the checkpoint's (restored) factors
+        assert abs(div - ref) <= 2e-6 * abs(ref) and not left, (div, ref)
+        res[mode] = (div, W4.cpu(), H4.cpu(), W.cpu().clone(), H.cpu().clone())
+    for i in (1, 2, 3, 4):
+        assert torch.equal(res['1'][i], res['0'][i])
+    record('riding_loss', prec=prec, shape=shape, riding=res['1'][0], loss_pass=res['0'][0])
+    fits = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TORCHNMF_AMD_RIDING_LOSS', mode)
+        m = NMF(W=W0.clone(), H=H0.clone()).to(dev)
+        fits[mode] = (m.fit(V, 1, 1e-3, 150, precision=prec), m.W.data.cpu().clone(), m.H.data.cpu().clone())
+    assert fits['1'][0] == fits['0'][0] and 10 < fits['1'][0] < 150
+    assert torch.equal(fits['1'][1], fits['0'][1]) and torch.equal(fits['1'][2], fits['0'][2])
+
+
 @pytest.mark.parametrize('beta', [1, 2])
 @pytest.mark.parametrize('name,tW,tH', [('frozenW', False, True), ('frozenH', True, False)])
 def test_fit_g4_frozen(dev, beta, name, tW, tH):
