@@ -18,6 +18,7 @@ prof() {  # name, bench args
   f=$(find $OUT/trace_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -4 $OUT/${name}_kernel_stats.csv | cut -c1-160
 }
 prof cfg1_f16
+prof cfg1_f16r --precision f16r
 prof cfg5_shard --config cfg5 --steps 6 --warmup 2
 prof beta05 --beta 0.5
 prof beta0 --beta 0
@@ -30,6 +31,7 @@ pmc() {  # name, bench args
   python $ROOT/tools/pmc_summary.py $OUT/pmc_$name > $OUT/${name}_pmc_summary.txt 2>&1; grep -A2 "pp_kernel\|sp_kernel\|sp2_kernel" $OUT/${name}_pmc_summary.txt | head -12
 }
 pmc cfg1_f16
+pmc cfg1_f16r --precision f16r
 pmc cfg5_shard --config cfg5 --steps 6 --warmup 2
 find $OUT -name "*.db" -delete; find $OUT -size +8M -delete; find $OUT -type d -name "trace_*" -exec rm -rf {} + 2>/dev/null; find $OUT -type d -name "pmc_*" -exec rm -rf {} + 2>/dev/null
 echo finished
