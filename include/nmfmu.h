@@ -279,8 +279,9 @@ int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream
  * checkpoint late). */
 /* (ABI 9) "riding loss": the periodic KL loss of the fit loop (nmf.py:400-401) WITHOUT its own pass over the target.
  * metrics.py:22 is  target @ (log(target + eps) - log(input + eps)) - target.sum() + input.sum():
- *   nmfmu_target_sums        once per fit: out2 = { sum x ln(x + eps), sum x } of the fp32 target (part: 2 * nmfmu_target_sums_nparts()
- *                            doubles of scratch)
+ *   nmfmu_target_sums        once per fit: out4 = { sum x ln(x + eps), sum x, max x, 1.0 if any x != fp16(x) else 0.0 } of the fp32
+ *                            target in ONE pass (part: 4 * nmfmu_target_sums_nparts() doubles of scratch); the last two are what a
+ *                            host needs to admit the fp16 modes (nmfmu_mu_step_with_loss reads the first two)
  *   nmfmu_mu_step_with_loss  the half-step that FOLLOWS a checkpoint (= nmfmu_mu_step(st, kl_den, 0, ..)), its kernel also
  *                            accumulating sum x log2(s) and sum s over its elements -- s = owner panel^T + eps is the reconstruction
  *                            of the factors before the update, i.e. the input the reference evaluates, from the same operand
@@ -292,7 +293,7 @@ int nmfmu_loss(const nmfmu_step* st, float* loss_part, double* out, void* stream
 int nmfmu_riding_loss_supported(const nmfmu_step* st);
 int nmfmu_riding_loss_part_count(const nmfmu_step* st);
 int nmfmu_target_sums_nparts(void);
-int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out2, void* stream);
+int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out4, void* stream);
 int nmfmu_mu_step_with_loss(const nmfmu_step* st, const float* kl_den, float* xlogs_part, const double* target_sums,
                             double* out2, void* stream);
 int nmfmu_loss_checkpoint(const nmfmu_step* st, float* loss_part, double* out2, const float* fa, float* fa_snap, int64_t na,

@@ -40,7 +40,7 @@ int launch_apply(int r_pad, const ApplyArgs& a, bool x3, bool pack_only, hipStre
 int launch_colsum_finalize(const float* part, int nblk, int r_pad, float* out, hipStream_t s);
 int launch_slab_reduce(const float* slab, int nslab, int64_t plane, float* out, hipStream_t s);
 int launch_sum_finalize_f32(const float* part, int n, double* out, hipStream_t s);
-int launch_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, int nparts, double* out2, hipStream_t s);
+int launch_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, int nparts, double* out4, hipStream_t s);
 int launch_riding_finish(const float* part, int npairs, const double* ac, double n_all, const uint32_t* status, double* out2,
                          hipStream_t s);
 int launch_checkpoint(const float* part, int n, const uint32_t* status, double* out, const float* a, float* a_snap, int64_t na,

@@ -452,7 +452,8 @@ __global__ void __launch_bounds__(256) checkpoint_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------
 // "riding loss" (round 6): fit()'s periodic KL loss without its own pass over V (reference: nmf.py:400-401 evaluates
 // kl_div(H W^T, V), metrics.py:22 = target @ (log(target + eps) - log(input + eps)) - target.sum() + input.sum()).
-//   A = sum x ln(x + eps), C = sum x        target_sums_kernel, once per fit (V does not change)
+//   A = sum x ln(x + eps), C = sum x        target_sums_kernel, once per fit (V does not change; the same pass answers the
+//                                           fp16 modes' admission questions: max x, any x fp16 does not hold)
 //   B = ln 2 * sum x log2(s + eps), D = sum s - (count) eps
 //                                           accumulated by the NEXT W half-step's kernel (its s is this iteration's H W^T + eps,
 //                                           from the same operand images the loss pass would read)
@@ -462,38 +463,57 @@ __global__ void __launch_bounds__(256) checkpoint_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) target_sums_kernel(const float* __restrict__ v, int64_t ld, int rows, int cols,
                                                           double* __restrict__ part) {
-  __shared__ double red[2][4];
+  // per block: { sum x ln(x + eps), sum x, max x, any(x != fp16(x)) } -- the last two are what the admission test of the
+  // fp16 modes asks about the target (engine.DenseMU.f16_stats), in the same single pass
+  __shared__ double red[4][4];
   double a = 0.0, c = 0.0;
+  float mx = 0.f;
+  int inexact = 0;
   const int64_t n = (int64_t)rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float x = ld == cols ? v[i] : v[(i / cols) * ld + (i % cols)];
     a += (double)(x * (__builtin_amdgcn_logf(x + kEps) * 0.6931471805599453f));
     c += (double)x;
+    mx = fmaxf(mx, x);
+    inexact |= ((float)(_Float16)x != x) ? 1 : 0;      // (NaN, and anything beyond 65504: inexact)
   }
+  double dm = (double)mx, di = (double)inexact;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64), c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a, red[1][threadIdx.x >> 6] = c;
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64), c += __shfl_xor(c, o, 64);
+    dm = fmax(dm, __shfl_xor(dm, o, 64)), di = fmax(di, __shfl_xor(di, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red[0][w] = a, red[1][w] = c, red[2][w] = dm, red[3][w] = di;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    part[4 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[4 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    part[4 * blockIdx.x + 2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    part[4 * blockIdx.x + 3] = fmax(fmax(red[3][0], red[3][1]), fmax(red[3][2], red[3][3]));
   }
 }
-__global__ void __launch_bounds__(256) target_sums_finalize_kernel(const double* __restrict__ part, int n, double* __restrict__ out2) {
-  __shared__ double red[2][256];
-  double a = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) a += part[2 * i], c += part[2 * i + 1];
-  red[0][threadIdx.x] = a, red[1][threadIdx.x] = c;
+__global__ void __launch_bounds__(256) target_sums_finalize_kernel(const double* __restrict__ part, int n, double* __restrict__ out4) {
+  __shared__ double red[4][256];
+  double a = 0.0, c = 0.0, m = 0.0, x = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[4 * i], c += part[4 * i + 1], m = fmax(m, part[4 * i + 2]), x = fmax(x, part[4 * i + 3]);
+  red[0][threadIdx.x] = a, red[1][threadIdx.x] = c, red[2][threadIdx.x] = m, red[3][threadIdx.x] = x;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o], red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o], red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + o]);
+      red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + o]);
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out2[0] = red[0][0], out2[1] = red[1][0];
+  if (threadIdx.x == 0) out4[0] = red[0][0], out4[1] = red[1][0], out4[2] = red[2][0], out4[3] = red[3][0];
 }
-int launch_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, int nparts, double* out2, hipStream_t s) {
+int launch_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, int nparts, double* out4, hipStream_t s) {
   hipLaunchKernelGGL(target_sums_kernel, dim3(nparts), dim3(256), 0, s, v, ld, rows, cols, part);
-  hipLaunchKernelGGL(target_sums_finalize_kernel, dim3(1), dim3(256), 0, s, part, nparts, out2);
+  hipLaunchKernelGGL(target_sums_finalize_kernel, dim3(1), dim3(256), 0, s, part, nparts, out4);
   return (int)hipGetLastError();
 }
 

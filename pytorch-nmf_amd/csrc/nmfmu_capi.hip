@@ -499,9 +499,9 @@ int nmfmu_riding_loss_part_count(const nmfmu_step* st) {
   return nmfmu_riding_loss_supported(st) ? 16 * (st->owner.rows_pad / st->block_rows) * st->nsplit : NMFMU_ERR_UNSUPPORTED;
 }
 int nmfmu_target_sums_nparts(void) { return 1024; }
-int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out2, void* stream) {
-  if (!v || !part || !out2 || rows <= 0 || cols <= 0 || ld < cols) return NMFMU_ERR_ARG;
-  return launch_target_sums(v, ld, rows, cols, part, nmfmu_target_sums_nparts(), out2, S(stream));
+int nmfmu_target_sums(const float* v, int64_t ld, int rows, int cols, double* part, double* out4, void* stream) {
+  if (!v || !part || !out4 || rows <= 0 || cols <= 0 || ld < cols) return NMFMU_ERR_ARG;
+  return launch_target_sums(v, ld, rows, cols, part, nmfmu_target_sums_nparts(), out4, S(stream));
 }
 int nmfmu_mu_step_with_loss(const nmfmu_step* st, const float* kl_den, float* xlogs_part, const double* target_sums,
                             double* out2, void* stream) {

@@ -177,9 +177,7 @@ class HipBackend:
 
     def riding_alloc(self, st, device):
         n = self.lib.nmfmu_riding_loss_part_count(C.byref(st.struct))
-        return (torch.empty(n, dtype=torch.float32, device=device),
-                torch.empty(2 * self.lib.nmfmu_target_sums_nparts(), dtype=torch.float64, device=device),
-                torch.zeros(2, dtype=torch.float64, device=device))          # [sum x ln(x + eps), sum x]
+        return torch.empty(n, dtype=torch.float32, device=device)
 
     def target_sums(self, V, part, out2):
         _capi.check(self.lib.nmfmu_target_sums(_ptr(V), V.stride(0), V.shape[0], V.shape[1], _ptr(part), _ptr(out2), self.stream()),
@@ -346,6 +344,22 @@ def mu_gamma(beta: float) -> float:
     return 1.0
 
 
+# One-entry memo of nmfmu_target_sums: the admission test of 'auto' and the riding loss of the engine built right after it ask
+# about the same target (keyed by storage, version counter and geometry, so an in-place edit of V invalidates it).
+TARGET_STATS = {'key': None, 'out4': None}
+
+
+def target_stats(V, be):
+    """Device float64[4] = {sum x ln(x + eps), sum x, max x, any(x != fp16(x))} of the fp32 target V (one pass)."""
+    key = (V.data_ptr(), V._version, tuple(V.shape), V.stride(0), V.device)
+    if TARGET_STATS['key'] != key:
+        part = torch.empty(4 * be.lib.nmfmu_target_sums_nparts(), dtype=torch.float64, device=V.device)
+        out4 = torch.zeros(4, dtype=torch.float64, device=V.device)
+        be.target_sums(V, part, out4)
+        TARGET_STATS['key'], TARGET_STATS['out4'] = key, out4
+    return TARGET_STATS['out4']
+
+
 class AsyncLossMixin:
     """Loss checkpoints of ``fit`` without a host sync (reference loop: nmf.py:393-407).
 
@@ -425,10 +439,19 @@ class DenseMU(AsyncLossMixin):
     F16_MIN_MEAN = 2.0 ** -10
 
     @classmethod
-    def f16_stats(cls, V, W, H):
+    def f16_stats(cls, V, W, H, be=None):
         """(in_range, exact): the data sit inside fp16's range with room for the ratios / V is exactly representable in
-        fp16.  Two passes over V (row chunks, so that the temporaries stay small next to V), one over W and H, one
-        host sync."""
+        fp16.  With a device backend: ONE pass over V (nmfmu_target_sums: max, fp16-exactness and the two sums the riding
+        loss needs later -- kept in TARGET_STATS for the engine built next), one over W and H, one host sync.  Otherwise
+        (the CPU test backend): two passes over V in row chunks, so that the temporaries stay small next to V."""
+        if (be is not None and hasattr(be, 'target_sums') and V.is_cuda and V.dtype == torch.float32 and V.dim() == 2
+                and V.stride(1) == 1):
+            out4 = target_stats(V, be)
+            st = torch.stack([out4[3].float(), out4[2].float(), (out4[1] / V.numel()).float(), W.max(), H.max(), W.mean(),
+                              H.mean()]).tolist()
+            inexact, vmax, vmean, wmax, hmax, wmean, hmean = st
+            in_range = max(vmax, wmax, hmax) <= cls.F16_MAX_ABS and min(vmean, wmean, hmean) >= cls.F16_MIN_MEAN
+            return in_range, not inexact
         bad = torch.zeros((), dtype=torch.bool, device=V.device)
         vmax = torch.zeros((), dtype=torch.float32, device=V.device)
         vsum = torch.zeros((), dtype=torch.float64, device=V.device)
@@ -462,7 +485,7 @@ class DenseMU(AsyncLossMixin):
         dims_ok = min(V.shape) >= cls.F16_MIN_DIM
         if group is None and not dims_ok:
             return None
-        in_range, exact = cls.f16_stats(V, W, H) if dims_ok else (False, False)
+        in_range, exact = cls.f16_stats(V, W, H, be) if dims_ok else (False, False)
         level = 2 if (in_range and exact) else (1 if in_range else 0)      # 2: f16, 1: f16x, 0: neither
         if level == 1 and not (hasattr(_capi, 'PREC_F16X') and be.supported(r_pad, _capi.PREC_F16X)
                                and os.environ.get('TORCHNMF_AMD_AUTO_F16X', '1') != '0'):
@@ -705,7 +728,7 @@ class DenseMU(AsyncLossMixin):
             return self._gram_step(self.step_w, 'w')
         if self._riding_pending:      # this half-step carries the loss of the checkpoint just begun (AsyncLossMixin)
             self._riding_pending = False
-            part, _, sums = self._riding['bufs']
+            part, sums = self._riding['bufs']
             ck = self._ck
             self.be.mu_step_with_loss(self.step_w, self.fH.colsum, part, sums, ck['stage'])
             ck['host'].copy_(ck['stage'], non_blocking=True)
@@ -804,8 +827,7 @@ class DenseMU(AsyncLossMixin):
                 or any(t.numel() % 4 or t.data_ptr() % 16 or not t.is_contiguous() for t in list(tens) + list(ck['snap']))):
             return False
         if rd['bufs'] is None:
-            rd['bufs'] = self.be.riding_alloc(self.step_w, tens[0].device)
-            self.be.target_sums(rd['V'], rd['bufs'][1], rd['bufs'][2])
+            rd['bufs'] = (self.be.riding_alloc(self.step_w, tens[0].device), target_stats(rd['V'], self.be).clone())
             rd['V'] = None                                  # (the engine does not keep the caller's target alive)
         # snapshots of (W, H) as they are now; the W half-step that follows does the rest
         for s_, t_ in zip(ck['snap'], tens):

@@ -686,6 +686,37 @@ def test_fused_loss_checkpoint_equals_the_generic_sequence(dev, monkeypatch, pre
     assert torch.equal(fits['1'][1], fits['0'][1]) and torch.equal(fits['1'][2], fits['0'][2])
 
 
+def test_target_stats_one_pass_matches_the_torch_passes(dev):
+    """Round 6: the admission test of precision='auto' asks its questions about V (max, fp16-exactness, mean) with ONE kernel
+    pass (nmfmu_target_sums) instead of ~7 GB of torch temporaries at configs[1]; the same pass leaves the two sums the riding
+    loss needs.  Same answers as the torch passes on exact / inexact / out-of-range / strided targets; sums against float64."""
+    from torchnmf_amd.engine import DenseMU, DEFAULT_BACKEND_FACTORY, target_stats, TARGET_STATS
+    be = DEFAULT_BACKEND_FACTORY()
+    g = torch.Generator().manual_seed(3)
+    W, H = (torch.rand(500, 8, generator=g) + 0.1).to(dev), (torch.rand(300, 8, generator=g) + 0.1).to(dev)
+    V = torch.rand(300, 500, generator=g)
+    big = torch.rand(300, 700, generator=g)
+    cases = {'plain': V, 'exact': V.half().float(), 'bf16': V.bfloat16().float(), 'counts': torch.randint(0, 2048, (300, 500), generator=g).float(),
+             'beyond': V.half().float() * 2.0 ** 17, 'tiny': V.half().float() * 2.0 ** -20, 'one_bad': V.half().float().index_put((torch.tensor([7]), torch.tensor([9])), torch.tensor(0.1)),
+             'strided': big[:, :500]}
+    for name, v in cases.items():
+        vd = v.to(dev) if name != 'strided' else big.to(dev)[:, :500]
+        assert (vd.stride(0) == 700) == (name == 'strided')
+        got = DenseMU.f16_stats(vd, W, H, be)
+        want = DenseMU.f16_stats(vd, W, H)
+        assert got == want, (name, got, want)
+        out4 = target_stats(vd, be).cpu()
+        v64 = v.double()
+        assert float(out4[1]) == pytest.approx(float(v64.sum()), rel=1e-9)
+        assert float(out4[0]) == pytest.approx(float((v64 * (v64 + 1e-8).log()).sum()), rel=2e-6, abs=1e-3)
+        assert float(out4[2]) == float(v.max())
+    # the memo follows the version counter: an in-place edit of V is seen
+    vd = cases['exact'].to(dev)
+    assert DenseMU.f16_stats(vd, W, H, be)[1] is True and TARGET_STATS['key'][0] == vd.data_ptr()
+    vd[3, 3] += 2.0 ** -15
+    assert DenseMU.f16_stats(vd, W, H, be)[1] is False
+
+
 @pytest.mark.parametrize('prec,shape', [('f16', (300, 1000, 20)), ('f16r', (300, 1000, 20)), ('f16', (1024, 2048, 64)),
                                         ('f16r', (2048, 4096, 128)), ('f16', (4096, 16384, 100))])
 def test_riding_loss_equals_the_loss_pass(dev, monkeypatch, prec, shape):
