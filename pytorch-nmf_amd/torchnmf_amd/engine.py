@@ -345,18 +345,20 @@ def mu_gamma(beta: float) -> float:
 
 
 # One-entry memo of nmfmu_target_sums: the admission test of 'auto' and the riding loss of the engine built right after it ask
-# about the same target (keyed by storage, version counter and geometry, so an in-place edit of V invalidates it).
-TARGET_STATS = {'key': None, 'out4': None}
+# about the same target.  Keyed by the tensor OBJECT (a weak reference: a new tensor that the caching allocator places at the
+# same address is another object) and its version counter (an in-place edit invalidates it).
+TARGET_STATS = {'ref': None, 'version': None, 'out4': None}
 
 
 def target_stats(V, be):
     """Device float64[4] = {sum x ln(x + eps), sum x, max x, any(x != fp16(x))} of the fp32 target V (one pass)."""
-    key = (V.data_ptr(), V._version, tuple(V.shape), V.stride(0), V.device)
-    if TARGET_STATS['key'] != key:
+    import weakref
+    ref = TARGET_STATS['ref']
+    if ref is None or ref() is not V or TARGET_STATS['version'] != V._version:
         part = torch.empty(4 * be.lib.nmfmu_target_sums_nparts(), dtype=torch.float64, device=V.device)
         out4 = torch.zeros(4, dtype=torch.float64, device=V.device)
         be.target_sums(V, part, out4)
-        TARGET_STATS['key'], TARGET_STATS['out4'] = key, out4
+        TARGET_STATS['ref'], TARGET_STATS['version'], TARGET_STATS['out4'] = weakref.ref(V), V._version, out4
     return TARGET_STATS['out4']
 
 

@@ -708,11 +708,21 @@ def test_target_stats_one_pass_matches_the_torch_passes(dev):
         out4 = target_stats(vd, be).cpu()
         v64 = v.double()
         assert float(out4[1]) == pytest.approx(float(v64.sum()), rel=1e-9)
-        assert float(out4[0]) == pytest.approx(float((v64 * (v64 + 1e-8).log()).sum()), rel=2e-6, abs=1e-3)
+        ref_a = float((v64 * (v.float() + torch.finfo(torch.float32).eps).double().log()).sum())      # (x + eps is an fp32 sum in the reference too)
+        assert float(out4[0]) == pytest.approx(ref_a, rel=2e-6, abs=1e-3), (name, float(out4[0]), ref_a)
         assert float(out4[2]) == float(v.max())
     # the memo follows the version counter: an in-place edit of V is seen
     vd = cases['exact'].to(dev)
-    assert DenseMU.f16_stats(vd, W, H, be)[1] is True and TARGET_STATS['key'][0] == vd.data_ptr()
+    assert DenseMU.f16_stats(vd, W, H, be)[1] is True and TARGET_STATS['ref']() is vd
+    # ... and the tensor OBJECT: another tensor at the same address (caching allocator) is not a hit
+    for _ in range(4):                                  # (whether or not the allocator hands the address out again)
+        del vd
+        vd = cases['plain'].to(dev)
+        assert DenseMU.f16_stats(vd, W, H, be)[1] is False
+        del vd
+        vd = cases['exact'].to(dev)
+        assert DenseMU.f16_stats(vd, W, H, be)[1] is True
+    vd = cases['exact'].to(dev)
     vd[3, 3] += 2.0 ** -15
     assert DenseMU.f16_stats(vd, W, H, be)[1] is False
 

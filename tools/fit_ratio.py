@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--iters', type=int, default=200)
 ap.add_argument('--beta', type=float, default=1.0)
 ap.add_argument('--toggle', default='TORCHNMF_AMD_RIDING_LOSS')
+ap.add_argument('--auto', action='store_true', help="one pass per target with precision='auto' (the admission test runs): whole call and loop")
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 N, C, R = 4096, 65536, 128
@@ -25,8 +26,8 @@ targets = {'exact': Vf.half().float(), 'plain': Vf}
 W0 = torch.rand(C, R, device=dev, generator=g) + 0.1
 H0 = torch.rand(N, R, device=dev, generator=g) + 0.1
 for kind, V in targets.items():
-    for rep in range(2):
-        for mode in ('1', '0'):
+    for rep in range(1 if a.auto else 2):
+        for mode in (('1',) if a.auto else ('1', '0')):
             os.environ[a.toggle] = mode
             ts = []
             for _ in range(3):
