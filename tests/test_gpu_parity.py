@@ -2495,7 +2495,7 @@ def test_software_pipelined_kernels_are_deterministic_under_load(dev, N, C, R, b
 
 
 @pytest.mark.parametrize('beta', [1, 0, 0.5, 1.5, 3])
-@pytest.mark.parametrize('shape', [(600, 2000, 100), (300, 700, 200), (200, 330, 24)])
+@pytest.mark.parametrize('shape', [(600, 2000, 100), (300, 700, 200), (200, 330, 24), (520, 1100, 48)])
 def test_half_steps_f16r_every_beta(dev, beta, shape):
     """precision='f16r' (round 6): fp16 operands, the target at THREE bytes per element -- the fp32 rounded to its top 24 bits,
     16 significant bits.  One iteration on plain fp32 floats (which fp16 would round) against the oracle ON THE UNROUNDED
