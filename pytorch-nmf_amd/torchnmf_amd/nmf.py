@@ -155,8 +155,21 @@ class BaseComponent(nn.Module):
         _require_device(W, 'fit')
         _require_device(H, 'fit')
         if W.dtype != torch.float32 or H.dtype != torch.float32:
-            raise NotImplementedError('factors must be float32 (the engine keeps fp32 masters and bf16 operand images); '
-                                      f'got W {W.dtype}, H {H.dtype}')
+            # The reference runs in whatever dtype the module was cast to (m.double(); nmf.py:216-221).  The engine's masters
+            # are fp32: fit on fp32 working copies of the factors and store the result in the module's dtype (round 6;
+            # float64 / float16 / bfloat16 modules -- against the reference in float64 the factors agree like the fp32 ones do).
+            if not (W.dtype.is_floating_point and H.dtype.is_floating_point):
+                raise NotImplementedError(f'factors must be floating point; got W {W.dtype}, H {H.dtype}')
+            keep = (W.data, H.data)
+            W.data, H.data = W.data.float().contiguous(), H.data.float().contiguous()
+            try:
+                return self.fit(V, beta, tol, max_iter, verbose, alpha, l1_ratio, precision=precision,
+                                process_group=process_group, allreduce=allreduce)
+            finally:
+                w32, h32 = W.data, H.data
+                W.data, H.data = keep
+                W.data.copy_(w32)
+                H.data.copy_(h32)
         if precision is None:
             precision = os.environ.get('TORCHNMF_AMD_PRECISION', 'auto')
         beta = float(beta)
@@ -292,7 +305,8 @@ class NMF(BaseComponent):
         _capi.check(lib.nmfmu_reconstruct(Hc.data_ptr(), Hc.shape[0], Wc.data_ptr(), Wc.shape[0], Hc.shape[1],
                                           out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream),
                     'nmfmu_reconstruct')
-        return out.reshape(lead + (Wc.shape[0],))
+        out = out.reshape(lead + (Wc.shape[0],))
+        return out if H.dtype == torch.float32 else out.to(H.dtype)      # (a module cast to another dtype answers in it)
 
     def _make_engine(self, V, beta, l1, l2, precision, group, allreduce=None):
         from .engine import DenseMU
