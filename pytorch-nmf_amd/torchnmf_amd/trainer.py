@@ -170,6 +170,9 @@ class BetaMu(Optimizer):
         BUFFERS (its source may have been edited in place without bumping anything we can see; the engine, its images
         and slabs are kept).  One engine per (target, W, H, beta, l1, l2): param groups with
         different hyper-parameters keep their own packed target instead of evicting each other."""
+        if W.dtype != torch.float32 or H.dtype != torch.float32:
+            raise NotImplementedError('BetaMu needs float32 factors (the update is applied in place to the parameters, whose '
+                                      f'storage is the engine\'s fp32 master); got W {W.dtype}, H {H.dtype}')
         key = (id(V_user), tuple(V.shape), W.data_ptr(), H.data_ptr(), float(beta), float(l1), float(l2))
         hit = self._engines.get(key)
         versions = [V_user._version, W._version, H._version]
