@@ -31,10 +31,11 @@
 //            saturate at 65504.  For beta < 1 the elementwise terms are negative powers of S and can sit at the
 //            bottom of fp16's range, so Gn and Gp are multiplied by a power of two derived from the factors' column
 //            sums (identical in every workgroup) before the conversion; the epilogue scales the accumulators back.
-//   f16r   : (round 6) as f16x at THREE bytes per element of X: an fp16 head h <= x (rounded toward zero) plus one byte u with
-//            x ~ h (1 + u 2^-18) -- 19 significant bits, a uniform RELATIVE step, so no per-tile scale.  The ratio stage
-//            multiplies its x-independent factor by (1 + u 2^-18) (two VALU per element) before the mixed multiply by h.
-//            beta != 2 (there the target is an MFMA operand itself: 'f16x' keeps its hi + lo pair).
+//   f16r   : (round 6) as f16x at THREE bytes per element of X: the fp32 rounded (nearest even) to its top 24 bits -- 16
+//            significant bits, fp32's range.  Bits 31..16 sit where the f16 layout has its 16-bit words, bits 15..8 in two
+//            more chunks per lane and tile; ONE v_perm_b32 per element rebuilds the fp32, the ratio stage then runs as for an
+//            fp32 target.  beta != 2 (there the target is an MFMA operand itself: 'f16x' keeps its hi + lo pair).  (A first
+//            form -- fp16 head + 8-bit relative residual -- needed four VALU per element to decode and lost to f16x.)
 //   f16x   : fp16 operands as above, but X stays fp32 in HBM (round 4) -- the target is never rounded, so the mode is
 //            parity-grade on data fp16 does not hold exactly (STFT magnitudes, plain floats) at 1x MFMA work; the X
 //            stream doubles (HBM-bound: 1.07 GB per half-step at configs[1]).  The ratio is formed in fp32 from the

@@ -419,7 +419,7 @@ def test_auto_precision_policy_on_the_standin_backend(cpu_engine, monkeypatch):
             return DenseMU(V, torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1, beta,
                            precision='auto', allow_f16=allow).precision_name
         assert pick(64, 80, 8) == 'f16'
-        assert pick(64, 80, 8, exact=False) == 'f16r'       # round 6: an inexact target keeps 19 bits (fp16 head + residual byte)
+        assert pick(64, 80, 8, exact=False) == 'f16r'       # round 6: an inexact target keeps its top 24 bits (3 bytes per element)
         assert pick(64, 80, 8, exact=False, beta=2.0) == 'f16x'   # beta == 2: the target is an MFMA operand, it stays fp32
         assert pick(64, 80, 8, allow=False) == 'bf16x3'
         assert pick(63, 80, 8) == 'bf16x3'
