@@ -867,11 +867,19 @@ def test_fit_smoke_like_reference(dev, beta, tol, alpha, l1_ratio):
     assert not torch.any(torch.isnan(m.W)) and not torch.any(torch.isnan(m.H))
 
 
-def test_fit_rejects_non_fp32_factors(dev):
+def test_fit_accepts_other_floating_dtypes_and_betamu_says_no(dev):
+    """Round 6: a module cast with .double() fits (test_fit_module_cast_to_another_dtype has the parity side) -- an fp32 target
+    is accepted beside float64 factors, as any target dtype is; BetaMu, which updates the parameters' own storage in place, says
+    clearly that it needs float32."""
     from torchnmf_amd.nmf import NMF
+    from torchnmf_amd.trainer import BetaMu
     m = NMF((20, 30), 4).double().to(dev)
-    with pytest.raises(NotImplementedError):
-        m.fit(torch.rand(20, 30, device=dev))
+    n = m.fit(torch.rand(20, 30, device=dev), max_iter=20)
+    assert 1 <= n <= 20 and m.W.dtype == torch.float64 and m.H.dtype == torch.float64
+    assert bool(torch.isfinite(m.W).all()) and bool((m.W >= 0).all())
+    V = torch.rand(20, 30, device=dev, dtype=torch.float64)
+    with pytest.raises(NotImplementedError, match='float32'):
+        BetaMu(m.parameters()).step(lambda: (V, m))
 
 
 def test_fit_error_behaviour(dev):
