@@ -973,8 +973,10 @@ def fit_leg(a, V, W0, H0, beta, precision, dev, engine_ms, cls_name='NMF'):
             'iters_per_s_whole_call': round(200e3 / wall, 1), 'iters_per_s_loop': round(200e3 / loop, 1),
             'ms_per_iter_loop': round(loop / 200, 4), 'engine_step_ms': round(engine_ms, 4),
             'loop_over_engine_step': round(loop / 200 / engine_ms, 4),
-            'note': 'loop = 200 MU iterations + 20 loss evaluations with their host syncs (nmf.py:393-407); setup = packing V in '
-                    'both orientations, validation flags, precision admission test, initial loss'}
+            'note': 'loop = 200 MU iterations + the 19 loss checkpoints of nmf.py:393-407 (no host sync; beta == 1 on the ping-pong '
+                    'kernel: the loss rides in the W half-step behind the checkpoint, otherwise one loss pass each) in ONE cold call, '
+                    'against engine_step_ms from long pre-rolled blocks; setup = packing V in both orientations, validation '
+                    'flags, precision admission test (one kernel pass), initial loss'}
 
 
 def ref_notebook_leg(a, dev, do_cpu):
