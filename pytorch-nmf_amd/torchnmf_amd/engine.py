@@ -179,8 +179,9 @@ class HipBackend:
         n = self.lib.nmfmu_riding_loss_part_count(C.byref(st.struct))
         return torch.empty(n, dtype=torch.float32, device=device)
 
-    def target_sums(self, V, part, out2):
-        _capi.check(self.lib.nmfmu_target_sums(_ptr(V), V.stride(0), V.shape[0], V.shape[1], _ptr(part), _ptr(out2), self.stream()),
+    def target_sums(self, V, part, out4):
+        """out4 (device float64[4]) = {sum x ln(x + eps), sum x, max x, any(x != fp16(x))} of the fp32 target, one pass."""
+        _capi.check(self.lib.nmfmu_target_sums(_ptr(V), V.stride(0), V.shape[0], V.shape[1], _ptr(part), _ptr(out4), self.stream()),
                     'nmfmu_target_sums')
 
     def mu_step_with_loss(self, st, kl_den, xlogs_part, target_sums, out2):
@@ -825,8 +826,7 @@ class DenseMU(AsyncLossMixin):
 
     def _checkpoint_riding(self, ck, tens) -> bool:
         rd = self._riding
-        if (rd is None or len(tens) != 2
-                or any(t.numel() % 4 or t.data_ptr() % 16 or not t.is_contiguous() for t in list(tens) + list(ck['snap']))):
+        if rd is None:
             return False
         if rd['bufs'] is None:
             rd['bufs'] = (self.be.riding_alloc(self.step_w, tens[0].device), target_stats(rd['V'], self.be).clone())
