@@ -1562,6 +1562,22 @@ def test_sharded_path_world1_rccl(dev):
         for r in res[1:]:
             assert rel_err(r[0], res[0][0]) < 1e-4 and rel_err(r[1], res[0][1]) < 1e-4
             assert r[2] == pytest.approx(res[0][2], rel=1e-5)
+        # (round 6) the 3-byte target on the sharded path: the same partial-sum kernels (ping-pong instance with six X pieces per
+        # tile), row halves, packed all-reduce and apply -- against the single-device engine on the same plain-float target
+        Vr = torch.rand(700, 2100, generator=gg).to(dev)
+        res = []
+        for grp, overlap in ((None, '1'), (dist.group.WORLD, '1'), (dist.group.WORLD, '0'), (dist.group.WORLD, 'direct')):
+            os.environ['TORCHNMF_AMD_AR_OVERLAP'] = '0' if overlap == 'direct' else overlap
+            W, H = Wb.clone().to(dev), Hb.clone().to(dev)
+            eng = DenseMU(Vr, W, H, 1.0, precision='f16r', group=grp, ar_direct=(overlap == 'direct') if grp is not None else None)
+            assert eng.precision_name == 'f16r' and eng.step_h.block_rows == 256
+            for _ in range(3):
+                eng.w_step()
+                eng.h_step()
+            res.append((W.cpu(), H.cpu(), eng.divergence()))
+        for r in res[1:]:
+            assert rel_err(r[0], res[0][0]) < 1e-4 and rel_err(r[1], res[0][1]) < 1e-4
+            assert r[2] == pytest.approx(res[0][2], rel=1e-5)
         # the same row halves with numerator AND denominator slabs (beta = 2), fp32-grade mode, against the oracle
         os.environ['TORCHNMF_AMD_AR_OVERLAP'] = '1'
         Vc, Wc, Hc = Vb.cpu()[:, :500], Wb[:500, :24], Hb[:, :24]

@@ -1,3 +1,3 @@
 #!/bin/bash
-# round 6: quick regression of the loss-checkpoint paths
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "riding or fused_loss or early_stop or another_dtype or other_floating" 2>&1 | tail -6
+# round 6: quick regression of one or two tests
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "sharded_path_world1_rccl" 2>&1 | tail -12
