@@ -1,3 +1,4 @@
 #!/bin/bash
-# round 6: quick regression of one or two tests
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "sharded_path_world1_rccl" 2>&1 | tail -12
+# round 6: per-workgroup timeline of the ping-pong kernel at configs[1] (same stamps, same script as the rank-256 kernel)
+OUT=gpurun_out/r6w; mkdir -p $OUT
+timeout 600 python tools/sp_timeline.py --rows 4096 --cols 65536 --rank 128 --iters 30 2>&1 | grep -v amdgpu.ids | tee $OUT/pp_timeline_cfg1.txt
