@@ -84,6 +84,11 @@ extern "C" {
 /* how the panel tile reaches LDS */
 #define NMFMU_STAGE_REG 0 /* global -> VGPR -> ds_write: no longer built, NMFMU_ERR_UNSUPPORTED */
 #define NMFMU_STAGE_DMA 1 /* global_load_lds (LDS-DMA)  */
+#define NMFMU_STAGE_DMA_NOP2 3 /* (ABI 9) as NMFMU_STAGE_DMA, and the caller promises that NOTHING reads the transposed images (p2_*) of
+                                  this step's factors: where the step's kernel does not read the panel's p2 itself -- beta == 1 at
+                                  padded rank 256 with fp16 operands (the software-pipelined kernel: ONE image + transposing LDS
+                                  reads) -- the fused apply / nmfmu_mu_apply no longer refresh the owner's p2 (64 of the 384 KiB a
+                                  workgroup's epilogue moves).  Everywhere else it behaves as NMFMU_STAGE_DMA */
 #define NMFMU_STAGE_DMA_SPLIT 2 /* as NMFMU_STAGE_DMA, and panel.p1_* / panel.p2_* are images of DIFFERENT matrices (PLCA: the
                                    Z-scaled factor for the reconstruction, the unscaled one for the second GEMM).  Since ABI 6
                                    the single-plane four-wave kernels stage ONE panel image and gather the second GEMM's

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(NT) apply_kernel(ApplyArgs a) {
   if (a.f16 && a.status && __any(clamped) && (tid & 63) == 0) atomicOr(a.status, 1u);
   // P2: [R_PAD][64] tiles; this block owns ROWS/8 of the 8 slots (8 consecutive factor rows each) of every rank row
   constexpr int NS = ROWS / 8;
-  for (int idx = tid; idx < R_PAD * NS; idx += NT) {
+  for (int idx = tid; idx < (a.p2_hi ? R_PAD * NS : 0); idx += NT) {   // (p2_hi == nullptr: NMFMU_STAGE_DMA_NOP2, nobody reads it)
     const int r = idx / NS, sl = idx - r * NS;
     u32x4 hi, lo;
 #pragma unroll

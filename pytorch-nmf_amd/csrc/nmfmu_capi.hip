@@ -84,7 +84,8 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
   if (!st->xp && (mode == kModeMU || mode == kModeXB)) return NMFMU_ERR_ARG;   // (the denominator-only pass and the loss may run without a target)
   if (st->owner.rows_pad % kRowPad || st->panel.rows_pad % kRowPad) return NMFMU_ERR_ARG;
   if (st->block_rows != 128 && st->block_rows != 256) return NMFMU_ERR_ARG;
-  if (st->stage != NMFMU_STAGE_DMA && st->stage != NMFMU_STAGE_DMA_SPLIT) return NMFMU_ERR_UNSUPPORTED;   // (register staging: no longer built)
+  if (st->stage != NMFMU_STAGE_DMA && st->stage != NMFMU_STAGE_DMA_SPLIT && st->stage != NMFMU_STAGE_DMA_NOP2)
+    return NMFMU_ERR_UNSUPPORTED;   // (register staging: no longer built)
   // split panel (PLCA: p1 = the Z-scaled factor, p2 = the unscaled one): the instantiation that stages BOTH images
   if (st->stage == NMFMU_STAGE_DMA_SPLIT && mode == kModeMU && !(st->precision == NMFMU_PREC_BF16X3)) {
     if (nmfmu_beta_kind(st->beta) != NMFMU_BETA_KL || st->block_rows != 128) return NMFMU_ERR_UNSUPPORTED;
@@ -163,6 +164,7 @@ int fused_dispatch(const nmfmu_step* st, int mode, float* loss_part, int M, int 
 #ifdef NMFMU_DEBUG_HOOKS
     if (g_pp_debug) a.debug = g_pp_debug;
 #endif
+    if (st->stage == NMFMU_STAGE_DMA_NOP2) a.o2_hi = nullptr;   // nobody reads the owner's transposed image: the epilogue skips it
     return launch_sp(st->r_pad, kOpF16, a, grid, s);
   }
   if (mode == kModeMU && sp2_eligible(st->r_pad, st->precision, st->beta)) {
@@ -393,6 +395,7 @@ static int apply_common(const nmfmu_step* st, const float* num, const float* den
   a.f16 = is_f16(st->precision);
   a.status = st->status;
   if (!a.p1_hi || !a.p2_hi || !a.colsum || !a.colsum_part) return NMFMU_ERR_ARG;
+  if (st->stage == NMFMU_STAGE_DMA_NOP2 && sp_eligible(st->r_pad, st->precision, st->beta)) a.p2_hi = a.p2_lo = nullptr;   // (see nmfmu.h)
   return launch_apply(st->r_pad, a, st->precision == NMFMU_PREC_BF16X3, /*pack_only=*/false, S(stream));
 }
 

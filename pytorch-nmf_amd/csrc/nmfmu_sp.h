@@ -425,8 +425,10 @@ __global__ void __launch_bounds__(256, 1) sp_kernel(const FusedArgs a) {
         }
         *reinterpret_cast<float4*>(frow) = *reinterpret_cast<const float4*>(fv);
         *reinterpret_cast<float4*>(frow + 4) = *reinterpret_cast<const float4*>(fv + 4);
-        *reinterpret_cast<float4*>(trow) = *reinterpret_cast<const float4*>(fv);
-        *reinterpret_cast<float4*>(trow + 4) = *reinterpret_cast<const float4*>(fv + 4);
+        if (a.o2_hi) {   // (the updated tile feeds the transposed image only)
+          *reinterpret_cast<float4*>(trow) = *reinterpret_cast<const float4*>(fv);
+          *reinterpret_cast<float4*>(trow + 4) = *reinterpret_cast<const float4*>(fv + 4);
+        }
         u32x4 hi;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) hi[qq] = pack_op<OPT>(fv[2 * qq], fv[2 * qq + 1]);
@@ -485,6 +487,9 @@ __global__ void __launch_bounds__(256, 1) sp_kernel(const FusedArgs a) {
     if (a.status && __any(clamped) && lane_e == 0) atomicOr(a.status, 1u);
     __syncthreads();
     // transposed image from the updated tile: 8 consecutive owner rows of one rank = one sixteen-byte slot
+    // (a.o2_hi == nullptr -- NMFMU_STAGE_DMA_NOP2: nothing reads this factor's transposed image, this kernel's own GEMM2 gathers
+    // from the row-major one -- skips the pass: 5.8 of the epilogue's 21 us, profiles/r06_sp_epilogue_ablations.txt)
+    if (a.o2_hi)
 #pragma unroll
     for (int ii = 0; ii < R_PAD / 64; ++ii) {
       const int r = ii * 64 + lane_e;

@@ -20,6 +20,7 @@ ERR_ARG = -3
 ERR_ALLOC = -4
 PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16X, PREC_F16R = 0, 1, 2, 3, 4
 STAGE_REG, STAGE_DMA, STAGE_DMA_SPLIT = 0, 1, 2
+STAGE_DMA_NOP2 = 3          # as STAGE_DMA; nothing reads the factors' transposed images (include/nmfmu.h)
 BETA_KL, BETA_EUC, BETA_IS, BETA_GEN = 0, 1, 2, 3
 KERNEL_FUSED, KERNEL_PP, KERNEL_SP = 0, 1, 2
 

@@ -549,7 +549,13 @@ class DenseMU(AsyncLossMixin):
         if not self.be.supported(self.r_pad, self.precision):
             raise NotImplementedError(f'precision {precision!r} is not available for rank {R} (padded {self.r_pad})')
         if stage is None:
-            stage = _capi.STAGE_DMA
+            # (round 6) beta == 1 at padded rank 256 with fp16 operands runs the software-pipelined kernel in BOTH half-steps and
+            # for the loss: ONE image per factor, GEMM2's operand gathered from it -- nothing reads the transposed images, so
+            # nobody has to keep them up to date (NMFMU_STAGE_DMA_NOP2: 17 % less epilogue traffic)
+            nop2 = (hasattr(self.be, 'kernel_family') and hasattr(_capi, 'STAGE_DMA_NOP2') and float(beta) == 1.0
+                    and self.r_pad == 256 and self.be.kernel_family(self.r_pad, self.precision, float(beta)) == _capi.KERNEL_SP
+                    and os.environ.get('TORCHNMF_AMD_NO_P2', '1') != '0')
+            stage = _capi.STAGE_DMA_NOP2 if nop2 else _capi.STAGE_DMA
         # beta == 2 without the reconstruction (nmf.py:61-63 has no eps inside its grad_outputs): numerator = one streaming
         # GEMM over X, denominator through the panel's rank x rank Gram matrix -- a third of the MFMA work, HBM-bound.
         # fit()'s engines only (allow_gram): BetaMu reads numerator AND denominator slabs (p.grad = pos - neg).

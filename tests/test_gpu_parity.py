@@ -686,6 +686,37 @@ def test_fused_loss_checkpoint_equals_the_generic_sequence(dev, monkeypatch, pre
     assert torch.equal(fits['1'][1], fits['0'][1]) and torch.equal(fits['1'][2], fits['0'][2])
 
 
+def test_rank256_kl_does_not_keep_the_transposed_images(dev, monkeypatch):
+    """Round 6 (NMFMU_STAGE_DMA_NOP2): beta == 1 at padded rank 256 with fp16 operands runs the software-pipelined kernel in
+    both half-steps and the four-wave loss kernel -- one image per factor, GEMM2's operand gathered from it.  Nothing reads the
+    transposed images, so the engine stops refreshing them (5.8 of the fused-apply epilogue's 21 us).  Proof by poison: with both
+    transposed images overwritten by NaN bit patterns after packing, three iterations and the loss give bit-identical results to
+    an engine that keeps them (TORCHNMF_AMD_NO_P2=0); the poisoned images are still poison afterwards, the kept ones are not.
+    Both the unsplit (fused apply) and the split (apply kernel) W half-step."""
+    from torchnmf_amd import _capi
+    from torchnmf_amd.engine import DenseMU
+    for N, C, R in ((300, 2300, 200), (2048, 1200, 256)):
+        g = torch.Generator().manual_seed(N + R)
+        V = torch.rand(N, C, generator=g).half().float().to(dev)
+        W0, H0 = torch.rand(C, R, generator=g) + 0.1, torch.rand(N, R, generator=g) + 0.1
+        out = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('TORCHNMF_AMD_NO_P2', mode)
+            W, H = W0.clone().to(dev), H0.clone().to(dev)
+            eng = DenseMU(V, W, H, 1.0, precision='f16')
+            assert (eng.step_h.struct.stage == _capi.STAGE_DMA_NOP2) == (mode == '1')
+            for fac in (eng.fW, eng.fH):
+                fac.p2_hi.view(torch.int16).fill_(0x7e00)          # fp16 NaN in every slot
+            for _ in range(3):
+                eng.w_step(), eng.h_step()
+            loss = eng.divergence()
+            poisoned = [bool((fac.p2_hi.view(torch.int16) == 0x7e00).all()) for fac in (eng.fW, eng.fH)]
+            assert poisoned == [mode == '1'] * 2, (mode, poisoned)
+            out[mode] = (W.cpu().clone(), H.cpu().clone(), loss)
+            assert bool(torch.isfinite(W).all()) and bool(torch.isfinite(H).all())
+        assert torch.equal(out['1'][0], out['0'][0]) and torch.equal(out['1'][1], out['0'][1]) and out['1'][2] == out['0'][2]
+
+
 def test_target_stats_one_pass_matches_the_torch_passes(dev):
     """Round 6: the admission test of precision='auto' asks its questions about V (max, fp16-exactness, mean) with ONE kernel
     pass (nmfmu_target_sums) instead of ~7 GB of torch temporaries at configs[1]; the same pass leaves the two sums the riding

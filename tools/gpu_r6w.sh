@@ -1,4 +1,3 @@
 #!/bin/bash
-# round 6: per-workgroup timeline of the ping-pong kernel at configs[1] (same stamps, same script as the rank-256 kernel)
-OUT=gpurun_out/r6w; mkdir -p $OUT
-timeout 600 python tools/sp_timeline.py --rows 4096 --cols 65536 --rank 128 --iters 30 2>&1 | grep -v amdgpu.ids | tee $OUT/pp_timeline_cfg1.txt
+# round 6: quick regression of selected tests
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "rank256 or cfg5 or r256 or deterministic or transposed_images or sharded_path or riding or betamu_auto" 2>&1 | grep -E "passed|failed|^E |Error" | tail -8
