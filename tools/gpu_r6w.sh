@@ -1,3 +1,4 @@
 #!/bin/bash
-# round 6: quick regression of selected tests
-timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "rank256 or cfg5 or r256 or deterministic or transposed_images or sharded_path or riding or betamu_auto" 2>&1 | grep -E "passed|failed|^E |Error" | tail -8
+# round 6: per-workgroup timeline of the two-accumulator pipelined kernel at configs[2] (beta = 0.5)
+OUT=gpurun_out/r6w; mkdir -p $OUT
+timeout 600 python tools/sp_timeline.py --rows 4096 --cols 65536 --rank 128 --beta 0.5 --iters 20 2>&1 | grep -v amdgpu.ids | tee $OUT/sp2_timeline_cfg2.txt

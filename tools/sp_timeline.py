@@ -5,7 +5,7 @@ include/nmfmu.h): this script runs the W half-step (2 048 workgroups of 128 tile
 workgroup per CU) and the H half-step (256 workgroups of 1 024 tiles, slab stores) back to back and prints where a launch's
 time goes: prologue / loop / epilogue per workgroup, the dead time between two workgroups on the same CU, the rounds.
 
-    python tools/sp_timeline.py [--rows 8192 --cols 262144 --rank 256] [--iters 12]
+    python tools/sp_timeline.py [--rows 8192 --cols 262144 --rank 256] [--iters 12] [--beta 1] [--precision f16]
 """
 import argparse
 import os
@@ -23,13 +23,15 @@ ap.add_argument('--rows', type=int, default=8192)
 ap.add_argument('--cols', type=int, default=262144)
 ap.add_argument('--rank', type=int, default=256)
 ap.add_argument('--iters', type=int, default=12)
+ap.add_argument('--beta', type=float, default=1.0)
+ap.add_argument('--precision', default='f16')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev).manual_seed(5)
-V = torch.rand(a.rows, a.cols, device=dev, generator=g).half().float()
+V = torch.rand(a.rows, a.cols, device=dev, generator=g).half().float().clamp(min=2.0 ** -7 if a.beta <= 0 else 0.0)
 W = torch.rand(a.cols, a.rank, device=dev, generator=g) + 0.1
 H = torch.rand(a.rows, a.rank, device=dev, generator=g) + 0.1
-eng = DenseMU(V, W, H, 1.0, precision='f16')
+eng = DenseMU(V, W, H, a.beta, precision=a.precision)
 del V
 
 
@@ -49,6 +51,9 @@ def timeline(st, step, name):
     finally:
         st.struct.stamps = None
     v = buf[64:].cpu().numpy().reshape(nwg, 5)
+    if not v.any():
+        print(f'== {name}: this half-step\'s kernel records no stamps (only the ping-pong and the rank-256 pipelined kernel do)')
+        return 0.0
     t = (v[:, :4] - v[:, 2].min()) / 100.0              # us since the first entry; columns: loop start, loop end, entry, exit
     start, end, entry, exit_ = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
     where = v[:, 4]
